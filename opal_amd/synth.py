@@ -1,0 +1,94 @@
+"""Deterministic synthetic protein database / query generator.
+
+Counter-based splitmix64 (no libc rand, no numpy RandomState): element i of a
+stream with seed s is mix(s + (i+1)*GOLDEN), so generation is vectorised and
+any slice can be produced independently (ranks of a multi-GPU run generate
+disjoint shards of the same database without talking to each other).
+
+Lengths: L = clamp(30, 5000, round(exp(5.70 + 0.55*z))), z = Box-Muller normal
+-> median ~299, mean ~348 (UniProt-like log-normal, BASELINE.json "~350 aa").
+Residues: the 20 standard amino acids drawn from Swiss-Prot background
+frequencies, encoded in BLOSUM50 alphabet order ``ARNDCQEGHILKMFPSTWYVBZX*``.
+"""
+import numpy as np
+
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+# percent, in the order of _AA below (Swiss-Prot release statistics, rounded as in SURVEY.md 8d)
+_AA = "LAGVESIKRDTPNQFYMHCW"
+_PCT = [9.9, 8.3, 7.1, 6.9, 6.8, 6.6, 5.9, 5.8, 5.5, 5.5, 5.3, 4.7, 4.1, 3.9, 3.9, 2.9, 2.4, 2.3, 1.4, 1.1]
+_BLOSUM_ORDER = "ARNDCQEGHILKMFPSTWYVBZX*"
+
+
+def splitmix64(seed, start, count):
+    """uint64[count]: outputs start .. start+count-1 of the stream `seed`."""
+    with np.errstate(over="ignore"):
+        i = np.arange(start + 1, start + count + 1, dtype=np.uint64)
+        z = np.uint64(seed) + i * _GOLDEN
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        return z ^ (z >> np.uint64(31))
+
+
+def _uniform(seed, start, count):
+    """float64 in (0,1): top 53 bits, offset by half an ulp so log() is finite."""
+    return ((splitmix64(seed, start, count) >> np.uint64(11)).astype(np.float64) + 0.5) / 9007199254740992.0
+
+
+def _residue_table():
+    cdf = np.cumsum(np.array(_PCT, dtype=np.float64))
+    cdf /= cdf[-1]
+    codes = np.array([_BLOSUM_ORDER.index(a) for a in _AA], dtype=np.uint8)
+    return cdf, codes
+
+
+def lengths(seed, first, count):
+    """int32[count]: lengths of sequences first .. first+count-1 of database `seed`."""
+    u1 = _uniform(seed, 2 * first, 2 * count)
+    z = np.sqrt(-2.0 * np.log(u1[0::2])) * np.cos(2.0 * np.pi * u1[1::2])
+    return np.clip(np.rint(np.exp(5.70 + 0.55 * z)), 30, 5000).astype(np.int32)
+
+
+def _residues(seed, start, count):
+    cdf, codes = _residue_table()
+    u = _uniform(seed ^ 0x5851F42D4C957F2D, start, count)
+    return codes[np.minimum(np.searchsorted(cdf, u, side="right"), len(codes) - 1)]
+
+
+def database(num_seqs, seed=42, first=0):
+    """Sequences first .. first+num_seqs-1 of the synthetic database `seed`.
+
+    Returns (residues:uint8[sum L], offsets:int64[num_seqs+1], lens:int32[num_seqs]); sequence j is
+    residues[offsets[j]:offsets[j+1]]. Residue k of sequence g (global index) is element g*5000 + k
+    of the residue stream, so shards are independent of how the database is cut.
+    """
+    lens = lengths(seed, first, num_seqs)
+    offsets = np.zeros(num_seqs + 1, dtype=np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    total = int(offsets[-1])
+    cdf, codes = _residue_table()
+    out = np.empty(total, dtype=np.uint8)
+    rseed = np.uint64(seed ^ 0x5851F42D4C957F2D)
+    batch = 512  # sequences per step: temporaries stay a few MB (fresh pages are slow to fault in)
+    for a in range(0, num_seqs, batch):
+        b = min(a + batch, num_seqs)
+        ln = lens[a:b]
+        n = int(offsets[b] - offsets[a])
+        seq_of = np.repeat(np.arange(a, b, dtype=np.int64), ln)
+        pos = np.arange(n, dtype=np.int64) - (offsets[a:b] - offsets[a])[seq_of - a]
+        c = ((seq_of + first) * 5000 + pos).astype(np.uint64)
+        with np.errstate(over="ignore"):
+            z = rseed + (c + np.uint64(1)) * _GOLDEN
+            z = (z ^ (z >> np.uint64(30))) * _M1
+            z = (z ^ (z >> np.uint64(27))) * _M2
+            z = z ^ (z >> np.uint64(31))
+        u = ((z >> np.uint64(11)).astype(np.float64) + 0.5) / 9007199254740992.0
+        out[offsets[a]:offsets[b]] = codes[np.minimum(np.searchsorted(cdf, u, side="right"), len(codes) - 1)]
+    return out, offsets, lens
+
+
+def query(length, seed=7):
+    """uint8[length] synthetic query drawn from the same background distribution."""
+    return _residues(seed, 0, length)

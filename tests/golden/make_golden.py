@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the reference itself.
+
+Runs ONLY in the build container: it loads oracle/_ref/libopal_ref.so, i.e. the
+reference's own SSE4.1/AVX2 library compiled by oracle/build_ref.sh from
+/root/reference/src/opal.cpp, and records its outputs (score, endQ, endT per
+database sequence) for
+  * the reference's bundled test_data (copied as data fixtures to tests/golden/data/),
+  * seeded synthetic protein sets (opal_amd.synth),
+  * test.cpp-style random 4-letter sets that force the 8->16 bit escalation,
+  * small known-answer cases (README example, escalation pins).
+Every gap setting runs in a fresh process (the reference freezes a static local at the
+first call's gapExt, opal.cpp:604). Inputs are either files in tests/golden/data or
+regenerated from seeds; a sha1 of the input residues is stored to catch generator drift.
+
+Usage: python tests/golden/make_golden.py            (writes tests/golden/*.json / *.npz)
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from opal_amd import synth  # noqa: E402
+from opal_amd.fasta import read_fasta  # noqa: E402
+from opal_amd.score_matrix import blosum50, simple_matrix  # noqa: E402
+import cases  # noqa: E402  (tests/cases.py: the shared case definitions)
+
+
+def sha1(seqs):
+    h = hashlib.sha1()
+    for s in seqs:
+        h.update(np.ascontiguousarray(s, dtype=np.uint8).tobytes())
+        h.update(b"|")
+    return h.hexdigest()
+
+
+def run_case(case_name):
+    """Executed in a child process: run one case through the reference, print JSON."""
+    import oracle_lib
+    ref = oracle_lib.RefLib()
+    case = cases.CASES[case_name]
+    query, seqs, matrix = cases.materialise(case)
+    out = {"name": case_name, "input_sha1": sha1([query] + list(seqs)), "runs": {}}
+    for mode in case["modes"]:
+        rc, score, eq, et, sset, _ = ref.search(query, seqs, case["gap_open"], case["gap_ext"], matrix,
+                                                case["search_type"], oracle_lib.MODES[mode],
+                                                case.get("overflow", oracle_lib.OVERFLOW_BUCKETS))
+        out["runs"][mode] = {"rc": int(rc), "score": score.tolist(), "endQ": eq.tolist(), "endT": et.tolist()}
+    if case.get("char_sw"):
+        rc, score, sset = ref.char_sw(query, seqs, case["gap_open"], case["gap_ext"], matrix)
+        out["char_sw"] = {"rc": int(rc), "score": score.tolist(), "scoreSet": sset.tolist()}
+    json.dump(out, sys.stdout)
+
+
+def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--case":
+        run_case(sys.argv[2])
+        return
+    small, big = {}, {}
+    for name, case in cases.CASES.items():
+        if not case.get("golden", True):
+            continue
+        txt = subprocess.check_output([sys.executable, __file__, "--case", name])
+        res = json.loads(txt)
+        print(name, {m: (r["rc"], max(r["score"]) if r["score"] else None) for m, r in res["runs"].items()})
+        if case.get("store") == "npz":
+            meta = {"input_sha1": res["input_sha1"], "rc": {m: r["rc"] for m, r in res["runs"].items()}}
+            big[name + "/meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+            for m, r in res["runs"].items():
+                for k in ("score", "endQ", "endT"):
+                    big[f"{name}/{m}/{k}"] = np.array(r[k], dtype=np.int32)
+        else:
+            small[name] = res
+    with open(os.path.join(HERE, "golden_small.json"), "w") as fh:
+        json.dump(small, fh, separators=(",", ":"), sort_keys=True)
+    np.savez_compressed(os.path.join(HERE, "golden_synth.npz"), **big)
+    print("wrote", len(small), "json cases,", len(big), "npz arrays")
+
+
+if __name__ == "__main__":
+    main()
