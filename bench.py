@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- GCUPS of the database-search hot path on MI355X (driver contract in the task prompt).
+
+A "step" is one pass of the hot path over one batch: one 300-residue query against the whole
+synthetic protein database shard of this rank (BASELINE.json configs[1]: 100 000 sequences,
+~350 aa, Smith-Waterman score-only), database already packed and resident in HBM, scores written
+to a device buffer in caller order. With N GPUs every rank owns its own 100 000-sequence shard of
+the same synthetic database (weak scaling, no data-path collective) and the per-sequence scores are
+collected on rank 0 with ONE RCCL gather per step, inside the timed region.
+
+GCUPS = queryLength * sum(dbSeqLengths) / 1e9 / seconds (reference src/opal_aligner.cpp:203-207;
+cells of overflow re-runs are not counted).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+
+
+def cpu_baseline(query, res, offs, lens, matrix, gap_open, gap_ext, budget_s=20.0):
+    """The reference's own AVX2 path (oracle/_ref/libopal_ref.so, built from /root/reference in the
+    build container) timed on this host; falls back to the scalar oracle port if it is absent."""
+    import oracle_lib
+    n_all = len(lens)
+    cores = os.cpu_count() or 1
+    if oracle_lib.have_ref():
+        ref = oracle_lib.RefLib()
+        # 1 thread, the reference's own methodology (aligner_comparison.md:11): bounded sample
+        n = min(n_all, 30000)
+        seqs = [res[offs[i]:offs[i + 1]] for i in range(n)]
+        cells = float(len(query)) * float(offs[n])
+        t0 = time.perf_counter()
+        rc, *_ = ref.search(query, seqs, gap_open, gap_ext, matrix, 0, 3, 1)
+        t1 = time.perf_counter() - t0
+        one = cells / t1 / 1e9
+        # all host cores: contiguous shards, one thread per core (ctypes releases the GIL)
+        nt = min(cores, 64)
+        n2 = min(n_all, max(n, int(n * min(nt, budget_s / max(t1, 1e-3)))))
+        seqs2 = [res[offs[i]:offs[i + 1]] for i in range(n2)]
+        bounds = np.linspace(0, n2, nt + 1).astype(int)
+        threads = [threading.Thread(target=ref.search, args=(query, seqs2[bounds[t]:bounds[t + 1]], gap_open, gap_ext,
+                                                             matrix, 0, 3, 1)) for t in range(nt)]
+        t0 = time.perf_counter()
+        for th in threads: th.start()
+        for th in threads: th.join()
+        tall = time.perf_counter() - t0
+        allc = float(len(query)) * float(offs[n2]) / tall / 1e9
+        return {"value": round(allc, 3), "unit": "GCUPS", "cores": nt, "kind": "reference",
+                "sample": f"first {n2} of {n_all} sequences, {nt} threads; 1 thread on first {n}: {one:.3f} GCUPS",
+                "one_thread_value": round(one, 3)}
+    orc = oracle_lib.Oracle()
+    n = min(n_all, 400)
+    seqs = [res[offs[i]:offs[i + 1]] for i in range(n)]
+    t0 = time.perf_counter()
+    orc.search(query, seqs, gap_open, gap_ext, matrix, 0, 3)
+    t1 = time.perf_counter() - t0
+    return {"value": round(float(len(query)) * float(offs[n]) / t1 / 1e9, 4), "unit": "GCUPS", "cores": 1, "kind": "port",
+            "sample": f"scalar oracle on the first {n} sequences"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--seqs", type=int, default=100000, help="database sequences per GPU")
+    ap.add_argument("--qlen", type=int, default=300)
+    ap.add_argument("--gap-open", type=int, default=11)
+    ap.add_argument("--gap-ext", type=int, default=1)
+    ap.add_argument("--mode", default="SW")
+    ap.add_argument("--search-type", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the measured path)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from opal_amd import synth
+    from opal_amd.api import MODES, PreparedDb
+    from opal_amd.score_matrix import blosum50
+
+    n = args.seqs
+    res, offs, lens = synth.database(n, seed=42, first=rank * n)  # this rank's shard of the same database
+    query = synth.query(args.qlen, seed=7)
+    matrix = blosum50()[1]
+    mode = MODES[args.mode]
+    pdb = PreparedDb(res, offs)
+    cells = float(args.qlen) * float(offs[-1])
+
+    dev = torch.device("cuda", local)
+    score = torch.zeros(n, dtype=torch.int32, device=dev)
+    endq = torch.zeros(n, dtype=torch.int32, device=dev) if args.search_type else None
+    endt = torch.zeros(n, dtype=torch.int32, device=dev) if args.search_type else None
+    gathered = [torch.empty_like(score) for _ in range(world)] if (world > 1 and rank == 0) else None
+    kernel_ms = []
+
+    def step():
+        rc, kms = pdb.search_device(query, args.gap_open, args.gap_ext, matrix, args.search_type, mode, score.data_ptr(),
+                                    endq.data_ptr() if endq is not None else 0, endt.data_ptr() if endt is not None else 0)
+        if rc != 0:
+            raise SystemExit(f"search failed rc={rc}")
+        kernel_ms.append(kms)
+        if world > 1:
+            dist.gather(score, gathered, dst=0)  # the path's only exchange: per-sequence results to rank 0
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms.clear()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tcells = torch.tensor([cells], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tcells, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    total_cells = float(tcells.item())
+
+    if rank == 0:
+        gcups = total_cells * args.steps / dt / 1e9
+        kms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+        # roofline of the dominant kernel (the width-16 DP kernel), per launch: algorithmic bytes =
+        # 4*w bytes per cell (read H,E + write H,E of a column-streaming design), w = 2
+        alg_bytes = cells * 8.0
+        achieved = alg_bytes / (kms * 1e-3) / 1e9
+        kernel_gcups = cells / (kms * 1e-3) / 1e9
+        out = {
+            "metric": "GCUPS (DP cell updates/s), SW score-only, 1 query vs synthetic protein DB",
+            "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "i16", "data": "synthetic",
+            "config": {"workload": f"{args.qlen}-aa query (seed 7) vs {n} synthetic protein seqs per GPU (seed 42, "
+                                   f"mean {float(offs[-1]) / n:.0f} aa), {args.mode} "
+                                   f"{'score-only' if not args.search_type else 'score+end'}, BLOSUM50, gaps "
+                                   f"{args.gap_open}/{args.gap_ext}, packed int16 first rung",
+                       "cells_per_step_per_gpu": cells, "parallelism": f"db-shard x{world}"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "note": "algorithmic bytes = 8 B/cell of a column-streaming int16 design; this kernel keeps "
+                                 "the column in VGPRs, so it is VALU-issue bound, see valu_roofline"},
+            "valu_roofline": {"kernel_gcups": round(kernel_gcups, 1), "kernel_ms": round(kms, 4),
+                              "lane_ops_per_cell": 5.0,
+                              "peak_gcups": round(VALU_LANE_OPS / 5.0 / 1e9, 0),
+                              "frac": round(kernel_gcups * 1e9 * 5.0 / VALU_LANE_OPS, 4)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(query, res, offs, lens, matrix, args.gap_open, args.gap_ext)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

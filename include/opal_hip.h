@@ -1,0 +1,130 @@
+/*
+ * opal_hip.h -- the seam between the host C++ library and the HIP device code,
+ * plus the additive "prepared database" API.
+ *
+ * Everything here is extern "C" and POD-only (plain pointers and sizes; no C++
+ * or torch types cross it).
+ *
+ * Part 1 (opal_hip_*) is the thin device shim the host scheduler in
+ * opal_amd/csrc/opal_api.cpp drives: memory, copies, and ONE kernel-launch
+ * entry that runs the affine-gap DP for a list of packed sequence pairs. It
+ * replaces the reference's SIMD kernels
+ *   searchDatabaseSW_<SimdSW<T>>      reference src/opal.cpp:164-470
+ *   searchDatabase_<Simd<T>, MODE>    reference src/opal.cpp:594-977
+ * and their per-lane refill (loadNextSequence, :472-490).
+ *
+ * Part 2 (opalx_*) is additive to opal.h: it lets a caller that already holds
+ * the database in device memory (bench.py, a server answering many queries)
+ * reuse the packed database across queries and receive results in device
+ * buffers, in caller order. opalSearchDatabase itself is implemented as
+ * create -> search -> destroy on top of it.
+ */
+#ifndef OPAL_HIP_H
+#define OPAL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ part 1 */
+
+/* One kernel launch over `num_items` work items. All pointers are device pointers. */
+typedef struct OpalHipLaunch {
+    /* what to compute */
+    int width;        /* 16: two sequences per lane as packed int16; 32: one sequence per lane, int32 */
+    int mode;         /* OPAL_MODE_* */
+    int want_end;     /* 0: score only; 1: also end locations (SW: second pass, needs out_score filled) */
+    int detect_wrap;  /* width 32, SW only: test ulH+P for 32-bit wrap (reference opal.cpp:302-303) */
+    /* wave geometry: each sequence (pair) is spread over `lanes_per_seq` adjacent lanes, each lane
+       holding `rows_per_lane` consecutive query rows in registers */
+    int lanes_per_seq;   /* power of two, 1..64 */
+    int rows_per_lane;   /* 1..OPAL_HIP_MAX_ROWS; lanes_per_seq*rows_per_lane >= query_length */
+    /* query */
+    const unsigned char* query;  /* [query_length] alphabet indices */
+    int query_length;
+    const int* score_matrix;     /* [alphabet_length^2], row = query letter */
+    int alphabet_length;
+    int gap_open, gap_ext;
+    /* packed database (see PackedDb in opal_api.cpp / DESIGN.md "data layout") */
+    const uint16_t* tokens;      /* per pair: max(lenA,lenB) entries, low byte = residue of A, high byte = B */
+    const uint64_t* pair_token_offset; /* [num_pairs] start of each pair's token stream */
+    const int* pair_len;         /* [2*num_pairs] lengths of A and B (0 = absent) */
+    const int* pair_seq;         /* [2*num_pairs] caller index of A and B (-1 = absent) */
+    /* work list: item i is work[i] if work != NULL else first_item + i.
+       width 16: an item is a pair index; width 32: an item is pair*2 + half */
+    const int* work;
+    int first_item;
+    int num_items;
+    /* outputs, indexed by caller sequence index */
+    int* out_score;
+    int* out_end_query;   /* may be NULL when want_end == 0 */
+    int* out_end_target;
+    /* overflow re-run list produced by width-16 kernels (items in width-32 encoding) */
+    int* overflow_count;  /* device counter, incremented atomically */
+    int* overflow_items;  /* capacity >= 2*num_pairs */
+    void* stream;         /* hipStream_t or NULL */
+} OpalHipLaunch;
+
+#define OPAL_HIP_MAX_ROWS 40
+
+int opal_hip_device_count(void);
+/* Select `device` for the calling thread. 0 on success. */
+int opal_hip_set_device(int device);
+void* opal_hip_malloc(size_t bytes);
+void opal_hip_free(void* p);
+int opal_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
+int opal_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
+int opal_hip_memset(void* dst, int value, size_t bytes, void* stream);
+int opal_hip_stream_sync(void* stream);
+/* Enqueue one DP kernel. 0 on success, non-zero if the shape is not launchable. */
+int opal_hip_launch(const OpalHipLaunch* args);
+/* Smallest rows_per_lane >= min_rows for which this kernel variant is instantiated (0: none). */
+int opal_hip_rows_supported(int width, int mode, int want_end, int min_rows);
+/* Bytes of LDS the launch would need (query profile), for the scheduler's shape choice. */
+size_t opal_hip_lds_bytes(int width, int lanes_per_seq, int rows_per_lane, int alphabet_length);
+const char* opal_hip_last_error(void);
+/* Timing helpers for bench.py: HIP events on the stream the kernels run on. */
+void* opal_hip_event_create(void);
+void opal_hip_event_destroy(void* ev);
+int opal_hip_event_record(void* ev, void* stream);
+float opal_hip_event_elapsed_ms(void* start, void* stop); /* synchronises on `stop` */
+
+/* ------------------------------------------------------------------ part 2 */
+
+typedef struct OpalxDb OpalxDb; /* opaque: packed database resident in device memory */
+
+/* Pack `db_length` sequences (host pointers, as in opalSearchDatabase) and upload them to the
+   current device. Returns NULL on failure (see opal_hip_last_error). */
+OpalxDb* opalx_db_create(unsigned char* const db[], int db_length, const int db_seq_lengths[]);
+/* Same, from one contiguous residue buffer: sequence j is residues[offsets[j] .. offsets[j+1]). */
+OpalxDb* opalx_db_create_flat(const unsigned char* residues, const int64_t* offsets, int db_length);
+void opalx_db_destroy(OpalxDb* db);
+int opalx_db_num_sequences(const OpalxDb* db);
+int64_t opalx_db_num_residues(const OpalxDb* db);
+
+/*
+ * Search the whole packed database. Results go to DEVICE buffers of db_length ints each, in
+ * caller order (d_end_query/d_end_target may be NULL for OPAL_SEARCH_SCORE). The call enqueues
+ * the kernels and waits for them. Returns 0 or an OPAL_ERR_* code. `kernel_ms`, if not NULL,
+ * receives the device time of all DP kernels (HIP events on the launch stream).
+ * search_type is OPAL_SEARCH_SCORE or OPAL_SEARCH_SCORE_END.
+ */
+int opalx_search_device(OpalxDb* db, const unsigned char* query, int query_length,
+                        int gap_open, int gap_ext, const int* score_matrix, int alphabet_length,
+                        int search_type, int mode, int overflow_method,
+                        int* d_score, int* d_end_query, int* d_end_target, float* kernel_ms);
+
+/* As above with HOST result buffers (copied back after the kernels). */
+int opalx_search_host(OpalxDb* db, const unsigned char* query, int query_length,
+                      int gap_open, int gap_ext, const int* score_matrix, int alphabet_length,
+                      int search_type, int mode, int overflow_method,
+                      int* score, int* end_query, int* end_target);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* OPAL_HIP_H */

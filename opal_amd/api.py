@@ -1,0 +1,147 @@
+"""Python mirror of the reference's interface for the database-search path, on top of the
+C-ABI library (include/opal.h, include/opal_hip.h).
+
+Names, argument meaning and error behaviour follow reference src/opal.h:17-165:
+``search_database`` is ``opalSearchDatabase`` (same argument order after the arrays),
+``search_database_char_sw`` is ``opalSearchDatabaseCharSW``; constants keep their names.
+``PreparedDb`` wraps the additive opalx_* API (database packed once, resident in HBM,
+results written to device buffers) used by bench.py and by callers with many queries.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+OPAL_ERR_OVERFLOW, OPAL_ERR_NO_SIMD_SUPPORT, OPAL_ERR_INVALID_MODE = 1, 2, 3
+OPAL_MODE_NW, OPAL_MODE_HW, OPAL_MODE_OV, OPAL_MODE_SW = 0, 1, 2, 3
+OPAL_OVERFLOW_SIMPLE, OPAL_OVERFLOW_BUCKETS = 0, 1
+OPAL_SEARCH_SCORE, OPAL_SEARCH_SCORE_END, OPAL_SEARCH_ALIGNMENT = 0, 1, 2
+OPAL_ALIGN_MATCH, OPAL_ALIGN_DEL, OPAL_ALIGN_INS, OPAL_ALIGN_MISMATCH = 0, 1, 2, 3
+MODES = {"NW": OPAL_MODE_NW, "HW": OPAL_MODE_HW, "OV": OPAL_MODE_OV, "SW": OPAL_MODE_SW}
+
+
+class OpalSearchResult(C.Structure):
+    """struct OpalSearchResult (reference src/opal.h:47-74): 40 bytes, same field order."""
+    _fields_ = [("scoreSet", C.c_int), ("score", C.c_int),
+                ("endLocationTarget", C.c_int), ("endLocationQuery", C.c_int),
+                ("startLocationTarget", C.c_int), ("startLocationQuery", C.c_int),
+                ("alignment", C.POINTER(C.c_ubyte)), ("alignmentLength", C.c_int)]
+
+
+def new_results(n):
+    """n initialised results (opalInitSearchResult) and the array of pointers the C API takes."""
+    L = _lib.lib()
+    arr = (OpalSearchResult * n)()
+    ptrs = (C.POINTER(OpalSearchResult) * n)()
+    for i in range(n):
+        L.opalInitSearchResult(C.byref(arr[i]))
+        ptrs[i] = C.pointer(arr[i])
+    return arr, ptrs
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _db_arrays(db):
+    seqs = [_u8(s) for s in db]
+    lens = np.array([len(s) for s in seqs], dtype=np.int32)
+    ptrs = (C.POINTER(C.c_ubyte) * len(seqs))()
+    dummy = np.zeros(1, dtype=np.uint8)
+    for i, s in enumerate(seqs):
+        ptrs[i] = (s if len(s) else dummy).ctypes.data_as(C.POINTER(C.c_ubyte))
+    return (seqs, dummy), ptrs, lens
+
+
+def search_database(query, db, gap_open, gap_ext, score_matrix, search_type=OPAL_SEARCH_SCORE,
+                    mode=OPAL_MODE_SW, overflow_method=OPAL_OVERFLOW_BUCKETS, results=None):
+    """opalSearchDatabase. `db` is a list of uint8 index arrays. Returns (rc, results_array)."""
+    L = _lib.lib()
+    q = _u8(query)
+    keep, ptrs, lens = _db_arrays(db)
+    m = np.ascontiguousarray(score_matrix, dtype=np.int32)
+    arr, rptrs = results if results is not None else new_results(len(lens))
+    rc = L.opalSearchDatabase(q.ctypes.data_as(C.POINTER(C.c_ubyte)), len(q), ptrs, len(lens),
+                              lens.ctypes.data_as(C.POINTER(C.c_int)), int(gap_open), int(gap_ext),
+                              m.ctypes.data_as(C.POINTER(C.c_int)), int(m.shape[0]), rptrs,
+                              int(search_type), int(mode), int(overflow_method))
+    return rc, (arr, rptrs)
+
+
+def search_database_char_sw(query, db, gap_open, gap_ext, score_matrix, results=None):
+    """opalSearchDatabaseCharSW. Returns (rc, results_array)."""
+    L = _lib.lib()
+    q = _u8(query)
+    keep, ptrs, lens = _db_arrays(db)
+    m = np.ascontiguousarray(score_matrix, dtype=np.int32)
+    arr, rptrs = results if results is not None else new_results(len(lens))
+    rc = L.opalSearchDatabaseCharSW(q.ctypes.data_as(C.POINTER(C.c_ubyte)), len(q), ptrs, len(lens),
+                                    lens.ctypes.data_as(C.POINTER(C.c_int)), int(gap_open), int(gap_ext),
+                                    m.ctypes.data_as(C.POINTER(C.c_int)), int(m.shape[0]), rptrs)
+    return rc, (arr, rptrs)
+
+
+def result_fields(results, *names):
+    arr = results[0]
+    return [np.array([getattr(arr[i], n) for i in range(len(arr))], dtype=np.int32) for n in names]
+
+
+class PreparedDb:
+    """A database packed once and kept in device memory (opalx_db_* in include/opal_hip.h)."""
+
+    def __init__(self, residues, offsets):
+        L = _lib.lib()
+        self._res = _u8(residues)
+        self._off = np.ascontiguousarray(offsets, dtype=np.int64)
+        self.num_sequences = len(self._off) - 1
+        self._h = L.opalx_db_create_flat(self._res.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                                         self._off.ctypes.data_as(C.POINTER(C.c_int64)), self.num_sequences)
+        if not self._h:
+            raise RuntimeError("opalx_db_create_flat failed: " + (L.opal_hip_last_error() or b"").decode())
+        self.num_residues = int(L.opalx_db_num_residues(self._h))
+
+    @classmethod
+    def from_sequences(cls, seqs):
+        lens = np.array([len(s) for s in seqs], dtype=np.int64)
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        flat = np.concatenate([_u8(s) for s in seqs]) if len(seqs) else np.zeros(0, np.uint8)
+        return cls(flat, offs)
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None and _lib._lib is not None:
+            _lib._lib.opalx_db_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
+
+    def search_device(self, query, gap_open, gap_ext, score_matrix, search_type, mode, d_score, d_end_q=0, d_end_t=0,
+                      overflow_method=OPAL_OVERFLOW_BUCKETS):
+        """Results into device buffers given as raw pointers (e.g. torch tensor .data_ptr()).
+        Returns (rc, kernel_ms)."""
+        q = _u8(query)
+        m = np.ascontiguousarray(score_matrix, dtype=np.int32)
+        ms = C.c_float(0)
+        rc = _lib.lib().opalx_search_device(self._h, q.ctypes.data_as(C.POINTER(C.c_ubyte)), len(q), int(gap_open),
+                                            int(gap_ext), m.ctypes.data_as(C.POINTER(C.c_int)), int(m.shape[0]),
+                                            int(search_type), int(mode), int(overflow_method),
+                                            C.c_void_p(d_score), C.c_void_p(d_end_q or None), C.c_void_p(d_end_t or None),
+                                            C.byref(ms))
+        return rc, ms.value
+
+    def search(self, query, gap_open, gap_ext, score_matrix, search_type=OPAL_SEARCH_SCORE, mode=OPAL_MODE_SW,
+               overflow_method=OPAL_OVERFLOW_BUCKETS):
+        """Host-array convenience: returns (rc, score, endQ, endT) int32 arrays."""
+        q = _u8(query)
+        m = np.ascontiguousarray(score_matrix, dtype=np.int32)
+        n = self.num_sequences
+        s = np.zeros(n, np.int32); eq = np.full(n, -1, np.int32); et = np.full(n, -1, np.int32)
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+        rc = _lib.lib().opalx_search_host(self._h, q.ctypes.data_as(C.POINTER(C.c_ubyte)), len(q), int(gap_open),
+                                          int(gap_ext), ip(m), int(m.shape[0]), int(search_type), int(mode),
+                                          int(overflow_method), ip(s), ip(eq), ip(et))
+        return rc, s, eq, et

@@ -1,0 +1,475 @@
+// dp_kernel.hpp -- gfx950 (MI355X, CDNA4) device code of the affine-gap database search.
+//
+// Replaces the reference's SIMD kernels (reference src/opal.cpp:164-470 searchDatabaseSW_,
+// :594-977 searchDatabase_, :472-490 loadNextSequence). Not a translation: the reference keeps
+// one database sequence per SIMD lane and streams a whole H/E column through memory; here a
+// wavefront is a 64-lane systolic array and the column never leaves the register file.
+//
+// Mapping (DESIGN.md "kernel"):
+//   * A wave holds 64/G "slots"; a slot is G adjacent lanes working on one PAIR of database
+//     sequences (width 16: two sequences packed as 2 x int16 in every VGPR, v_pk_* saturating
+//     math) or on one sequence (width 32). G = 1 is the pure lane-owns-a-sequence mapping.
+//   * Lane k of a slot owns S consecutive query rows and keeps their H and E values in VGPRs for
+//     the whole sequence (S is a template parameter: the row loop is straight-line code).
+//   * At step s lane k computes column c = s-k. The bottom H and F of lane k-1 and the LDS
+//     profile address of that column's residues arrive through one wave_shr:1 DPP shift each.
+//   * The query profile QP[target letter][query row] = scoreMatrix[query[row]][letter] is staged
+//     once per block in LDS, laid out [letter][lane k][row j], so a lane fetches 4 rows of one
+//     letter with one ds_read_b64 (width 16) / ds_read_b128 (width 32); lanes that hold the same
+//     letter broadcast, different letters fall in different banks (odd letter stride).
+//   * Database residues stream from HBM as 16-bit tokens (low byte: sequence A, high byte: B).
+//   * Width 16 hands saturated local scores to a re-run list that the host schedules at width 32
+//     (the 16 -> 32 bit rung of the reference's precision ladder, opal.cpp:496-535 / :983-1021;
+//     gfx950 has no packed 8-bit VALU, so an 8-bit rung would only add work).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <stdint.h>
+
+#define MODE_NW 0
+#define MODE_HW 1
+#define MODE_OV 2
+#define MODE_SW 3
+
+#define FLAG_SWEND 1  // SW second pass: locate the end cell of a known score
+#define FLAG_WRAP 2   // width 32 SW: detect 32-bit wrap of ulH + P (reference opal.cpp:302-303,339-351)
+
+#define WAVES_PER_BLOCK 4
+
+struct KParams {
+    const unsigned char* query;
+    const int* matrix;
+    int Q, A, Go, Ge;
+    const uint16_t* tokens;
+    const uint64_t* pairOff;
+    const int* pairLen;
+    const int* pairSeq;
+    const int* work;
+    int firstItem, numItems, log2G;
+    int* outScore;
+    int* outEndQ;
+    int* outEndT;
+    int* ovfCount;
+    int* ovfItems;
+};
+
+typedef void (*KernelFn)(const KParams);
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------ lane-vector arithmetic
+template <int WIDTH> struct Vec;
+
+template <> struct Vec<16> {  // two int16 scores per register
+    typedef unsigned int reg;
+    typedef short elem;
+    static constexpr int NH = 2;        // sequences per lane
+    static constexpr int NEG = -32768;  // profile value of pad residues / rows below the query
+    static constexpr int SATMAX = 32767;
+    static __device__ __forceinline__ reg splat(int v) { return ((unsigned)v & 0xffffu) | ((unsigned)v << 16); }
+    static __device__ __forceinline__ reg adds(reg a, reg b) {
+        return __builtin_bit_cast(reg, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+    }
+    static __device__ __forceinline__ reg subs(reg a, reg b) {
+        return __builtin_bit_cast(reg, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+    }
+    static __device__ __forceinline__ reg subu(reg a, reg b) {  // unsigned saturating: max(a-b, 0)
+        return __builtin_bit_cast(reg, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+    }
+    static __device__ __forceinline__ reg maxs(reg a, reg b) {
+        return __builtin_bit_cast(reg, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+    }
+    static __device__ __forceinline__ int half(reg a, int h) { return h ? ((int)a >> 16) : (int)(short)(a & 0xffffu); }
+    static __device__ __forceinline__ int clampv(long long v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : (int)v); }
+};
+
+template <> struct Vec<32> {  // one int32 score per register
+    typedef int reg;
+    typedef int elem;
+    static constexpr int NH = 1;
+    static constexpr int NEG = -(1 << 30);
+    static constexpr int SATMAX = 0x7fffffff;
+    static __device__ __forceinline__ reg splat(int v) { return v; }
+    static __device__ __forceinline__ reg adds(reg a, reg b) { return (int)((unsigned)a + (unsigned)b); }  // wrapping, like the reference
+    static __device__ __forceinline__ reg subs(reg a, reg b) { return (int)((unsigned)a - (unsigned)b); }
+    static __device__ __forceinline__ reg subu(reg a, reg b) { return (int)__builtin_elementwise_sub_sat((unsigned)a, (unsigned)b); }
+    static __device__ __forceinline__ reg maxs(reg a, reg b) { return a > b ? a : b; }
+    static __device__ __forceinline__ int half(reg a, int) { return a; }
+    static __device__ __forceinline__ int clampv(long long v) {
+        return v < -(1LL << 30) ? -(1 << 30) : (v > (1LL << 30) ? (1 << 30) : (int)v);
+    }
+};
+
+// wave_shr:1 -- lane i receives lane i-1's value (lane 0 keeps `old`).
+__device__ __forceinline__ unsigned shr1(unsigned v, unsigned old) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x138, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        int o = __shfl_xor(v, d, 64);
+        v = v > o ? v : o;
+    }
+    return v;
+}
+
+// Register select with a wave-uniform runtime index (used once per sequence, NW only).
+template <typename T, int S, int LO, int HI> struct SelectRow {
+    static __device__ __forceinline__ T get(const T (&a)[S], int idx) {
+        if constexpr (LO + 1 == HI) {
+            return a[LO];
+        } else {
+            constexpr int MID = (LO + HI) / 2;
+            if (idx < MID) return SelectRow<T, S, LO, MID>::get(a, idx);
+            return SelectRow<T, S, MID, HI>::get(a, idx);
+        }
+    }
+};
+
+// LDS geometry shared by kernel and host-side sizing
+__host__ __device__ inline int opal_profile_stride(int es, int G, int S) {
+    const int rowsPad = (S + 3) & ~3;
+    int stride = G * rowsPad * es;                         // one target letter's profile
+    if (((stride / (4 * es)) & 1) == 0) stride += 4 * es;  // odd multiple of the read width: letters in distinct banks
+    return stride;
+}
+
+// ------------------------------------------------------------------ the DP kernel
+template <int WIDTH, int MODE, int FLAGS, int S>
+__global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KParams p) {
+    using V = Vec<WIDTH>;
+    using reg = typename V::reg;
+    using elem = typename V::elem;
+    constexpr int NH = V::NH;
+    constexpr int ES = (int)sizeof(elem);  // bytes per profile entry
+    constexpr int RB = 4;                  // rows fetched per LDS read
+    constexpr int SPAD = (S + RB - 1) & ~(RB - 1);
+    constexpr int LANE_BYTES = SPAD * ES;  // one lane's segment of a profile row
+    constexpr bool SWEND = (FLAGS & FLAG_SWEND) != 0;
+    constexpr bool WRAP = (FLAGS & FLAG_WRAP) != 0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int log2G = p.log2G;
+    const int G = 1 << log2G;
+    const int stride = opal_profile_stride(ES, G, S);
+    const int Q = p.Q, A = p.A;
+    // Query rows are spread over G*S >= Q lane registers. NW pads BELOW the query (pad rows never
+    // feed a real row). SW/HW/OV pad ABOVE it: a virtual row with profile 0, H[r][-1] = 0 and
+    // E = -Go reproduces the zero top boundary exactly (H = 0, F passed down = -Go), and puts query row
+    // Q-1 in the last register of the last lane, where it is read without a register select.
+    const int padTop = (MODE == MODE_NW) ? 0 : (G * S - Q);
+
+    // ---- stage the query profile in LDS: QP[letter][k][j] = M[query[k*S+j-padTop]][letter]; letter A = padding
+    {
+        const int perLetter = G * SPAD;
+        const int total = (A + 1) * perLetter;
+        for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+            const int letter = idx / perLetter;
+            const int rem = idx - letter * perLetter;
+            const int k = rem / SPAD;
+            const int j = rem - k * SPAD;
+            const int r = k * S + j - padTop;
+            int v = V::NEG;    // pad residue, and (NW) rows below the query
+            if (r < 0) v = 0;  // virtual rows above the query: transparent
+            else if (letter < A && j < S && r < Q) v = p.matrix[(int)p.query[r] * A + letter];
+            *reinterpret_cast<elem*>(lds + letter * stride + k * LANE_BYTES + j * ES) = (elem)v;
+        }
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int slots = 64 >> log2G;
+    const int job = (int)blockIdx.x * WAVES_PER_BLOCK + wave;
+    const int k = lane & (G - 1);
+    const int slot = lane >> log2G;
+    const int itemIdx = job * slots + slot;
+    const bool valid = itemIdx < p.numItems;
+    // (idle slots and whole idle waves run the loop below with no columns of their own)
+
+    int len[NH], seq[NH];
+    uint64_t tokBase = 0;
+    int half0 = 0, pairIdx = 0;
+#pragma unroll
+    for (int h = 0; h < NH; h++) { len[h] = 0; seq[h] = -1; }
+    if (valid) {
+        const int w = p.firstItem + itemIdx;
+        const int item = p.work ? p.work[w] : w;
+        pairIdx = (WIDTH == 16) ? item : (item >> 1);
+        half0 = (WIDTH == 16) ? 0 : (item & 1);
+        tokBase = p.pairOff[pairIdx];
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            len[h] = p.pairLen[2 * pairIdx + half0 + h];
+            seq[h] = p.pairSeq[2 * pairIdx + half0 + h];
+            if (seq[h] < 0) len[h] = 0;
+        }
+    }
+    int slotLen = len[0];
+    if (NH == 2 && len[NH - 1] > slotLen) slotLen = len[NH - 1];
+    const int maxLen = __builtin_amdgcn_readfirstlane(wave_max_i32(slotLen));
+    const int nsteps = maxLen > 0 ? maxLen + G - 1 : 0;
+
+    // SW second pass: the score to look for (from the first pass); 0 or saturated: nothing to do
+    int target[NH];
+#pragma unroll
+    for (int h = 0; h < NH; h++) target[h] = 0;
+    if (SWEND) {
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            int t = (seq[h] >= 0) ? p.outScore[seq[h]] : 0;
+            if (WIDTH == 16 && t >= V::SATMAX) t = 0;  // the width-32 re-run owns this one
+            target[h] = t;
+        }
+    }
+
+    // ---- per-lane DP state
+    const int Go = p.Go, Ge = p.Ge;
+    const reg Qv = V::splat(Go), Rv = V::splat(Ge);
+    const int r0 = k * S - padTop;  // query row held in register 0 (negative: virtual rows)
+    reg Hp[S], En[S];               // H[r][c-1] and E[r][c] for my rows
+#pragma unroll
+    for (int j = 0; j < S; j++) {
+        if (MODE == MODE_SW) { Hp[j] = 0; En[j] = 0; }
+        else if (MODE == MODE_OV || r0 + j < 0) { Hp[j] = 0; En[j] = V::splat(V::clampv(-(long long)Go)); }
+        else {  // NW, HW: H[r][-1] = -Go - r*Ge (opal.cpp:671-679), E[r][0] = H[r][-1] - Go
+            const long long hb = -(long long)Go - (long long)(r0 + j) * Ge;
+            Hp[j] = V::splat(V::clampv(hb));
+            En[j] = V::splat(V::clampv(hb - Go));
+        }
+    }
+    // what the lane below reads: H and next-row F of my last row. Before my first column it must be
+    // H[last row][-1] (the diagonal input of the lane below at its first column).
+    reg outH = 0, outF = 0;
+    if ((MODE == MODE_NW || MODE == MODE_HW) && r0 + S - 1 >= 0)
+        outH = V::splat(V::clampv(-(long long)Go - (long long)(r0 + S - 1) * Ge));
+    reg diagIn = 0;  // H[r0-1][c-1]; H[-1][-1] = 0 in every mode
+    const unsigned padOff = (unsigned)(A * stride);
+    unsigned offv[NH];
+#pragma unroll
+    for (int h = 0; h < NH; h++) offv[h] = padOff + (unsigned)(k * LANE_BYTES);  // pad columns until real ones arrive
+
+    // results
+    reg mx = 0;                 // SW: running maximum
+    int best[NH], bestCol[NH];  // HW/OV: last-row maximum and its first column; NW: final cell
+    int prevBest[NH];           // OV: last-row maximum over columns 0..L-2
+    int lcMax[NH], lcRow[NH];   // OV: maximum of the last column over my rows, smallest row
+    int endCol[NH], endRow[NH]; // SW second pass
+    int wrapped = 0;
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+        best[h] = INT_MIN; bestCol[h] = -1; prevBest[h] = INT_MIN; lcMax[h] = INT_MIN; lcRow[h] = -1;
+        endCol[h] = INT_MAX; endRow[h] = -1;
+    }
+    // where query row Q-1 lives: NW: lane kLast, register jLast; otherwise last register of lane G-1
+    const int kLast = (MODE == MODE_NW) ? (Q - 1) / S : G - 1;
+    const int jLast = (MODE == MODE_NW) ? (Q - 1) - kLast * S : S - 1;
+    // my registers [jlo, jhi) hold real query rows
+    int jlo = -r0, jhi = Q - r0;
+    jlo = jlo < 0 ? 0 : (jlo > S ? S : jlo);
+    jhi = jhi < 0 ? 0 : (jhi > S ? S : jhi);
+
+    // token prefetch (one step ahead)
+    unsigned tokNext = 0;
+    if (0 < slotLen) tokNext = p.tokens[tokBase];
+
+    for (int s = 0; s < nsteps; s++) {
+        const unsigned tok = tokNext;
+        if (s + 1 < slotLen) tokNext = p.tokens[tokBase + (uint64_t)(s + 1)];
+
+        // ---- inputs of this column: from the boundary (lane 0 of the slot) or from the lane above
+        reg topH = 0;
+        if (MODE == MODE_NW) topH = V::splat(V::clampv(-(long long)Go - (long long)s * Ge));  // H[-1][c] (opal.cpp:686-689)
+        reg inH = (reg)shr1((unsigned)outH, 0u);
+        reg inF = (reg)shr1((unsigned)outF, 0u);
+        if (k == 0) {
+            inH = topH;
+            inF = (MODE == MODE_SW) ? V::subu(topH, Qv) : V::subs(topH, Qv);
+        }
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            unsigned mine;
+            if (WIDTH == 16) mine = (h == 0) ? (tok & 0xffu) : ((tok >> 8) & 0xffu);
+            else mine = half0 ? ((tok >> 8) & 0xffu) : (tok & 0xffu);
+            mine = (s < len[h]) ? mine * (unsigned)stride : padOff;
+            const unsigned shifted = shr1(offv[h], 0u) + (unsigned)LANE_BYTES;
+            offv[h] = (k == 0) ? mine : shifted;
+        }
+        const int c = s - k;  // my column
+
+        if (MODE == MODE_SW || c >= 0) {
+            reg diag = diagIn;
+            reg f = inF;
+            reg h = 0;
+            reg cm = 0;  // SW second pass: this column's maximum over my rows
+#pragma unroll
+            for (int rb = 0; rb < SPAD / RB; rb++) {
+                reg P[RB];
+                if constexpr (WIDTH == 16) {
+                    const uint2 a = *reinterpret_cast<const uint2*>(lds + offv[0] + rb * RB * ES);
+                    const uint2 b = *reinterpret_cast<const uint2*>(lds + offv[1] + rb * RB * ES);
+                    P[0] = __builtin_amdgcn_perm(b.x, a.x, 0x05040100u);
+                    P[1] = __builtin_amdgcn_perm(b.x, a.x, 0x07060302u);
+                    P[2] = __builtin_amdgcn_perm(b.y, a.y, 0x05040100u);
+                    P[3] = __builtin_amdgcn_perm(b.y, a.y, 0x07060302u);
+                } else {
+                    const int4 a = *reinterpret_cast<const int4*>(lds + offv[0] + rb * RB * ES);
+                    P[0] = a.x; P[1] = a.y; P[2] = a.z; P[3] = a.w;
+                }
+#pragma unroll
+                for (int i = 0; i < RB; i++) {
+                    const int j = rb * RB + i;
+                    if (j < S) {
+                        // E = max(H<- - Go, E<- - Ge) was formed one column ago; F likewise one row ago
+                        // (reference core loop opal.cpp:280-327 / :748-771)
+                        const reg e = En[j];
+                        const reg d = V::adds(diag, P[i]);
+                        if (WRAP) wrapped |= (d <= INT_MIN / 2);
+                        h = V::maxs(V::maxs(d, e), f);
+                        reg hq;
+                        if (MODE == MODE_SW) {
+                            // E, F are kept >= 0 by unsigned saturation, so H >= 0 needs no extra max
+                            if (SWEND) cm = V::maxs(cm, h); else mx = V::maxs(mx, h);
+                            hq = V::subu(h, Qv);
+                            En[j] = V::maxs(V::subu(e, Rv), hq);
+                            f = V::maxs(V::subu(f, Rv), hq);
+                        } else {
+                            hq = V::subs(h, Qv);
+                            En[j] = V::maxs(V::subs(e, Rv), hq);
+                            f = V::maxs(V::subs(f, Rv), hq);
+                        }
+                        diag = Hp[j];
+                        Hp[j] = h;
+                    }
+                }
+            }
+            outH = h;
+            outF = f;
+
+            if (MODE == MODE_SW && SWEND) {
+                // rare: this column holds a cell equal to the known score -> record the first (col, row)
+                bool hit = false;
+#pragma unroll
+                for (int hh = 0; hh < NH; hh++)
+                    hit |= (target[hh] > 0 && endCol[hh] == INT_MAX && V::half(cm, hh) == target[hh]);
+                if (hit) {
+#pragma unroll
+                    for (int hh = 0; hh < NH; hh++) {
+                        if (target[hh] > 0 && endCol[hh] == INT_MAX && V::half(cm, hh) == target[hh]) {
+#pragma unroll
+                            for (int j = S - 1; j >= 0; j--)
+                                if (j >= jlo && j < jhi && V::half(Hp[j], hh) == target[hh]) endRow[hh] = r0 + j;
+                            if (endRow[hh] >= 0) endCol[hh] = c;
+                        }
+                    }
+                }
+            }
+            if (MODE == MODE_NW) {
+                // final cell: once per sequence, on the lane/register holding query row Q-1
+                bool fin = false;
+#pragma unroll
+                for (int hh = 0; hh < NH; hh++) fin |= (k == kLast && c == len[hh] - 1);
+                if (fin) {
+                    const reg hl = SelectRow<reg, S, 0, S>::get(Hp, jLast);
+#pragma unroll
+                    for (int hh = 0; hh < NH; hh++)
+                        if (c == len[hh] - 1) best[hh] = V::half(hl, hh);
+                }
+            }
+            if ((MODE == MODE_HW || MODE == MODE_OV) && k == kLast) {
+                // last query row = last register of the last lane = this column's outH
+#pragma unroll
+                for (int hh = 0; hh < NH; hh++) {
+                    const int v = V::half(outH, hh);
+                    if (c < len[hh]) {
+                        if (c == len[hh] - 1) prevBest[hh] = best[hh];
+                        if (v > best[hh]) { best[hh] = v; bestCol[hh] = c; }  // strict >: first column wins (opal.cpp:824-834)
+                    }
+                }
+            }
+            if (MODE == MODE_OV) {
+                bool lastc = false;
+#pragma unroll
+                for (int hh = 0; hh < NH; hh++) lastc |= (c == len[hh] - 1);
+                if (lastc) {
+#pragma unroll
+                    for (int hh = 0; hh < NH; hh++) {
+                        if (c == len[hh] - 1) {
+#pragma unroll
+                            for (int j = S - 1; j >= 0; j--) {
+                                const int v = V::half(Hp[j], hh);
+                                if (j >= jlo && j < jhi && v >= lcMax[hh]) { lcMax[hh] = v; lcRow[hh] = r0 + j; }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        diagIn = inH;
+    }
+
+    // ---- results
+    if (MODE == MODE_SW && !SWEND) {
+        for (int d = 1; d < G; d <<= 1) mx = V::maxs(mx, (reg)__shfl_xor((int)mx, d, 64));  // maximum over the slot
+        if (WRAP) {
+            for (int d = 1; d < G; d <<= 1) wrapped |= __shfl_xor(wrapped, d, 64);
+        }
+        if (k == 0) {
+#pragma unroll
+            for (int hh = 0; hh < NH; hh++) {
+                if (seq[hh] < 0) continue;
+                const int sc = V::half(mx, hh);
+                if (WIDTH == 16 && sc >= V::SATMAX) {  // saturated (opal.cpp:364-370): hand over to width 32
+                    const int at = atomicAdd(p.ovfCount, 1);
+                    p.ovfItems[at] = pairIdx * 2 + half0 + hh;
+                } else if (WIDTH == 32 && WRAP && wrapped) {
+                    atomicAdd(p.ovfCount, 1);  // 32-bit overflow: the host returns OPAL_ERR_OVERFLOW
+                } else {
+                    p.outScore[seq[hh]] = sc;
+                    if (p.outEndQ) { p.outEndQ[seq[hh]] = -1; p.outEndT[seq[hh]] = -1; }
+                }
+            }
+        }
+    }
+    if (MODE == MODE_SW && SWEND) {
+        // smallest column, then smallest lane (= smallest rows) over the slot
+#pragma unroll
+        for (int hh = 0; hh < NH; hh++) {
+            int col = endCol[hh], row = endRow[hh], src = k;
+            for (int d = 1; d < G; d <<= 1) {
+                const int ocol = __shfl_xor(col, d, 64), orow = __shfl_xor(row, d, 64), osrc = __shfl_xor(src, d, 64);
+                if (ocol < col || (ocol == col && osrc < src)) { col = ocol; row = orow; src = osrc; }
+            }
+            if (k == 0 && seq[hh] >= 0 && target[hh] > 0) {
+                p.outEndQ[seq[hh]] = (col == INT_MAX) ? -1 : row;
+                p.outEndT[seq[hh]] = (col == INT_MAX) ? -1 : col;
+            }
+        }
+    }
+    if (MODE != MODE_SW) {
+#pragma unroll
+        for (int hh = 0; hh < NH; hh++) {
+            int sc = best[hh], eq = Q - 1, et = (MODE == MODE_NW) ? len[hh] - 1 : bestCol[hh];
+            if (MODE == MODE_OV) {
+                // last-column maximum over all lanes of the slot (value, then smallest row) (opal.cpp:881-904)
+                int v = lcMax[hh], r = lcRow[hh];
+                for (int d = 1; d < G; d <<= 1) {
+                    const int ov = __shfl_xor(v, d, 64), orow = __shfl_xor(r, d, 64);
+                    if (ov > v || (ov == v && orow >= 0 && (r < 0 || orow < r))) { v = ov; r = orow; }
+                }
+                if (k == kLast && v > prevBest[hh]) { sc = v; et = len[hh] - 1; eq = r; }
+            }
+            if (k == kLast && seq[hh] >= 0) {
+                p.outScore[seq[hh]] = sc;
+                if (p.outEndQ) { p.outEndQ[seq[hh]] = eq; p.outEndT[seq[hh]] = et; }
+            }
+        }
+    }
+}
+
+// Kernel tables, one per translation unit (inst_*.hip); nullptr = shape not instantiated.
+KernelFn opal_kernel_sw16(int rows);                      // width 16, SW, score only: rows 1..40
+KernelFn opal_kernel_w16(int mode, int flags, int rows);  // width 16, the other variants: rows 4,8,..,40
+KernelFn opal_kernel_w32(int mode, int flags, int rows);  // width 32: rows 8,16,24,32,40

@@ -1,0 +1,573 @@
+// opal_api.cpp -- host side of the MI355X-native aligner: the opal.h C API, the database packer
+// and the launch scheduler (which plays the role of the reference's precision ladder).
+//
+// Plain C++ (no HIP headers): everything that touches the device goes through the extern "C"
+// shim of include/opal_hip.h.
+//
+//   opalSearchDatabase        reference src/opal.cpp:1435-1519
+//   opalSearchDatabaseCharSW  reference src/opal.cpp:1522-1546
+//   result helpers            reference src/opal.cpp:1549-1564
+//   precision ladder          reference src/opal.cpp:496-535 (SW), :983-1021 (NW/HW/OV)
+//
+// There is NO CPU fallback: without a usable gfx950 device every search returns
+// OPAL_ERR_NO_SIMD_SUPPORT and says why on stderr.
+#include <algorithm>
+#include <climits>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "opal.h"
+#include "opal_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------ packed db
+// Sequences sorted by length (descending), paired up neighbour with neighbour. A pair is the unit a
+// wave slot works on at width 16 (two sequences packed in one register); its residues are stored
+// column by column as 16-bit tokens (low byte A, high byte B) so one 2-byte load feeds both.
+struct HostPack {
+    std::vector<uint16_t> tokens;
+    std::vector<uint64_t> pairOff;  // [P]
+    std::vector<int> pairLen;       // [2P]
+    std::vector<int> pairSeq;       // [2P] caller index, -1 = absent
+    std::vector<int> emptySeqs;     // caller indices of zero-length sequences (handled on the host)
+    int64_t residues = 0;
+    int numSeqs = 0;
+};
+
+template <typename GetSeq>
+static void pack_sequences(int n, const int* lens, GetSeq getSeq, HostPack& out) {
+    out.numSeqs = n;
+    std::vector<int> order;
+    order.reserve(n);
+    for (int i = 0; i < n; i++) {
+        if (lens[i] > 0) order.push_back(i);
+        else out.emptySeqs.push_back(i);
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lens[a] > lens[b]; });
+    const int m = (int)order.size();
+    const int P = (m + 1) / 2;
+    out.pairOff.resize(P);
+    out.pairLen.assign(2 * (size_t)P, 0);
+    out.pairSeq.assign(2 * (size_t)P, -1);
+    uint64_t total = 0;
+    for (int p = 0; p < P; p++) {
+        out.pairOff[p] = total;
+        total += (uint64_t)lens[order[2 * p]];  // A is the longer one
+    }
+    out.tokens.assign(total + 8, 0);
+    for (int p = 0; p < P; p++) {
+        const int a = order[2 * p];
+        const int b = (2 * p + 1 < m) ? order[2 * p + 1] : -1;
+        const int la = lens[a], lb = b >= 0 ? lens[b] : 0;
+        out.pairSeq[2 * p] = a; out.pairLen[2 * p] = la;
+        out.pairSeq[2 * p + 1] = b; out.pairLen[2 * p + 1] = lb;
+        const unsigned char* sa = getSeq(a);
+        const unsigned char* sb = b >= 0 ? getSeq(b) : nullptr;
+        uint16_t* t = out.tokens.data() + out.pairOff[p];
+        int c = 0;
+        for (; c < lb; c++) t[c] = (uint16_t)(sa[c] | (sb[c] << 8));
+        for (; c < la; c++) t[c] = (uint16_t)sa[c];
+        out.residues += la + lb;
+    }
+}
+
+}  // namespace
+
+struct OpalxDb {
+    int numSeqs = 0;
+    int numPairs = 0;
+    int64_t residues = 0;
+    // host copies the scheduler needs
+    std::vector<int> pairLen;  // [2P], pairs sorted by length of A descending
+    std::vector<int> pairSeq;
+    std::vector<int> emptySeqs;
+    // device
+    uint16_t* dTokens = nullptr;
+    uint64_t* dPairOff = nullptr;
+    int* dPairLen = nullptr;
+    int* dPairSeq = nullptr;
+    int* dOvfCount = nullptr;  // [2] counters: width-16 overflow list length, width-32 wrap count
+    int* dOvfItems = nullptr;  // [2P]
+    int* dWork = nullptr;      // [2P] scratch work list
+    unsigned char* dQuery = nullptr;
+    int* dMatrix = nullptr;
+    size_t queryCap = 0, matrixCap = 0;
+};
+
+namespace {
+
+static int g_deviceChecked = 0;  // 0 unknown, 1 ok, -1 none
+
+static bool device_ok() {
+    if (g_deviceChecked == 0) {
+        if (opal_hip_device_count() > 0) {
+            g_deviceChecked = 1;
+            const char* env = getenv("OPAL_HIP_DEVICE");
+            if (env && *env && opal_hip_set_device(atoi(env)) != 0) g_deviceChecked = -1;
+        } else {
+            g_deviceChecked = -1;
+        }
+        if (g_deviceChecked < 0)
+            fprintf(stderr, "[opal] no usable HIP device (gfx950 required); there is no CPU fallback\n");
+    }
+    return g_deviceChecked > 0;
+}
+
+static OpalxDb* upload(HostPack& hp) {
+    OpalxDb* db = new OpalxDb;
+    db->numSeqs = hp.numSeqs;
+    db->numPairs = (int)hp.pairOff.size();
+    db->residues = hp.residues;
+    db->pairLen = hp.pairLen;
+    db->pairSeq = hp.pairSeq;
+    db->emptySeqs = hp.emptySeqs;
+    const size_t P = hp.pairOff.size();
+    db->dTokens = (uint16_t*)opal_hip_malloc(hp.tokens.size() * sizeof(uint16_t));
+    db->dPairOff = (uint64_t*)opal_hip_malloc(P * sizeof(uint64_t));
+    db->dPairLen = (int*)opal_hip_malloc(2 * P * sizeof(int));
+    db->dPairSeq = (int*)opal_hip_malloc(2 * P * sizeof(int));
+    db->dOvfCount = (int*)opal_hip_malloc(2 * sizeof(int));
+    db->dOvfItems = (int*)opal_hip_malloc(2 * P * sizeof(int));
+    db->dWork = (int*)opal_hip_malloc(2 * P * sizeof(int));
+    bool ok = db->dTokens && db->dPairOff && db->dPairLen && db->dPairSeq && db->dOvfCount && db->dOvfItems && db->dWork;
+    if (ok && P) {
+        ok = !opal_hip_memcpy_h2d(db->dTokens, hp.tokens.data(), hp.tokens.size() * sizeof(uint16_t), nullptr) &&
+             !opal_hip_memcpy_h2d(db->dPairOff, hp.pairOff.data(), P * sizeof(uint64_t), nullptr) &&
+             !opal_hip_memcpy_h2d(db->dPairLen, hp.pairLen.data(), 2 * P * sizeof(int), nullptr) &&
+             !opal_hip_memcpy_h2d(db->dPairSeq, hp.pairSeq.data(), 2 * P * sizeof(int), nullptr) &&
+             !opal_hip_stream_sync(nullptr);
+    }
+    if (!ok) { opalx_db_destroy(db); return nullptr; }
+    return db;
+}
+
+// ------------------------------------------------------------------------------------ scheduling
+struct Geometry { int G = 0, rows = 0; };
+
+// Choose lanes-per-sequence G and rows-per-lane for one launch. Model: every SIMD issues one
+// wave-instruction per 2 clocks; a column step of a lane costs ~(10*rows + 25) instructions; a job
+// (wave) needs maxLen+G-1 steps. Minimise max(throughput time, longest job's own time).
+static Geometry choose_geometry(int width, int mode, int wantEnd, int Q, int A, const int* pairLenSorted,
+                                int first, int count, int seqsPerSlot) {
+    Geometry best;
+    double bestT = 1e300;
+    const char* forceG = getenv("OPAL_HIP_LANES_PER_SEQ");
+    const double simds = 1024.0;
+    for (int G = 1; G <= 64; G *= 2) {
+        if (forceG && *forceG && atoi(forceG) != G) continue;
+        const int need = (Q + G - 1) / G;
+        if (need > OPAL_HIP_MAX_ROWS) continue;
+        const int rows = opal_hip_rows_supported(width, mode, wantEnd, need);
+        if (!rows) continue;
+        if (opal_hip_lds_bytes(width, G, rows, A) > 160 * 1024) continue;
+        if (G > 1 && (G / 2) * rows >= Q && !forceG) continue;  // lanes that would hold padding only
+        const int slots = 64 / G;
+        const double tstep = 2.0 * (10.0 * rows + 25.0);
+        double total = 0;
+        int jobs = 0;
+        for (int i = 0; i < count; i += slots) {  // first pair of each job is its longest
+            total += (double)(pairLenSorted[2 * (size_t)(first + i)] + G - 1);
+            jobs++;
+        }
+        const double occ = std::min(4.0, std::max(1.0, jobs / simds));
+        const double throughput = total * tstep / simds;
+        const double longest = (double)(pairLenSorted[2 * (size_t)first] + G - 1) * tstep * occ;
+        const double T = std::max(throughput, longest) + 0.15 * std::min(throughput, longest);
+        if (T < bestT) { bestT = T; best.G = G; best.rows = rows; }
+    }
+    (void)seqsPerSlot;
+    return best;
+}
+
+struct SearchCtx {
+    OpalxDb* db;
+    int Q, A, Go, Ge, mode, wantEnd;
+    int* dScore; int* dEndQ; int* dEndT;
+    void* stream;
+};
+
+static int launch_range(const SearchCtx& c, int width, int swEndPass, int detectWrap, const int* work, int firstItem,
+                        int numItems, int firstPairForModel, int* ovfCounter) {
+    if (numItems <= 0) return 0;
+    // the geometry model looks at pair lengths; for width 32 items are halves: use the pair list as a proxy
+    const int pairsForModel = width == 16 ? numItems : std::max(1, numItems / 2);
+    Geometry g = choose_geometry(width, c.mode, swEndPass, c.Q, c.A, c.db->pairLen.data(), firstPairForModel,
+                                 std::min(pairsForModel, c.db->numPairs - firstPairForModel), width == 16 ? 2 : 1);
+    if (!g.G) {
+        fprintf(stderr, "[opal] query of %d residues (alphabet %d) does not fit the on-chip query profile at width %d\n",
+                c.Q, c.A, width);
+        return OPAL_ERR_NO_SIMD_SUPPORT;
+    }
+    OpalHipLaunch a;
+    memset(&a, 0, sizeof a);
+    a.width = width; a.mode = c.mode; a.want_end = swEndPass; a.detect_wrap = detectWrap;
+    a.lanes_per_seq = g.G; a.rows_per_lane = g.rows;
+    a.query = c.db->dQuery; a.query_length = c.Q; a.score_matrix = c.db->dMatrix; a.alphabet_length = c.A;
+    a.gap_open = c.Go; a.gap_ext = c.Ge;
+    a.tokens = c.db->dTokens; a.pair_token_offset = c.db->dPairOff; a.pair_len = c.db->dPairLen; a.pair_seq = c.db->dPairSeq;
+    a.work = work; a.first_item = firstItem; a.num_items = numItems;
+    a.out_score = c.dScore; a.out_end_query = c.wantEnd ? c.dEndQ : nullptr; a.out_end_target = c.wantEnd ? c.dEndT : nullptr;
+    a.overflow_count = ovfCounter; a.overflow_items = c.db->dOvfItems;
+    a.stream = c.stream;
+    return opal_hip_launch(&a) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
+}
+
+// reference opal.cpp:178-198 / :610-630 at 32 bits
+static bool args_fit_int32(int Go, int Ge, const int* M, int A) {
+    const int lo = INT_MIN / 2, hi = INT_MAX / 2;
+    if (Go <= lo || hi <= Go || Ge <= lo || hi <= Ge) return false;
+    for (int i = 0; i < A * A; i++)
+        if (M[i] <= lo || hi <= M[i]) return false;
+    return true;
+}
+
+static int ensure_query_buffers(OpalxDb* db, const unsigned char* query, int Q, const int* M, int A) {
+    const size_t qb = (size_t)std::max(Q, 1), mb = (size_t)A * A * sizeof(int);
+    if (db->queryCap < qb) {
+        opal_hip_free(db->dQuery);
+        db->dQuery = (unsigned char*)opal_hip_malloc(qb);
+        db->queryCap = db->dQuery ? qb : 0;
+    }
+    if (db->matrixCap < mb) {
+        opal_hip_free(db->dMatrix);
+        db->dMatrix = (int*)opal_hip_malloc(mb);
+        db->matrixCap = db->dMatrix ? mb : 0;
+    }
+    if (!db->dQuery || !db->dMatrix) return 1;
+    if (Q && opal_hip_memcpy_h2d(db->dQuery, query, (size_t)Q, nullptr)) return 1;
+    if (opal_hip_memcpy_h2d(db->dMatrix, M, mb, nullptr)) return 1;
+    return 0;
+}
+
+// Values for the degenerate shapes the kernels never see (empty query or empty target): the
+// boundary column/row of the DP matrix (same definitions as oracle/opal_oracle.c).
+static void degenerate_result(int mode, int Q, int L, int Go, int Ge, int* score, int* endQ, int* endT) {
+    if (mode == OPAL_MODE_SW) { *score = 0; *endQ = -1; *endT = -1; return; }
+    if (mode == OPAL_MODE_NW) {
+        const int n = Q + L;
+        *score = n ? (int)(-(long long)Go - (long long)(n - 1) * Ge) : 0;
+    } else if (mode == OPAL_MODE_HW) {
+        *score = (Q && !L) ? (int)(-(long long)Go - (long long)(Q - 1) * Ge) : 0;
+    } else {
+        *score = 0;
+    }
+    *endQ = Q - 1; *endT = L - 1;
+}
+
+static int write_one(int* dArr, int idx, int value) {
+    if (!dArr) return 0;
+    return opal_hip_memcpy_h2d(dArr + idx, &value, sizeof(int), nullptr) || opal_hip_stream_sync(nullptr);
+}
+
+/*
+ * The scheduler. Plays the role of the reference's precision ladder (opal.cpp:496-535, :983-1021)
+ * with the rungs gfx950 has: packed 16-bit first, 32-bit for whatever saturates or cannot be
+ * proven safe. OPAL_OVERFLOW_SIMPLE and OPAL_OVERFLOW_BUCKETS give identical results in the
+ * reference (only the re-run granularity differs); here both map to the same schedule.
+ */
+static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, const int* M, int A,
+                       int searchType, int mode, int* dScore, int* dEndQ, int* dEndT, float* kernelMs) {
+    if (kernelMs) *kernelMs = 0.f;
+    if (mode != OPAL_MODE_NW && mode != OPAL_MODE_HW && mode != OPAL_MODE_OV && mode != OPAL_MODE_SW)
+        return OPAL_ERR_INVALID_MODE;
+    if (!args_fit_int32(Go, Ge, M, A)) return OPAL_ERR_OVERFLOW;
+    if (Go < 0 || Ge < 0) {
+        fprintf(stderr, "[opal] negative gap penalties are not supported (opal.h: non-negative)\n");
+        return OPAL_ERR_OVERFLOW;
+    }
+    if (!device_ok()) return OPAL_ERR_NO_SIMD_SUPPORT;
+    const int wantEnd = searchType != OPAL_SEARCH_SCORE;
+    const int P = db->numPairs;
+    int rc = 0;
+
+    // ---- degenerate shapes: answered from the matrix boundary
+    for (int idx : db->emptySeqs) {
+        int s, eq, et;
+        degenerate_result(mode, Q, 0, Go, Ge, &s, &eq, &et);
+        if (!wantEnd) { eq = et = -1; }
+        if (write_one(dScore, idx, s) || write_one(dEndQ, idx, eq) || write_one(dEndT, idx, et)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    }
+    if (Q == 0) {
+        for (int i = 0; i < 2 * P; i++) {
+            if (db->pairSeq[i] < 0) continue;
+            int s, eq, et;
+            degenerate_result(mode, 0, db->pairLen[i], Go, Ge, &s, &eq, &et);
+            if (!wantEnd) { eq = et = -1; }
+            if (write_one(dScore, db->pairSeq[i], s) || write_one(dEndQ, db->pairSeq[i], eq) || write_one(dEndT, db->pairSeq[i], et))
+                return OPAL_ERR_NO_SIMD_SUPPORT;
+        }
+        return opal_hip_stream_sync(nullptr) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
+    }
+    if (P == 0) return opal_hip_stream_sync(nullptr) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
+
+    if (ensure_query_buffers(db, query, Q, M, A)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (opal_hip_memset(db->dOvfCount, 0, 2 * sizeof(int), nullptr)) return OPAL_ERR_NO_SIMD_SUPPORT;
+
+    long long maxS = 0, minS = 0;
+    for (int i = 0; i < A * A; i++) { maxS = std::max<long long>(maxS, M[i]); minS = std::min<long long>(minS, M[i]); }
+    const bool fits16 = Go <= 32767 && Ge <= 32767 && maxS <= 32767 && minS >= -32768;
+
+    SearchCtx c{db, Q, A, Go, Ge, mode, wantEnd, dScore, dEndQ, dEndT, nullptr};
+    void* evStart = kernelMs ? opal_hip_event_create() : nullptr;
+    void* evStop = kernelMs ? opal_hip_event_create() : nullptr;
+    if (evStart) opal_hip_event_record(evStart, nullptr);
+
+    if (mode == OPAL_MODE_SW) {
+        // rung 1: everything at width 16 (if the inputs fit), saturated scores go to the re-run list
+        int n32 = 0;
+        const int* work32 = nullptr;
+        int first32 = 0;
+        if (fits16) {
+            if ((rc = launch_range(c, 16, 0, 0, nullptr, 0, P, 0, db->dOvfCount))) return rc;
+            int cnt = 0;
+            if (opal_hip_memcpy_d2h(&cnt, db->dOvfCount, sizeof(int), nullptr) || opal_hip_stream_sync(nullptr))
+                return OPAL_ERR_NO_SIMD_SUPPORT;
+            n32 = cnt; work32 = db->dOvfItems;
+        } else {
+            n32 = 2 * P; first32 = 0; work32 = nullptr;  // items pair*2+half enumerate every sequence
+        }
+        // rung 2: width 32, with the reference's wrap test when a wrap is arithmetically possible
+        if (n32 > 0) {
+            const long long maxLen = db->pairLen[0];
+            const int detect = (double)std::min<long long>(Q, maxLen) * (double)maxS > (double)INT_MAX;
+            if ((rc = launch_range(c, 32, 0, detect, work32, first32, n32, 0, db->dOvfCount + 1))) return rc;
+            if (detect) {
+                int wraps = 0;
+                if (opal_hip_memcpy_d2h(&wraps, db->dOvfCount + 1, sizeof(int), nullptr) || opal_hip_stream_sync(nullptr))
+                    return OPAL_ERR_NO_SIMD_SUPPORT;
+                if (wraps) rc = OPAL_ERR_OVERFLOW;
+            }
+        }
+        if (wantEnd && rc == 0) {
+            // end locations: second pass that looks for the known score (first column, then first row)
+            if (fits16 && (rc = launch_range(c, 16, 1, 0, nullptr, 0, P, 0, db->dOvfCount))) return rc;
+            if (n32 > 0 && (rc = launch_range(c, 32, 1, 0, work32, first32, n32, 0, db->dOvfCount + 1))) return rc;
+        }
+    } else {
+        // NW/HW/OV: width 16 where an a-priori bound proves that no value leaves the 16-bit range,
+        // width 32 otherwise. Pairs are sorted by length (descending) and both bounds grow with the
+        // length, so the width-32 pairs form a prefix of the pair list.
+        int p32 = 0;
+        if (!fits16) p32 = P;
+        else {
+            while (p32 < P) {
+                const long long L = db->pairLen[2 * (size_t)p32];
+                const long long lo = 3LL * Go + (Q + L + 2) * (long long)Ge;
+                const long long hi = std::min<long long>(Q, L) * maxS;
+                if (lo < 32768 - 1 && hi < 32767) break;
+                p32++;
+            }
+        }
+        // 32-bit safety (our definition where the reference is undefined, see oracle/opal_oracle.c):
+        // sequences whose bound leaves [-2^30, 2^30] are not computed and the call returns OVERFLOW.
+        // Width-32 items (pair*2+half) enumerate the sequences in descending length, so the unsafe
+        // ones are a prefix of the item list.
+        int nBad = 0;
+        while (nBad < 2 * p32) {
+            const long long L = db->pairLen[nBad];
+            const long long lo = 3LL * Go + (Q + L + 2) * (long long)Ge;
+            const long long hi = std::min<long long>(Q, L) * maxS;
+            if (lo < (1LL << 30) && hi < (1LL << 30)) break;
+            nBad++;
+        }
+        if (nBad > 0) rc = OPAL_ERR_OVERFLOW;
+        if (2 * p32 > nBad &&
+            launch_range(c, 32, 0, 0, nullptr, nBad, 2 * p32 - nBad, nBad / 2, db->dOvfCount + 1))
+            return OPAL_ERR_NO_SIMD_SUPPORT;
+        if (P > p32 && launch_range(c, 16, 0, 0, nullptr, p32, P - p32, p32, db->dOvfCount))
+            return OPAL_ERR_NO_SIMD_SUPPORT;
+    }
+    if (evStop) opal_hip_event_record(evStop, nullptr);
+    if (opal_hip_stream_sync(nullptr)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (kernelMs && evStart && evStop) *kernelMs = opal_hip_event_elapsed_ms(evStart, evStop);
+    opal_hip_event_destroy(evStart);
+    opal_hip_event_destroy(evStop);
+    return rc;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ opalx_* API
+extern "C" OpalxDb* opalx_db_create(unsigned char* const db[], int db_length, const int db_seq_lengths[]) {
+    if (!device_ok()) return nullptr;
+    HostPack hp;
+    pack_sequences(db_length, db_seq_lengths, [&](int i) { return (const unsigned char*)db[i]; }, hp);
+    return upload(hp);
+}
+
+extern "C" OpalxDb* opalx_db_create_flat(const unsigned char* residues, const int64_t* offsets, int db_length) {
+    if (!device_ok()) return nullptr;
+    std::vector<int> lens((size_t)db_length);
+    for (int i = 0; i < db_length; i++) lens[i] = (int)(offsets[i + 1] - offsets[i]);
+    HostPack hp;
+    pack_sequences(db_length, lens.data(), [&](int i) { return residues + offsets[i]; }, hp);
+    return upload(hp);
+}
+
+extern "C" void opalx_db_destroy(OpalxDb* db) {
+    if (!db) return;
+    opal_hip_free(db->dTokens); opal_hip_free(db->dPairOff); opal_hip_free(db->dPairLen); opal_hip_free(db->dPairSeq);
+    opal_hip_free(db->dOvfCount); opal_hip_free(db->dOvfItems); opal_hip_free(db->dWork);
+    opal_hip_free(db->dQuery); opal_hip_free(db->dMatrix);
+    delete db;
+}
+
+extern "C" int opalx_db_num_sequences(const OpalxDb* db) { return db ? db->numSeqs : 0; }
+extern "C" int64_t opalx_db_num_residues(const OpalxDb* db) { return db ? db->residues : 0; }
+
+extern "C" int opalx_search_device(OpalxDb* db, const unsigned char* query, int query_length, int gap_open, int gap_ext,
+                                   const int* score_matrix, int alphabet_length, int search_type, int mode,
+                                   int overflow_method, int* d_score, int* d_end_query, int* d_end_target,
+                                   float* kernel_ms) {
+    (void)overflow_method;  // both methods give identical results (see search_core)
+    if (!db) return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (search_type != OPAL_SEARCH_SCORE && (!d_end_query || !d_end_target)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    return search_core(db, query, query_length, gap_open, gap_ext, score_matrix, alphabet_length, search_type, mode,
+                       d_score, d_end_query, d_end_target, kernel_ms);
+}
+
+extern "C" int opalx_search_host(OpalxDb* db, const unsigned char* query, int query_length, int gap_open, int gap_ext,
+                                 const int* score_matrix, int alphabet_length, int search_type, int mode,
+                                 int overflow_method, int* score, int* end_query, int* end_target) {
+    (void)overflow_method;
+    if (!db) return OPAL_ERR_NO_SIMD_SUPPORT;
+    const int n = db->numSeqs;
+    const int wantEnd = search_type != OPAL_SEARCH_SCORE;
+    const size_t bytes = (size_t)std::max(n, 1) * sizeof(int);
+    int* d = (int*)opal_hip_malloc(3 * bytes);
+    if (!d) return OPAL_ERR_NO_SIMD_SUPPORT;
+    int* dS = d; int* dQ = d + std::max(n, 1); int* dT = d + 2 * (size_t)std::max(n, 1);
+    // pre-load the caller's values so that sequences the search does not write keep them
+    int rc = 0;
+    if (opal_hip_memcpy_h2d(dS, score, (size_t)n * sizeof(int), nullptr)) rc = OPAL_ERR_NO_SIMD_SUPPORT;
+    if (!rc && end_query && opal_hip_memcpy_h2d(dQ, end_query, (size_t)n * sizeof(int), nullptr)) rc = OPAL_ERR_NO_SIMD_SUPPORT;
+    if (!rc && end_target && opal_hip_memcpy_h2d(dT, end_target, (size_t)n * sizeof(int), nullptr)) rc = OPAL_ERR_NO_SIMD_SUPPORT;
+    if (!rc)
+        rc = search_core(db, query, query_length, gap_open, gap_ext, score_matrix, alphabet_length, search_type, mode, dS,
+                         wantEnd ? dQ : nullptr, wantEnd ? dT : nullptr, nullptr);
+    if (rc != OPAL_ERR_NO_SIMD_SUPPORT && rc != OPAL_ERR_INVALID_MODE) {
+        int e = opal_hip_memcpy_d2h(score, dS, (size_t)n * sizeof(int), nullptr);
+        if (wantEnd && end_query) e |= opal_hip_memcpy_d2h(end_query, dQ, (size_t)n * sizeof(int), nullptr);
+        if (wantEnd && end_target) e |= opal_hip_memcpy_d2h(end_target, dT, (size_t)n * sizeof(int), nullptr);
+        e |= opal_hip_stream_sync(nullptr);
+        if (e) rc = OPAL_ERR_NO_SIMD_SUPPORT;
+    }
+    opal_hip_free(d);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------ opal.h API
+extern "C" void opalInitSearchResult(OpalSearchResult* result) {
+    result->scoreSet = 0;
+    result->endLocationTarget = result->endLocationQuery = -1;
+    result->startLocationTarget = result->startLocationQuery = -1;
+    result->alignment = NULL;
+    result->alignmentLength = 0;  // `score` is deliberately left alone, like the reference
+}
+
+extern "C" int opalSearchResultIsEmpty(const OpalSearchResult result) { return !result.scoreSet; }
+
+extern "C" void opalSearchResultSetScore(OpalSearchResult* result, int score) {
+    result->scoreSet = 1;
+    result->score = score;
+}
+
+int opal_find_alignments(unsigned char query[], int queryLength, unsigned char* db[], int dbLength, int dbSeqLengths[],
+                         int gapOpen, int gapExt, int* scoreMatrix, int alphabetLength, OpalSearchResult* results[],
+                         int mode);  // opal_traceback.cpp
+
+extern "C" int opalSearchDatabase(unsigned char query[], int queryLength, unsigned char* db[], int dbLength,
+                                  int dbSeqLengths[], int gapOpen, int gapExt, int* scoreMatrix, int alphabetLength,
+                                  OpalSearchResult* results[], const int searchType, int mode, int overflowMethod) {
+    if (mode != OPAL_MODE_NW && mode != OPAL_MODE_HW && mode != OPAL_MODE_OV && mode != OPAL_MODE_SW)
+        return OPAL_ERR_INVALID_MODE;
+    // Results that already hold what is asked for are kept (opal.h:118-122, opal.cpp:1446-1451);
+    // implemented with the documented, whole-database indexing (the reference indexes `skip`
+    // bucket-locally, opal.cpp:510,998).
+    std::vector<int> todo;
+    todo.reserve((size_t)dbLength);
+    for (int i = 0; i < dbLength; i++) {
+        const bool have = results[i]->scoreSet &&
+                          (searchType == OPAL_SEARCH_SCORE ||
+                           (results[i]->endLocationQuery >= 0 && results[i]->endLocationTarget >= 0));
+        if (!have) todo.push_back(i);
+    }
+    int rc = 0;
+    if (!todo.empty()) {
+        if (!device_ok()) return OPAL_ERR_NO_SIMD_SUPPORT;
+        const int n = (int)todo.size();
+        std::vector<int> lens((size_t)n);
+        for (int i = 0; i < n; i++) lens[i] = dbSeqLengths[todo[i]];
+        HostPack hp;
+        pack_sequences(n, lens.data(), [&](int i) { return (const unsigned char*)db[todo[i]]; }, hp);
+        OpalxDb* pdb = upload(hp);
+        if (!pdb) return OPAL_ERR_NO_SIMD_SUPPORT;
+        const int st = searchType == OPAL_SEARCH_SCORE ? OPAL_SEARCH_SCORE : OPAL_SEARCH_SCORE_END;
+        // INT_MIN marks "not written by the search" (a sequence the search had to give up on)
+        std::vector<int> score((size_t)n, INT_MIN), endQ((size_t)n, -1), endT((size_t)n, -1);
+        rc = opalx_search_host(pdb, query, queryLength, gapOpen, gapExt, scoreMatrix, alphabetLength, st, mode,
+                               overflowMethod, score.data(), endQ.data(), endT.data());
+        opalx_db_destroy(pdb);
+        if (rc == OPAL_ERR_NO_SIMD_SUPPORT || rc == OPAL_ERR_INVALID_MODE) return rc;
+        for (int i = 0; i < n; i++) {
+            if (score[i] == INT_MIN) continue;
+            OpalSearchResult* r = results[todo[i]];
+            opalSearchResultSetScore(r, score[i]);
+            r->endLocationQuery = endQ[i];
+            r->endLocationTarget = endT[i];
+        }
+    } else if (!args_fit_int32(gapOpen, gapExt, scoreMatrix, alphabetLength)) {
+        rc = OPAL_ERR_OVERFLOW;
+    }
+    if (rc) return rc;  // alignment fields untouched on error (opal.cpp:1473)
+
+    if (searchType == OPAL_SEARCH_ALIGNMENT) {
+        return opal_find_alignments(query, queryLength, db, dbLength, dbSeqLengths, gapOpen, gapExt, scoreMatrix,
+                                    alphabetLength, results, mode);
+    }
+    for (int i = 0; i < dbLength; i++) {  // opal.cpp:1508-1515
+        results[i]->alignment = NULL;
+        results[i]->alignmentLength = -1;
+        results[i]->startLocationQuery = -1;
+        results[i]->startLocationTarget = -1;
+    }
+    return 0;
+}
+
+extern "C" int opalSearchDatabaseCharSW(unsigned char query[], int queryLength, unsigned char** db, int dbLength,
+                                        int dbSeqLengths[], int gapOpen, int gapExt, int* scoreMatrix, int alphabetLength,
+                                        OpalSearchResult* results[]) {
+    // The reference runs its 8-bit kernel only (opal.cpp:1533-1536): arguments that do not fit a
+    // signed char fail the pass before any result is written (opal.cpp:178-198).
+    bool fits = gapOpen >= SCHAR_MIN && gapOpen <= SCHAR_MAX && gapExt >= SCHAR_MIN && gapExt <= SCHAR_MAX;
+    for (int i = 0; fits && i < alphabetLength * alphabetLength; i++)
+        fits = scoreMatrix[i] >= SCHAR_MIN && scoreMatrix[i] <= SCHAR_MAX;
+    if (!fits) {
+        for (int i = 0; i < dbLength; i++) { results[i]->score = -1; results[i]->scoreSet = 0; }
+        return OPAL_ERR_OVERFLOW;
+    }
+    if (!device_ok()) return OPAL_ERR_NO_SIMD_SUPPORT;
+    OpalxDb* pdb = opalx_db_create(db, dbLength, dbSeqLengths);
+    if (!pdb) return OPAL_ERR_NO_SIMD_SUPPORT;
+    std::vector<int> score((size_t)dbLength, INT_MIN);
+    int rc = opalx_search_host(pdb, query, queryLength, gapOpen, gapExt, scoreMatrix, alphabetLength, OPAL_SEARCH_SCORE,
+                               OPAL_MODE_SW, OPAL_OVERFLOW_SIMPLE, score.data(), nullptr, nullptr);
+    opalx_db_destroy(pdb);
+    if (rc == OPAL_ERR_NO_SIMD_SUPPORT) return rc;
+    rc = 0;
+    for (int i = 0; i < dbLength; i++) {
+        // the 8-bit pass represents 0..127: a sequence overflows iff its exact score is >= 128
+        if (score[i] == INT_MIN || score[i] >= 128) {
+            results[i]->score = -1; results[i]->scoreSet = 0; rc = OPAL_ERR_OVERFLOW;
+        } else {
+            opalSearchResultSetScore(results[i], score[i]);
+            results[i]->endLocationQuery = -1; results[i]->endLocationTarget = -1;
+        }
+    }
+    return rc;
+}

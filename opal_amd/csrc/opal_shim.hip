@@ -1,0 +1,149 @@
+// opal_shim.hip -- the thin extern "C" HIP shim declared in include/opal_hip.h (part 1):
+// device selection, memory, copies, events and the single kernel-launch entry. No DP logic and
+// no scheduling here: the kernels are in dp_kernel.hpp, the scheduler in opal_api.cpp.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "dp_kernel.hpp"
+#include "opal_hip.h"
+
+static thread_local char g_err[512] = "";
+
+static int fail(const char* what, hipError_t e) {
+    snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+    fprintf(stderr, "[opal-hip] %s\n", g_err);
+    return 2;
+}
+
+extern "C" const char* opal_hip_last_error(void) { return g_err; }
+
+extern "C" int opal_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int opal_hip_set_device(int device) {
+    hipError_t e = hipSetDevice(device);
+    return e == hipSuccess ? 0 : fail("hipSetDevice", e);
+}
+
+extern "C" void* opal_hip_malloc(size_t bytes) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) { fail("hipMalloc", e); return nullptr; }
+    return p;
+}
+
+extern "C" void opal_hip_free(void* p) { if (p) (void)hipFree(p); }
+
+extern "C" int opal_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : fail("hipMemcpyAsync(H2D)", e);
+}
+
+extern "C" int opal_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : fail("hipMemcpyAsync(D2H)", e);
+}
+
+extern "C" int opal_hip_memset(void* dst, int value, size_t bytes, void* stream) {
+    hipError_t e = hipMemsetAsync(dst, value, bytes, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : fail("hipMemsetAsync", e);
+}
+
+extern "C" int opal_hip_stream_sync(void* stream) {
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    return e == hipSuccess ? 0 : fail("hipStreamSynchronize", e);
+}
+
+extern "C" void* opal_hip_event_create(void) {
+    hipEvent_t ev;
+    if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+    return (void*)ev;
+}
+extern "C" void opal_hip_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+extern "C" int opal_hip_event_record(void* ev, void* stream) {
+    hipError_t e = hipEventRecord((hipEvent_t)ev, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : fail("hipEventRecord", e);
+}
+extern "C" float opal_hip_event_elapsed_ms(void* start, void* stop) {
+    float ms = -1.f;
+    if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return -1.f;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) return -1.f;
+    return ms;
+}
+
+static size_t lds_bytes(int width, int G, int rows, int A) {
+    const int es = width == 16 ? 2 : 4;
+    return (size_t)(A + 1) * (size_t)opal_profile_stride(es, G, rows);
+}
+
+extern "C" size_t opal_hip_lds_bytes(int width, int lanes_per_seq, int rows_per_lane, int alphabet_length) {
+    return lds_bytes(width, lanes_per_seq, rows_per_lane, alphabet_length);
+}
+
+static KernelFn pick_kernel(int width, int mode, int flags, int rows) {
+    if (width == 16) return opal_kernel_w16(mode, flags, rows);
+    if (width == 32) return opal_kernel_w32(mode, flags, rows);
+    return nullptr;
+}
+
+static int launch_flags(const OpalHipLaunch* a) {
+    int flags = 0;
+    if (a->mode == MODE_SW && a->want_end) flags |= FLAG_SWEND;
+    if (a->mode == MODE_SW && a->width == 32 && a->detect_wrap && !a->want_end) flags |= FLAG_WRAP;
+    return flags;
+}
+
+extern "C" int opal_hip_rows_supported(int width, int mode, int want_end, int min_rows) {
+    OpalHipLaunch a;
+    memset(&a, 0, sizeof a);
+    a.width = width; a.mode = mode; a.want_end = want_end;
+    for (int r = min_rows < 1 ? 1 : min_rows; r <= OPAL_HIP_MAX_ROWS; r++)
+        if (pick_kernel(width, mode, launch_flags(&a), r)) return r;
+    return 0;
+}
+
+extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
+    const int G = a->lanes_per_seq;
+    int log2G = 0;
+    while ((1 << log2G) < G) log2G++;
+    if (a->mode < 0 || a->mode > 3) { snprintf(g_err, sizeof g_err, "bad mode %d", a->mode); return 3; }
+    KernelFn fn = nullptr;
+    if ((1 << log2G) == G && G <= 64 && a->rows_per_lane >= 1 && a->rows_per_lane <= OPAL_HIP_MAX_ROWS &&
+        (long long)G * a->rows_per_lane >= a->query_length && a->query_length >= 1)
+        fn = pick_kernel(a->width, a->mode, launch_flags(a), a->rows_per_lane);
+    if (!fn) {
+        snprintf(g_err, sizeof g_err, "unlaunchable shape: width=%d mode=%d G=%d rows=%d Q=%d", a->width, a->mode, G,
+                 a->rows_per_lane, a->query_length);
+        fprintf(stderr, "[opal-hip] %s\n", g_err);
+        return 2;
+    }
+    if (a->num_items <= 0) return 0;
+    KParams p;
+    memset(&p, 0, sizeof p);
+    p.query = a->query; p.matrix = a->score_matrix; p.Q = a->query_length; p.A = a->alphabet_length;
+    p.Go = a->gap_open; p.Ge = a->gap_ext;
+    p.tokens = a->tokens; p.pairOff = a->pair_token_offset; p.pairLen = a->pair_len; p.pairSeq = a->pair_seq;
+    p.work = a->work; p.firstItem = a->first_item; p.numItems = a->num_items; p.log2G = log2G;
+    p.outScore = a->out_score; p.outEndQ = a->out_end_query; p.outEndT = a->out_end_target;
+    p.ovfCount = a->overflow_count; p.ovfItems = a->overflow_items;
+    const int slots = 64 / G;
+    const int jobs = (a->num_items + slots - 1) / slots;
+    const int blocks = (jobs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    const size_t lds = lds_bytes(a->width, G, a->rows_per_lane, a->alphabet_length);
+    if (lds > 160 * 1024) {
+        snprintf(g_err, sizeof g_err, "query profile needs %zu bytes of LDS (>160 KiB)", lds);
+        fprintf(stderr, "[opal-hip] %s\n", g_err);
+        return 2;
+    }
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail("hipFuncSetAttribute", e);
+    }
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(WAVES_PER_BLOCK * 64), lds, (hipStream_t)a->stream, p);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("kernel launch", e);
+}

@@ -1,0 +1,146 @@
+"""GPU parity tests: the HIP path, called through the C ABI (opalSearchDatabase in
+opal_amd/csrc/libopal.so), against (a) the committed golden vectors recorded from the reference's
+own SSE4.1/AVX2 library and (b) the CPU oracle on the same inputs. Integer results: bit-exact."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import golden_io
+import oracle_lib
+from oracle_lib import MODES
+
+pytestmark = pytest.mark.gpu
+
+LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "opal_amd", "csrc", "libopal.so")
+
+
+@pytest.fixture(scope="module")
+def ours():
+    assert os.path.exists(LIB), "libopal.so not built"
+    return oracle_lib.OpalABI(LIB)
+
+
+def _check(got, want, mode, what):
+    rc, s, eq, et = got
+    wrc, ws, weq, wet = want
+    assert rc == wrc, f"{what}: rc {rc} != {wrc}"
+    np.testing.assert_array_equal(s, ws, err_msg=f"{what} score")
+    ok = (ws != 0) if mode == "SW" else np.ones_like(ws, dtype=bool)  # SW score 0: reference end is undefined
+    np.testing.assert_array_equal(eq[ok], weq[ok], err_msg=f"{what} endQ")
+    np.testing.assert_array_equal(et[ok], wet[ok], err_msg=f"{what} endT")
+
+
+@pytest.mark.parametrize("name", sorted(cases.CASES))
+def test_case_vs_golden_and_oracle(name, ours, oracle, golden):
+    case = cases.CASES[name]
+    query, seqs, matrix = cases.materialise(case)
+    g = golden[name]
+    for mode in case["modes"]:
+        rc, s, eq, et, sset, _ = ours.search(query, seqs, case["gap_open"], case["gap_ext"], matrix,
+                                             case["search_type"], MODES[mode], case.get("overflow", 1))
+        assert (sset == 1).all()
+        want = g["runs"][mode]
+        _check((rc, s, eq, et), (want["rc"], want["score"], want["endQ"], want["endT"]), mode, f"{name}/{mode} vs golden")
+        orc = oracle.search(query, seqs, case["gap_open"], case["gap_ext"], matrix, case["search_type"], MODES[mode])
+        rc2, s2, eq2, et2 = orc
+        assert rc == rc2
+        np.testing.assert_array_equal(s, s2)
+        np.testing.assert_array_equal(eq, eq2)  # including our defined (-1,-1) for SW score 0
+        np.testing.assert_array_equal(et, et2)
+    if case.get("char_sw"):
+        rc, s, sset = ours.char_sw(query, seqs, case["gap_open"], case["gap_ext"], matrix)
+        want = g["char_sw"]
+        assert rc == want["rc"]
+        np.testing.assert_array_equal(sset, want["scoreSet"])
+        np.testing.assert_array_equal(s, want["score"])
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 32, 64])
+@pytest.mark.parametrize("mode", ["SW", "NW", "HW", "OV"])
+def test_every_wave_geometry(lanes, mode, ours, oracle, monkeypatch):
+    """Force each lanes-per-sequence value: results must not depend on how rows are spread over lanes."""
+    from opal_amd import synth
+    from opal_amd.score_matrix import blosum50
+    qlen = {1: 33, 2: 61, 4: 97, 8: 200, 16: 300, 32: 513, 64: 700}[lanes]
+    res, offs, lens = synth.database(140, seed=100 + lanes)
+    db = [res[offs[i]:offs[i + 1]] for i in range(140)]
+    q = synth.query(qlen, seed=lanes)
+    m = blosum50()[1]
+    monkeypatch.setenv("OPAL_HIP_LANES_PER_SEQ", str(lanes))
+    rc, s, eq, et, _, _ = ours.search(q, db, 3, 1, m, 1, MODES[mode])
+    want = oracle.search(q, db, 3, 1, m, 1, MODES[mode])
+    _check((rc, s, eq, et), want, mode, f"G={lanes} {mode}")
+
+
+def test_api_rules(ours, oracle):
+    q, db, m = cases.materialise(cases.CASES["readme_example"])
+    # score-only search: end locations -1; alignment fields post-filled (opal.cpp:1508-1515)
+    rc, s, eq, et, sset, (arr, _) = ours.search(q, db, 3, 1, m, 0, MODES["SW"])
+    assert rc == 0 and s.tolist() == [14, 10, 16, 12] and (eq == -1).all() and (et == -1).all()
+    assert all(arr[i].alignmentLength == -1 and not arr[i].alignment and arr[i].startLocationQuery == -1 for i in range(4))
+    # invalid mode: 3, nothing written
+    rc, s, eq, et, sset, _ = ours.search(q, db, 3, 1, m, 0, 7)
+    assert rc == 3 and (sset == 0).all()
+    # matrix entry outside (INT_MIN/2, INT_MAX/2): OPAL_ERR_OVERFLOW
+    big = m.copy(); big[0, 0] = 2 ** 30
+    rc, *_ = ours.search(q, db, 3, 1, big, 0, MODES["SW"])
+    assert rc == 1
+    # 32-bit wrap in SW is detected like the reference does (opal.cpp:302-303,339-351)
+    mm = cases.simple_matrix(4, 2 ** 30 - 2, -1)
+    rc, s, *_ = ours.search([1, 1], [[1, 1]], 3, 1, mm, 0, MODES["SW"])
+    assert rc == 0 and s[0] == 2 ** 31 - 4
+    rc, *_ = ours.search([1, 1, 1], [[1, 1, 1]], 3, 1, mm, 0, MODES["SW"])
+    assert rc == 1
+    # SW score 0 -> end (-1,-1)
+    rc, s, eq, et, *_ = ours.search([0, 0, 0], [[1, 1, 1, 1]], 3, 1, cases.simple_matrix(4, 2, -1), 1, MODES["SW"])
+    assert (rc, s[0], eq[0], et[0]) == (0, 0, -1, -1)
+
+
+def test_result_reuse(ours):
+    """A non-empty result (with end location when one is asked for) is kept, not recomputed (opal.h:118-122)."""
+    q, db, m = cases.materialise(cases.CASES["td_O74807_sprot15_o3"])
+    res = ours.new_results(len(db))
+    arr, ptrs = res
+    arr[3].scoreSet = 1; arr[3].score = 12345; arr[3].endLocationQuery = 7; arr[3].endLocationTarget = 9
+    arr[5].scoreSet = 1; arr[5].score = 777  # no end location: must be recomputed for SCORE_END
+    rc, s, eq, et, sset, _ = ours.search(q, db, 3, 1, m, 1, MODES["SW"], results=res)
+    assert rc == 0 and s[3] == 12345 and (eq[3], et[3]) == (7, 9)
+    assert s[5] == 68 and s[0] == 155
+    rc, s, *_ = ours.search(q, db, 3, 1, m, 0, MODES["NW"], results=res)  # everything already has a score
+    assert rc == 0 and s[0] == 155
+
+
+def test_empty_and_ragged(ours, oracle):
+    """Zero-length targets, one-residue targets, an empty database; values defined in oracle/opal_oracle.c."""
+    from opal_amd.score_matrix import blosum50
+    m = blosum50()[1]
+    q = np.arange(20, dtype=np.uint8)
+    db = [np.zeros(0, np.uint8), np.array([3], np.uint8), np.arange(20, dtype=np.uint8), np.zeros(0, np.uint8),
+          np.array([1, 2], np.uint8)]
+    for mode in cases.ALL_MODES:
+        rc, s, eq, et, *_ = ours.search(q, db, 3, 1, m, 1, MODES[mode])
+        want = oracle.search(q, db, 3, 1, m, 1, MODES[mode])
+        _check((rc, s, eq, et), want, mode, f"ragged {mode}")
+    rc, s, *_ = ours.search(q, [], 3, 1, m, 0, MODES["SW"])
+    assert rc == 0 and len(s) == 0
+
+
+@pytest.mark.parametrize("mode", ["SW", "NW", "HW", "OV"])
+def test_width32_paths(mode, ours, oracle):
+    """Inputs that cannot use packed 16-bit math: huge matrix entries / gap penalties, long targets."""
+    from opal_amd import synth
+    q = (synth.splitmix64(5, 0, 90) % np.uint64(4)).astype(np.uint8)
+    _, db = cases.random4(77, 10, 40, 4, 50, 300)
+    m = cases.simple_matrix(4, 40000, -30000)
+    rc, s, eq, et, *_ = ours.search(q, db, 50000, 1000, m, 1, MODES[mode])
+    want = oracle.search(q, db, 50000, 1000, m, 1, MODES[mode])
+    _check((rc, s, eq, et), want, mode, f"w32 big-values {mode}")
+    # long targets with a large extension penalty: the 16-bit a-priori bound fails, 32-bit takes over
+    _, dbl = cases.random4(78, 10, 12, 4, 3000, 6000)
+    m2 = cases.simple_matrix(4, 3, -2)
+    rc, s, eq, et, *_ = ours.search(q, dbl + db[:7], 9, 7, m2, 1, MODES[mode])
+    want = oracle.search(q, dbl + db[:7], 9, 7, m2, 1, MODES[mode])
+    _check((rc, s, eq, et), want, mode, f"w32 long {mode}")
