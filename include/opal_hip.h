@@ -66,6 +66,7 @@ typedef struct OpalHipLaunch {
     int* overflow_count;  /* device counter, incremented atomically */
     int* overflow_items;  /* capacity >= 2*num_pairs */
     void* stream;         /* hipStream_t or NULL */
+    int priority;         /* 0..3: wave issue priority (s_setprio) of this launch's waves */
 } OpalHipLaunch;
 
 #define OPAL_HIP_MAX_ROWS 40
@@ -79,6 +80,9 @@ int opal_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
 int opal_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
 int opal_hip_memset(void* dst, int value, size_t bytes, void* stream);
 int opal_hip_stream_sync(void* stream);
+void* opal_hip_stream_create(void);       /* non-blocking stream: ordered only through events */
+void opal_hip_stream_destroy(void* stream);
+int opal_hip_stream_wait_event(void* stream, void* event);
 /* Enqueue one DP kernel. 0 on success, non-zero if the shape is not launchable. */
 int opal_hip_launch(const OpalHipLaunch* args);
 /* Smallest rows_per_lane >= min_rows for which this kernel variant is instantiated (0: none). */

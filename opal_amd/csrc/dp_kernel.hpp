@@ -51,6 +51,7 @@ struct KParams {
     int* outEndT;
     int* ovfCount;
     int* ovfItems;
+    int prio;
 };
 
 typedef void (*KernelFn)(const KParams);
@@ -129,10 +130,15 @@ template <typename T, int S, int LO, int HI> struct SelectRow {
 };
 
 // LDS geometry shared by kernel and host-side sizing
+// Every LDS read is one naturally aligned 16-byte ds_read_b128 (a misaligned one is replayed at ~64
+// cycles): a lane's segment of a letter's profile is padded to a multiple of 16 bytes, and the letter
+// stride is an ODD multiple of 16 bytes so that different letters fall into different 16-byte bank slots.
+__host__ __device__ inline int opal_rows_per_read(int es) { return 16 / es; }
 __host__ __device__ inline int opal_profile_stride(int es, int G, int S) {
-    const int rowsPad = (S + 3) & ~3;
-    int stride = G * rowsPad * es;                         // one target letter's profile
-    if (((stride / (4 * es)) & 1) == 0) stride += 4 * es;  // odd multiple of the read width: letters in distinct banks
+    const int rpr = 16 / es;
+    const int rowsPad = (S + rpr - 1) / rpr * rpr;
+    int stride = G * rowsPad * es;        // one target letter's profile
+    if (((stride / 16) & 1) == 0) stride += 16;
     return stride;
 }
 
@@ -144,8 +150,8 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
     using elem = typename V::elem;
     constexpr int NH = V::NH;
     constexpr int ES = (int)sizeof(elem);  // bytes per profile entry
-    constexpr int RB = 4;                  // rows fetched per LDS read
-    constexpr int SPAD = (S + RB - 1) & ~(RB - 1);
+    constexpr int RB = 16 / ES;            // rows fetched per LDS read (one ds_read_b128)
+    constexpr int SPAD = (S + RB - 1) / RB * RB;
     constexpr int LANE_BYTES = SPAD * ES;  // one lane's segment of a profile row
     constexpr bool SWEND = (FLAGS & FLAG_SWEND) != 0;
     constexpr bool WRAP = (FLAGS & FLAG_WRAP) != 0;
@@ -178,6 +184,9 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
         }
     }
     __syncthreads();
+
+    // waves of the long-sequence classes take issue priority over co-resident waves of other launches
+    if (p.prio > 0) __builtin_amdgcn_s_setprio(2);
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -308,14 +317,21 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
             for (int rb = 0; rb < SPAD / RB; rb++) {
                 reg P[RB];
                 if constexpr (WIDTH == 16) {
-                    const uint2 a = *reinterpret_cast<const uint2*>(lds + offv[0] + rb * RB * ES);
-                    const uint2 b = *reinterpret_cast<const uint2*>(lds + offv[1] + rb * RB * ES);
+                    const uint4 a = *reinterpret_cast<const uint4*>(
+                        __builtin_assume_aligned(lds + offv[0] + rb * RB * ES, 16));
+                    const uint4 b = *reinterpret_cast<const uint4*>(
+                        __builtin_assume_aligned(lds + offv[1] + rb * RB * ES, 16));
                     P[0] = __builtin_amdgcn_perm(b.x, a.x, 0x05040100u);
                     P[1] = __builtin_amdgcn_perm(b.x, a.x, 0x07060302u);
                     P[2] = __builtin_amdgcn_perm(b.y, a.y, 0x05040100u);
                     P[3] = __builtin_amdgcn_perm(b.y, a.y, 0x07060302u);
+                    P[4] = __builtin_amdgcn_perm(b.z, a.z, 0x05040100u);
+                    P[5] = __builtin_amdgcn_perm(b.z, a.z, 0x07060302u);
+                    P[6] = __builtin_amdgcn_perm(b.w, a.w, 0x05040100u);
+                    P[7] = __builtin_amdgcn_perm(b.w, a.w, 0x07060302u);
                 } else {
-                    const int4 a = *reinterpret_cast<const int4*>(lds + offv[0] + rb * RB * ES);
+                    const int4 a = *reinterpret_cast<const int4*>(
+                        __builtin_assume_aligned(lds + offv[0] + rb * RB * ES, 16));
                     P[0] = a.x; P[1] = a.y; P[2] = a.z; P[3] = a.w;
                 }
 #pragma unroll

@@ -97,6 +97,18 @@ struct OpalxDb {
     unsigned char* dQuery = nullptr;
     int* dMatrix = nullptr;
     size_t queryCap = 0, matrixCap = 0;
+    // side streams for launches that may overlap (created on first use; blocking streams: they order
+    // themselves against the null stream, which carries the copies, memsets and timing events)
+    void* streams[3] = {nullptr, nullptr, nullptr};
+    void* events[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* stream(int i) {
+        if (!streams[i]) streams[i] = opal_hip_stream_create();
+        return streams[i];
+    }
+    void* event(int i) {
+        if (!events[i]) events[i] = opal_hip_event_create();
+        return events[i];
+    }
 };
 
 namespace {
@@ -147,74 +159,142 @@ static OpalxDb* upload(HostPack& hp) {
 }
 
 // ------------------------------------------------------------------------------------ scheduling
-struct Geometry { int G = 0, rows = 0; };
-
-// Choose lanes-per-sequence G and rows-per-lane for one launch. Model: every SIMD issues one
-// wave-instruction per 2 clocks; a column step of a lane costs ~(10*rows + 25) instructions; a job
-// (wave) needs maxLen+G-1 steps. Minimise max(throughput time, longest job's own time).
-static Geometry choose_geometry(int width, int mode, int wantEnd, int Q, int A, const int* pairLenSorted,
-                                int first, int count, int seqsPerSlot) {
-    Geometry best;
-    double bestT = 1e300;
-    const char* forceG = getenv("OPAL_HIP_LANES_PER_SEQ");
-    const double simds = 1024.0;
-    for (int G = 1; G <= 64; G *= 2) {
-        if (forceG && *forceG && atoi(forceG) != G) continue;
-        const int need = (Q + G - 1) / G;
-        if (need > OPAL_HIP_MAX_ROWS) continue;
-        const int rows = opal_hip_rows_supported(width, mode, wantEnd, need);
-        if (!rows) continue;
-        if (opal_hip_lds_bytes(width, G, rows, A) > 160 * 1024) continue;
-        if (G > 1 && (G / 2) * rows >= Q && !forceG) continue;  // lanes that would hold padding only
-        const int slots = 64 / G;
-        const double tstep = 2.0 * (10.0 * rows + 25.0);
-        double total = 0;
-        int jobs = 0;
-        for (int i = 0; i < count; i += slots) {  // first pair of each job is its longest
-            total += (double)(pairLenSorted[2 * (size_t)(first + i)] + G - 1);
-            jobs++;
-        }
-        const double occ = std::min(4.0, std::max(1.0, jobs / simds));
-        const double throughput = total * tstep / simds;
-        const double longest = (double)(pairLenSorted[2 * (size_t)first] + G - 1) * tstep * occ;
-        const double T = std::max(throughput, longest) + 0.15 * std::min(throughput, longest);
-        if (T < bestT) { bestT = T; best.G = G; best.rows = rows; }
-    }
-    (void)seqsPerSlot;
-    return best;
-}
+struct LaunchClass { int first, count, G, rows; };
 
 struct SearchCtx {
     OpalxDb* db;
     int Q, A, Go, Ge, mode, wantEnd;
     int* dScore; int* dEndQ; int* dEndT;
-    void* stream;
 };
 
+// Measured on MI355X (profiles/r01_ubench_*): packed-int16 and 32-bit max/min issue one wave
+// instruction per ~4 clocks per SIMD. A lane's column step costs about (12*rows + 25) instructions.
+static double step_clocks(int rows) { return 4.3 * (12.0 * rows + 25.0); }
+
+/*
+ * Split the item range [first, first+count) (sorted by length, longest first) into classes of
+ * equal wave geometry. Each sequence (pair) is spread over G lanes; a wave therefore needs
+ * len+G-1 column steps of `rows` rows each. Short sequences want a small G (little fill/drain and
+ * per-step overhead), the few very long ones a large G so that no single wave outlives the rest of
+ * the launch. `lenOf(i)` is the length of item i.
+ */
+template <typename LenOf>
+static std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass, int Q, int A, LenOf lenOf, int first,
+                                             int count) {
+    std::vector<LaunchClass> out;
+    if (count <= 0) return out;
+    struct Cand { int G, rows; double eff; };
+    std::vector<Cand> cands;
+    const char* forceG = getenv("OPAL_HIP_LANES_PER_SEQ");
+    double lenSum = 0;
+    const int sample = std::max(1, count / 4096);
+    int nsamp = 0;
+    for (int i = 0; i < count; i += sample) { lenSum += lenOf(first + i); nsamp++; }
+    const double lavg = lenSum / nsamp;
+    for (int G = 1; G <= 64; G *= 2) {
+        if (forceG && *forceG && atoi(forceG) != G) continue;
+        const int need = (Q + G - 1) / G;
+        if (need > OPAL_HIP_MAX_ROWS) continue;
+        const int rows = opal_hip_rows_supported(width, mode, swEndPass, need);
+        if (!rows) continue;
+        if (opal_hip_lds_bytes(width, G, rows, A) > 160 * 1024) continue;
+        if (G > 1 && (G / 2) * rows >= Q && !(forceG && *forceG)) continue;  // half the lanes would hold padding only
+        const double eff = ((double)Q / (G * rows)) * (12.0 * rows / (12.0 * rows + 25.0)) * (lavg / (lavg + G - 1));
+        cands.push_back({G, rows, eff});
+    }
+    if (cands.empty()) return out;
+    size_t base = 0;
+    for (size_t i = 1; i < cands.size(); i++)
+        if (cands[i].eff > cands[base].eff * 1.02) base = i;
+    // time of the whole range at the base geometry if the machine were perfectly filled
+    const double simds = 1024.0;
+    const int slotsBase = 64 / cands[base].G;
+    const double totalClocks = lenSum * sample / slotsBase * step_clocks(cands[base].rows) / simds;
+    const char* budEnv = getenv("OPAL_HIP_TAIL_FRACTION");
+    const double budget = std::max(totalClocks * (budEnv && *budEnv ? atof(budEnv) : 0.35), 20000.0);
+    // walk from the longest item: the smallest geometry (>= base) whose lone-wave time fits the budget
+    size_t ci = cands.size() - 1;
+    int start = first;
+    auto fits = [&](size_t c, int len) { return (len + cands[c].G - 1) * step_clocks(cands[c].rows) <= budget; };
+    int i = first;
+    while (i < first + count) {
+        const int len = lenOf(i);
+        size_t want = base;
+        while (want + 1 < cands.size() && !fits(want, len)) want++;
+        if (i == first) ci = want;
+        if (want != ci) {
+            // close the current class at a multiple of its slots-per-wave
+            out.push_back({start, i - start, cands[ci].G, cands[ci].rows});
+            start = i;
+            ci = want;
+        }
+        if (ci == base) break;  // everything from here on uses the base geometry
+        i += 64 / cands[ci].G;
+    }
+    out.push_back({start, first + count - start, cands[ci].G, cands[ci].rows});
+    while (out.size() > 4) {  // at most three side streams: fold the two longest classes together
+        out[1].count += out[0].count;
+        out[1].first = out[0].first;
+        out[1].G = out[0].G; out[1].rows = out[0].rows;
+        out.erase(out.begin());
+    }
+    return out;
+}
+
+template <typename LenOf>
 static int launch_range(const SearchCtx& c, int width, int swEndPass, int detectWrap, const int* work, int firstItem,
-                        int numItems, int firstPairForModel, int* ovfCounter) {
+                        int numItems, LenOf lenOf, int* ovfCounter) {
     if (numItems <= 0) return 0;
-    // the geometry model looks at pair lengths; for width 32 items are halves: use the pair list as a proxy
-    const int pairsForModel = width == 16 ? numItems : std::max(1, numItems / 2);
-    Geometry g = choose_geometry(width, c.mode, swEndPass, c.Q, c.A, c.db->pairLen.data(), firstPairForModel,
-                                 std::min(pairsForModel, c.db->numPairs - firstPairForModel), width == 16 ? 2 : 1);
-    if (!g.G) {
+    std::vector<LaunchClass> classes;
+    if (work) {
+        // re-run lists are unordered: one class sized for the longest sequence of the database
+        auto l0 = [&](int) { return c.db->pairLen.empty() ? 1 : c.db->pairLen[0]; };
+        classes = plan_classes(width, c.mode, swEndPass, c.Q, c.A, l0, firstItem, numItems);
+    } else {
+        classes = plan_classes(width, c.mode, swEndPass, c.Q, c.A, lenOf, firstItem, numItems);
+    }
+    if (classes.empty()) {
         fprintf(stderr, "[opal] query of %d residues (alphabet %d) does not fit the on-chip query profile at width %d\n",
                 c.Q, c.A, width);
         return OPAL_ERR_NO_SIMD_SUPPORT;
     }
-    OpalHipLaunch a;
-    memset(&a, 0, sizeof a);
-    a.width = width; a.mode = c.mode; a.want_end = swEndPass; a.detect_wrap = detectWrap;
-    a.lanes_per_seq = g.G; a.rows_per_lane = g.rows;
-    a.query = c.db->dQuery; a.query_length = c.Q; a.score_matrix = c.db->dMatrix; a.alphabet_length = c.A;
-    a.gap_open = c.Go; a.gap_ext = c.Ge;
-    a.tokens = c.db->dTokens; a.pair_token_offset = c.db->dPairOff; a.pair_len = c.db->dPairLen; a.pair_seq = c.db->dPairSeq;
-    a.work = work; a.first_item = firstItem; a.num_items = numItems;
-    a.out_score = c.dScore; a.out_end_query = c.wantEnd ? c.dEndQ : nullptr; a.out_end_target = c.wantEnd ? c.dEndT : nullptr;
-    a.overflow_count = ovfCounter; a.overflow_items = c.db->dOvfItems;
-    a.stream = c.stream;
-    return opal_hip_launch(&a) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
+    // The last class (the bulk of the database) runs on the null stream; the classes of long
+    // sequences run beside it on up to three side streams (one hardware queue each), forked from and
+    // joined back into the null stream with events, longest sequences enqueued first.
+    const int nside = std::min<int>((int)classes.size() - 1, 3);
+    void* fork = nullptr;
+    if (nside > 0) {
+        fork = c.db->event(0);
+        if (!fork || opal_hip_event_record(fork, nullptr)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    }
+    for (size_t ki = 0; ki < classes.size(); ki++) {
+        const LaunchClass& k = classes[ki];
+        OpalHipLaunch a;
+        memset(&a, 0, sizeof a);
+        a.width = width; a.mode = c.mode; a.want_end = swEndPass; a.detect_wrap = detectWrap;
+        a.lanes_per_seq = k.G; a.rows_per_lane = k.rows;
+        a.query = c.db->dQuery; a.query_length = c.Q; a.score_matrix = c.db->dMatrix; a.alphabet_length = c.A;
+        a.gap_open = c.Go; a.gap_ext = c.Ge;
+        a.tokens = c.db->dTokens; a.pair_token_offset = c.db->dPairOff; a.pair_len = c.db->dPairLen; a.pair_seq = c.db->dPairSeq;
+        a.work = work; a.first_item = k.first; a.num_items = k.count;
+        a.out_score = c.dScore; a.out_end_query = c.wantEnd ? c.dEndQ : nullptr; a.out_end_target = c.wantEnd ? c.dEndT : nullptr;
+        a.overflow_count = ovfCounter; a.overflow_items = c.db->dOvfItems;
+        const bool side = (int)ki < nside;
+        a.stream = side ? c.db->stream((int)ki) : nullptr;
+        a.priority = side ? 1 : 0;
+        if (getenv("OPAL_HIP_DEBUG"))
+            fprintf(stderr, "[opal] launch width=%d mode=%d end=%d items=[%d,+%d) G=%d rows=%d%s\n", width, c.mode, swEndPass,
+                    k.first, k.count, k.G, k.rows, side ? " (side stream)" : "");
+        if (side && opal_hip_stream_wait_event(a.stream, fork)) return OPAL_ERR_NO_SIMD_SUPPORT;
+        if (opal_hip_launch(&a)) return OPAL_ERR_NO_SIMD_SUPPORT;
+        if (side) {
+            void* done = c.db->event(1 + (int)ki);
+            if (!done || opal_hip_event_record(done, a.stream)) return OPAL_ERR_NO_SIMD_SUPPORT;
+        }
+    }
+    for (int i = 0; i < nside; i++)
+        if (opal_hip_stream_wait_event(nullptr, c.db->event(1 + i))) return OPAL_ERR_NO_SIMD_SUPPORT;
+    return 0;
 }
 
 // reference opal.cpp:178-198 / :610-630 at 32 bits
@@ -312,7 +392,9 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
     for (int i = 0; i < A * A; i++) { maxS = std::max<long long>(maxS, M[i]); minS = std::min<long long>(minS, M[i]); }
     const bool fits16 = Go <= 32767 && Ge <= 32767 && maxS <= 32767 && minS >= -32768;
 
-    SearchCtx c{db, Q, A, Go, Ge, mode, wantEnd, dScore, dEndQ, dEndT, nullptr};
+    SearchCtx c{db, Q, A, Go, Ge, mode, wantEnd, dScore, dEndQ, dEndT};
+    auto pairLenOf = [db](int p) { return db->pairLen[2 * (size_t)p]; };   // width-16 items are pairs
+    auto seqLenOf = [db](int it) { return db->pairLen[(size_t)it]; };      // width-32 items are pair*2+half
     void* evStart = kernelMs ? opal_hip_event_create() : nullptr;
     void* evStop = kernelMs ? opal_hip_event_create() : nullptr;
     if (evStart) opal_hip_event_record(evStart, nullptr);
@@ -323,7 +405,7 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
         const int* work32 = nullptr;
         int first32 = 0;
         if (fits16) {
-            if ((rc = launch_range(c, 16, 0, 0, nullptr, 0, P, 0, db->dOvfCount))) return rc;
+            if ((rc = launch_range(c, 16, 0, 0, nullptr, 0, P, pairLenOf, db->dOvfCount))) return rc;
             int cnt = 0;
             if (opal_hip_memcpy_d2h(&cnt, db->dOvfCount, sizeof(int), nullptr) || opal_hip_stream_sync(nullptr))
                 return OPAL_ERR_NO_SIMD_SUPPORT;
@@ -335,7 +417,7 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
         if (n32 > 0) {
             const long long maxLen = db->pairLen[0];
             const int detect = (double)std::min<long long>(Q, maxLen) * (double)maxS > (double)INT_MAX;
-            if ((rc = launch_range(c, 32, 0, detect, work32, first32, n32, 0, db->dOvfCount + 1))) return rc;
+            if ((rc = launch_range(c, 32, 0, detect, work32, first32, n32, seqLenOf, db->dOvfCount + 1))) return rc;
             if (detect) {
                 int wraps = 0;
                 if (opal_hip_memcpy_d2h(&wraps, db->dOvfCount + 1, sizeof(int), nullptr) || opal_hip_stream_sync(nullptr))
@@ -345,8 +427,8 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
         }
         if (wantEnd && rc == 0) {
             // end locations: second pass that looks for the known score (first column, then first row)
-            if (fits16 && (rc = launch_range(c, 16, 1, 0, nullptr, 0, P, 0, db->dOvfCount))) return rc;
-            if (n32 > 0 && (rc = launch_range(c, 32, 1, 0, work32, first32, n32, 0, db->dOvfCount + 1))) return rc;
+            if (fits16 && (rc = launch_range(c, 16, 1, 0, nullptr, 0, P, pairLenOf, db->dOvfCount))) return rc;
+            if (n32 > 0 && (rc = launch_range(c, 32, 1, 0, work32, first32, n32, seqLenOf, db->dOvfCount + 1))) return rc;
         }
     } else {
         // NW/HW/OV: width 16 where an a-priori bound proves that no value leaves the 16-bit range,
@@ -377,9 +459,9 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
         }
         if (nBad > 0) rc = OPAL_ERR_OVERFLOW;
         if (2 * p32 > nBad &&
-            launch_range(c, 32, 0, 0, nullptr, nBad, 2 * p32 - nBad, nBad / 2, db->dOvfCount + 1))
+            launch_range(c, 32, 0, 0, nullptr, nBad, 2 * p32 - nBad, seqLenOf, db->dOvfCount + 1))
             return OPAL_ERR_NO_SIMD_SUPPORT;
-        if (P > p32 && launch_range(c, 16, 0, 0, nullptr, p32, P - p32, p32, db->dOvfCount))
+        if (P > p32 && launch_range(c, 16, 0, 0, nullptr, p32, P - p32, pairLenOf, db->dOvfCount))
             return OPAL_ERR_NO_SIMD_SUPPORT;
     }
     if (evStop) opal_hip_event_record(evStop, nullptr);
@@ -414,6 +496,8 @@ extern "C" void opalx_db_destroy(OpalxDb* db) {
     opal_hip_free(db->dTokens); opal_hip_free(db->dPairOff); opal_hip_free(db->dPairLen); opal_hip_free(db->dPairSeq);
     opal_hip_free(db->dOvfCount); opal_hip_free(db->dOvfItems); opal_hip_free(db->dWork);
     opal_hip_free(db->dQuery); opal_hip_free(db->dMatrix);
+    for (void* st : db->streams) opal_hip_stream_destroy(st);
+    for (void* ev : db->events) opal_hip_event_destroy(ev);
     delete db;
 }
 

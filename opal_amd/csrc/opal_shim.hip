@@ -58,6 +58,17 @@ extern "C" int opal_hip_stream_sync(void* stream) {
     return e == hipSuccess ? 0 : fail("hipStreamSynchronize", e);
 }
 
+extern "C" void* opal_hip_stream_create(void) {
+    hipStream_t st;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return (void*)st;
+}
+extern "C" int opal_hip_stream_wait_event(void* stream, void* event) {
+    hipError_t e = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0);
+    return e == hipSuccess ? 0 : fail("hipStreamWaitEvent", e);
+}
+extern "C" void opal_hip_stream_destroy(void* stream) { if (stream) (void)hipStreamDestroy((hipStream_t)stream); }
+
 extern "C" void* opal_hip_event_create(void) {
     hipEvent_t ev;
     if (hipEventCreate(&ev) != hipSuccess) return nullptr;
@@ -77,7 +88,7 @@ extern "C" float opal_hip_event_elapsed_ms(void* start, void* stop) {
 
 static size_t lds_bytes(int width, int G, int rows, int A) {
     const int es = width == 16 ? 2 : 4;
-    return (size_t)(A + 1) * (size_t)opal_profile_stride(es, G, rows);
+    return (size_t)(A + 1) * (size_t)opal_profile_stride(es, G, rows) + 16;
 }
 
 extern "C" size_t opal_hip_lds_bytes(int width, int lanes_per_seq, int rows_per_lane, int alphabet_length) {
@@ -130,6 +141,7 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
     p.work = a->work; p.firstItem = a->first_item; p.numItems = a->num_items; p.log2G = log2G;
     p.outScore = a->out_score; p.outEndQ = a->out_end_query; p.outEndT = a->out_end_target;
     p.ovfCount = a->overflow_count; p.ovfItems = a->overflow_items;
+    p.prio = a->priority;
     const int slots = 64 / G;
     const int jobs = (a->num_items + slots - 1) / slots;
     const int blocks = (jobs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
