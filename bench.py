@@ -27,41 +27,42 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+# VALU issue bound of the width-16 kernel (profiles/r01_ubench_valu_*.txt): v_pk_*_i16 and v_perm_b32 issue one
+# wave-instruction per 4 clocks per SIMD; a row of a column costs 10 of them and covers 64 lanes x 2 sequences.
+SIMDS, CLOCK_HZ, INSTR_PER_ROW, CLK_PER_INSTR, CELLS_PER_INSTR_ROW = 1024, 2.4e9, 10.0, 4.0, 128.0
+VALU_PEAK_GCUPS = SIMDS * CLOCK_HZ / (INSTR_PER_ROW * CLK_PER_INSTR / CELLS_PER_INSTR_ROW) / 1e9
 
 
-def cpu_baseline(query, res, offs, lens, matrix, gap_open, gap_ext, budget_s=20.0):
-    """The reference's own AVX2 path (oracle/_ref/libopal_ref.so, built from /root/reference in the
-    build container) timed on this host; falls back to the scalar oracle port if it is absent."""
+def cpu_baseline(query, res, offs, lens, matrix, gap_open, gap_ext):
+    """The reference's own AVX2 path (oracle/_ref/libopal_ref.so, built from /root/reference in the build
+    container) timed on this host's cores through a small pthread harness (oracle/ref_bench.c); falls back
+    to the scalar oracle port if the reference build is absent. Bounded to ~10-30 s of CPU work."""
     import oracle_lib
     n_all = len(lens)
     cores = os.cpu_count() or 1
-    if oracle_lib.have_ref():
-        ref = oracle_lib.RefLib()
-        # 1 thread, the reference's own methodology (aligner_comparison.md:11): bounded sample
-        n = min(n_all, 30000)
-        seqs = [res[offs[i]:offs[i + 1]] for i in range(n)]
-        cells = float(len(query)) * float(offs[n])
-        t0 = time.perf_counter()
-        rc, *_ = ref.search(query, seqs, gap_open, gap_ext, matrix, 0, 3, 1)
-        t1 = time.perf_counter() - t0
-        one = cells / t1 / 1e9
-        # all host cores: contiguous shards, one thread per core (ctypes releases the GIL)
-        nt = min(cores, 64)
-        n2 = min(n_all, max(n, int(n * min(nt, budget_s / max(t1, 1e-3)))))
-        seqs2 = [res[offs[i]:offs[i + 1]] for i in range(n2)]
-        bounds = np.linspace(0, n2, nt + 1).astype(int)
-        threads = [threading.Thread(target=ref.search, args=(query, seqs2[bounds[t]:bounds[t + 1]], gap_open, gap_ext,
-                                                             matrix, 0, 3, 1)) for t in range(nt)]
-        t0 = time.perf_counter()
-        for th in threads: th.start()
-        for th in threads: th.join()
-        tall = time.perf_counter() - t0
-        allc = float(len(query)) * float(offs[n2]) / tall / 1e9
-        return {"value": round(allc, 3), "unit": "GCUPS", "cores": nt, "kind": "reference",
-                "sample": f"first {n2} of {n_all} sequences, {nt} threads; 1 thread on first {n}: {one:.3f} GCUPS",
-                "one_thread_value": round(one, 3)}
+    bench_so = os.path.join(oracle_lib.ORACLE_DIR, "_ref", "libref_bench.so")
+    if oracle_lib.have_ref() and os.path.exists(bench_so):
+        C.CDLL(oracle_lib.ref_lib_path(), mode=C.RTLD_GLOBAL)
+        lib = C.CDLL(bench_so)
+        lib.ref_bench_run.restype = C.c_double
+        q = np.ascontiguousarray(query, np.uint8); r = np.ascontiguousarray(res, np.uint8)
+        o = np.ascontiguousarray(offs, np.int64); m = np.ascontiguousarray(matrix, np.int32)
+        up = lambda a: a.ctypes.data_as(C.POINTER(C.c_ubyte))
+
+        def run(n, threads):
+            return lib.ref_bench_run(up(q), len(q), up(r), o.ctypes.data_as(C.POINTER(C.c_int64)), int(n), int(gap_open),
+                                     int(gap_ext), m.ctypes.data_as(C.POINTER(C.c_int)), int(m.shape[0]), 3, int(threads), None)
+        n1 = min(n_all, 30000)   # 1 thread (the reference's own methodology, aligner_comparison.md:11): ~0.5 s
+        run(min(n_all, 2000), 1)  # warm-up
+        t1 = min(run(n1, 1) for _ in range(2))
+        one = float(len(q)) * float(o[n1]) / t1 / 1e9
+        nt = min(cores, 256)
+        tall = min(run(n_all, nt) for _ in range(3))
+        allc = float(len(q)) * float(o[n_all]) / tall / 1e9
+        return {"value": round(allc, 2), "unit": "GCUPS", "cores": nt, "kind": "reference",
+                "sample": f"whole workload ({n_all} sequences) on {nt} threads, best of 3; 1 thread on the first {n1}: "
+                          f"{one:.2f} GCUPS", "one_thread_value": round(one, 2)}
     orc = oracle_lib.Oracle()
     n = min(n_all, 400)
     seqs = [res[offs[i]:offs[i + 1]] for i in range(n)]
@@ -169,10 +170,9 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "note": "algorithmic bytes = 8 B/cell of a column-streaming int16 design; this kernel keeps "
                                  "the column in VGPRs, so it is VALU-issue bound, see valu_roofline"},
-            "valu_roofline": {"kernel_gcups": round(kernel_gcups, 1), "kernel_ms": round(kms, 4),
-                              "lane_ops_per_cell": 5.0,
-                              "peak_gcups": round(VALU_LANE_OPS / 5.0 / 1e9, 0),
-                              "frac": round(kernel_gcups * 1e9 * 5.0 / VALU_LANE_OPS, 4)},
+            "valu_roofline": {"bound": "valu-issue", "kernel_gcups": round(kernel_gcups, 1), "kernel_ms": round(kms, 4),
+                              "peak_gcups": round(VALU_PEAK_GCUPS, 0), "frac": round(kernel_gcups / VALU_PEAK_GCUPS, 4),
+                              "model": "1024 SIMDs x 2.4 GHz / (10 packed instr x 4 clk per 128 cells)"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(query, res, offs, lens, matrix, args.gap_open, args.gap_ext)

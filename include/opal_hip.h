@@ -127,6 +127,16 @@ int opalx_search_host(OpalxDb* db, const unsigned char* query, int query_length,
                       int search_type, int mode, int overflow_method,
                       int* score, int* end_query, int* end_target);
 
+/*
+ * Host traceback (no device work): for every result that holds a score and an end location, fill
+ * start location and alignment operations, exactly as OPAL_SEARCH_ALIGNMENT does after the search
+ * (reference src/opal.cpp:1475-1507, findAlignment :1236-1431). `alignment` is malloc()ed.
+ */
+struct OpalSearchResult;
+int opalx_find_alignments(unsigned char query[], int query_length, unsigned char* db[], int db_length,
+                          int db_seq_lengths[], int gap_open, int gap_ext, int* score_matrix, int alphabet_length,
+                          struct OpalSearchResult* results[], int mode);
+
 #ifdef __cplusplus
 }
 #endif

@@ -561,10 +561,6 @@ extern "C" void opalSearchResultSetScore(OpalSearchResult* result, int score) {
     result->score = score;
 }
 
-int opal_find_alignments(unsigned char query[], int queryLength, unsigned char* db[], int dbLength, int dbSeqLengths[],
-                         int gapOpen, int gapExt, int* scoreMatrix, int alphabetLength, OpalSearchResult* results[],
-                         int mode);  // opal_traceback.cpp
-
 extern "C" int opalSearchDatabase(unsigned char query[], int queryLength, unsigned char* db[], int dbLength,
                                   int dbSeqLengths[], int gapOpen, int gapExt, int* scoreMatrix, int alphabetLength,
                                   OpalSearchResult* results[], const int searchType, int mode, int overflowMethod) {
@@ -611,7 +607,7 @@ extern "C" int opalSearchDatabase(unsigned char query[], int queryLength, unsign
     if (rc) return rc;  // alignment fields untouched on error (opal.cpp:1473)
 
     if (searchType == OPAL_SEARCH_ALIGNMENT) {
-        return opal_find_alignments(query, queryLength, db, dbLength, dbSeqLengths, gapOpen, gapExt, scoreMatrix,
+        return opalx_find_alignments(query, queryLength, db, dbLength, dbSeqLengths, gapOpen, gapExt, scoreMatrix,
                                     alphabetLength, results, mode);
     }
     for (int i = 0; i < dbLength; i++) {  // opal.cpp:1508-1515

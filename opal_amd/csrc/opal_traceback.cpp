@@ -1,10 +1,167 @@
 // opal_traceback.cpp -- host traceback for OPAL_SEARCH_ALIGNMENT (SURVEY.md 8f "next #1").
-// Placeholder until the traceback lands: fails loudly instead of pretending.
+//
+// What it restates: reference src/opal.cpp:1475-1507 (the reverse-prefix driver) and :1236-1431
+// (findAlignment). Given a score and an end cell (both from the GPU search), the query prefix
+// [0..endQ] and the target prefix [0..endT] are reversed and aligned from the corner with the mode's
+// stop rule until the first column that reaches the score; the cell where that happens is the start
+// of the alignment, the traceback from it gives the operations.
+//
+// Differences in HOW (not in results):
+//   * one byte of traceback flags per cell instead of three ints, no band (cells outside the
+//     reference's band cannot lie on a path that reaches the score, and every tie the traceback
+//     tests is between paths that do, so the band never changes a decision);
+//   * sequences are independent, so they are spread over host threads.
+// The decisions themselves follow the reference exactly, so the operation strings are identical:
+//   H prefers E, then F, then the diagonal (opal.cpp:1378-1386); a gap state prefers to close
+//   (opal.cpp:1389, 1394); the first column reaching the score wins (:1275), then the first row
+//   (:1355).
+#include <algorithm>
+#include <climits>
+#include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
 
 #include "opal.h"
+#include "opal_hip.h"
 
-int opal_find_alignments(unsigned char[], int, unsigned char*[], int, int[], int, int, int*, int, OpalSearchResult*[], int) {
-    fprintf(stderr, "[opal] OPAL_SEARCH_ALIGNMENT is not implemented yet in this build\n");
-    return OPAL_ERR_NO_SIMD_SUPPORT;
+namespace {
+
+constexpr int NEG = INT_MIN / 2;  // "minus infinity" that survives one subtraction of a gap penalty
+
+// flags per cell
+constexpr uint8_t H_FROM_E = 0, H_FROM_F = 1, H_FROM_DIAG = 2, H_MASK = 3;
+constexpr uint8_t E_OPENS = 4;  // E == H[left] - gapOpen : the gap starts here
+constexpr uint8_t F_OPENS = 8;  // F == H[up]   - gapOpen
+
+struct Aligned {
+    int score = 0, endQ = -1, endT = -1;  // in the frame of the two sequences given
+    std::vector<unsigned char> ops;       // from (0,0) to (endQ,endT)
+};
+
+/*
+ * Align q[0..Q) with t[0..T) starting in the top-left corner (both leading gaps are charged like in
+ * NW), stop at the first column where a cell the mode allows as an end reaches `scoreLimit`
+ * (reference opal.cpp:1236-1431).
+ */
+static void find_alignment(const unsigned char* q, int Q, const unsigned char* t, int T, int Go, int Ge, const int* M, int A,
+                           int scoreLimit, int mode, Aligned& out) {
+    std::vector<int> Hp((size_t)Q), Ep((size_t)Q), Hc((size_t)Q), Ec((size_t)Q);
+    for (int r = 0; r < Q; r++) { Hp[r] = -Go - r * Ge; Ep[r] = NEG; }  // initial column (opal.cpp:1266-1269)
+    std::vector<uint8_t> dirs;
+    dirs.reserve((size_t)Q * (size_t)std::min(T, 1024));
+    int maxScore = INT_MIN, H = INT_MIN, c = 0;
+    for (c = 0; c < T && maxScore < scoreLimit; c++) {
+        dirs.resize((size_t)(c + 1) * Q);
+        uint8_t* d = dirs.data() + (size_t)c * Q;
+        int uF = NEG, uH = -Go - c * Ge, ulH = c == 0 ? 0 : uH + Ge;
+        const int* Mrow = nullptr;
+        (void)Mrow;
+        for (int r = 0; r < Q; r++) {
+            const int eo = Hp[r] - Go, ee = Ep[r] - Ge;
+            const int E = std::max(eo, ee);
+            const int fo = uH - Go, fe = uF - Ge;
+            const int F = std::max(fo, fe);
+            const int diag = ulH + M[q[r] * A + t[c]];
+            H = std::max(E, std::max(F, diag));
+            uint8_t f = (H == E) ? H_FROM_E : (H == F) ? H_FROM_F : H_FROM_DIAG;
+            if (E == eo) f |= E_OPENS;
+            if (F == fo) f |= F_OPENS;
+            d[r] = f;
+            if (mode == OPAL_MODE_SW || (mode == OPAL_MODE_OV && c == T - 1)) maxScore = std::max(maxScore, H);
+            uF = F; uH = H; ulH = Hp[r];
+            Hc[r] = H; Ec[r] = E;
+        }
+        if (mode == OPAL_MODE_HW || mode == OPAL_MODE_OV) maxScore = std::max(maxScore, H);  // last row
+        Hp.swap(Hc); Ep.swap(Ec);
+    }
+    const int lastCol = c - 1;
+    // score and end cell (opal.cpp:1340-1362); Hp now holds the last computed column
+    if (mode == OPAL_MODE_NW) {
+        out.score = H; out.endT = T - 1; out.endQ = Q - 1;
+    } else if (mode == OPAL_MODE_HW) {
+        out.score = maxScore; out.endT = lastCol; out.endQ = Q - 1;
+    } else {
+        out.score = maxScore; out.endT = lastCol;
+        int r = 0;
+        while (r < Q && Hp[r] != maxScore) r++;
+        out.endQ = r < Q ? r : Q - 1;
+    }
+    // traceback (opal.cpp:1369-1409)
+    std::vector<unsigned char>& ops = out.ops;
+    ops.clear();
+    int ri = out.endQ, ci = out.endT;
+    enum { SH, SE, SF } state = SH;
+    while (ri >= 0 && ci >= 0) {
+        const uint8_t f = dirs[(size_t)ci * Q + ri];
+        if (state == SH) {
+            if ((f & H_MASK) == H_FROM_E) state = SE;
+            else if ((f & H_MASK) == H_FROM_F) state = SF;
+            else { ops.push_back(q[ri] == t[ci] ? OPAL_ALIGN_MATCH : OPAL_ALIGN_MISMATCH); ri--; ci--; }
+        } else if (state == SE) {
+            state = (f & E_OPENS) ? SH : SE;
+            ops.push_back(OPAL_ALIGN_INS);
+            ci--;
+        } else {
+            state = (f & F_OPENS) ? SH : SF;
+            ops.push_back(OPAL_ALIGN_DEL);
+            ri--;
+        }
+    }
+    while (ri >= 0) { ops.push_back(OPAL_ALIGN_DEL); ri--; }  // leading gap: only one of the two loops runs
+    while (ci >= 0) { ops.push_back(OPAL_ALIGN_INS); ci--; }
+    std::reverse(ops.begin(), ops.end());
+}
+
+static void align_one(const unsigned char* rQuery, int queryLength, const unsigned char* target, int Go, int Ge,
+                      const int* M, int A, OpalSearchResult* res, int mode, std::vector<unsigned char>& rTarget) {
+    if (mode == OPAL_MODE_SW && res->score == 0) {  // no alignment at all (opal.cpp:1479-1483)
+        res->alignment = NULL; res->alignmentLength = 0;
+        res->startLocationQuery = res->startLocationTarget = -1;
+        res->endLocationQuery = res->endLocationTarget = -1;
+        return;
+    }
+    const int aq = res->endLocationQuery + 1, at = res->endLocationTarget + 1;
+    if (aq <= 0 || at <= 0) {  // degenerate shapes (empty query or target): nothing to trace
+        res->alignment = NULL; res->alignmentLength = 0;
+        res->startLocationQuery = res->startLocationTarget = -1;
+        return;
+    }
+    const unsigned char* alignQuery = rQuery + queryLength - aq;  // reversed prefix of the query
+    rTarget.resize((size_t)at);
+    for (int i = 0; i < at; i++) rTarget[i] = target[at - 1 - i];
+    Aligned a;
+    find_alignment(alignQuery, aq, rTarget.data(), at, Go, Ge, M, A, res->score, mode, a);
+    res->startLocationQuery = aq - a.endQ - 1;
+    res->startLocationTarget = at - a.endT - 1;
+    res->alignmentLength = (int)a.ops.size();
+    res->alignment = (unsigned char*)malloc(a.ops.size() ? a.ops.size() : 1);  // caller free()s (opal.h)
+    for (size_t i = 0; i < a.ops.size(); i++) res->alignment[i] = a.ops[a.ops.size() - 1 - i];  // back to forward order
+}
+
+}  // namespace
+
+extern "C" int opalx_find_alignments(unsigned char query[], int queryLength, unsigned char* db[], int dbLength,
+                                     int dbSeqLengths[], int gapOpen, int gapExt, int* scoreMatrix, int alphabetLength,
+                                     OpalSearchResult* results[], int mode) {
+    (void)dbSeqLengths;
+    std::vector<unsigned char> rQuery((size_t)std::max(queryLength, 1));
+    for (int i = 0; i < queryLength; i++) rQuery[i] = query[queryLength - 1 - i];
+    unsigned nt = std::thread::hardware_concurrency();
+    const char* env = getenv("OPAL_HOST_THREADS");
+    if (env && *env) nt = (unsigned)atoi(env);
+    nt = std::max(1u, std::min(nt, 32u));
+    nt = std::min<unsigned>(nt, (unsigned)std::max(dbLength, 1));
+    auto work = [&](unsigned tid) {
+        std::vector<unsigned char> rTarget;
+        for (int i = (int)tid; i < dbLength; i += (int)nt)
+            align_one(rQuery.data(), queryLength, db[i], gapOpen, gapExt, scoreMatrix, alphabetLength, results[i], mode, rTarget);
+    };
+    if (nt == 1) { work(0); return 0; }
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; t++) pool.emplace_back(work, t);
+    for (auto& th : pool) th.join();
+    return 0;
 }

@@ -18,6 +18,8 @@ g++ $CXXFLAGS -fPIC -shared \
     -DopalSearchResultIsEmpty=ref_opalSearchResultIsEmpty \
     -DopalSearchResultSetScore=ref_opalSearchResultSetScore \
     "$REF/src/opal.cpp" -o "$OUT/libopal_ref.so"
+# Multi-threaded timing harness around the reference library (bench.py cpu_baseline leg).
+gcc -O2 -fPIC -shared "$HERE/ref_bench.c" -L"$OUT" -lopal_ref -lpthread -Wl,-rpath,'$ORIGIN' -o "$OUT/libref_bench.so"
 # Reference applications, reference objects only (for golden generation / comparison).
 g++ $CXXFLAGS "$REF/src/opal.cpp" "$REF/src/ScoreMatrix.cpp" "$REF/src/opal_aligner.cpp" -o "$OUT/ref_opal_aligner"
 g++ $CXXFLAGS "$REF/src/opal.cpp" "$REF/src/ScoreMatrix.cpp" "$REF/src/test.cpp" -o "$OUT/ref_test"

@@ -78,6 +78,14 @@ _add("random4_q200_db300_o0", kind="random4", qlen=200, nseq=300, seed=1002, mat
      alphabet=4, gap_open=5, gap_ext=2, minlen=1, maxlen=400)
 
 
+# ---- alignment (traceback) goldens: start locations and operation strings recorded from the reference
+for _n in ("readme_example", "td_test1_test1", "td_O74807_sprot15_o3", "td_O74807_sprot15_o11", "pin_100_same_match3"):
+    CASES[_n]["align"] = True
+_add("random4_q120_db40_align", kind="random4", qlen=120, nseq=40, seed=1003, matrix=("simple", 3, -2),
+     alphabet=4, gap_open=4, gap_ext=1, minlen=20, maxlen=260, align=True)
+_add("synth_q90_db60_align", kind="synth", qlen=90, nseq=60, first=30000, matrix="blosum50", align=True)
+
+
 def _matrix(spec, alphabet_length=None):
     if spec == "blosum50":
         return blosum50()[1]

@@ -54,6 +54,16 @@ def run_case(case_name):
                                                 case["search_type"], oracle_lib.MODES[mode],
                                                 case.get("overflow", oracle_lib.OVERFLOW_BUCKETS))
         out["runs"][mode] = {"rc": int(rc), "score": score.tolist(), "endQ": eq.tolist(), "endT": et.tolist()}
+    if case.get("align"):
+        out["align"] = {}
+        for mode in case["modes"]:
+            rc, score, eq, et, sset, (arr, _) = ref.search(query, seqs, case["gap_open"], case["gap_ext"], matrix,
+                                                           oracle_lib.SEARCH_ALIGNMENT, oracle_lib.MODES[mode],
+                                                           case.get("overflow", oracle_lib.OVERFLOW_BUCKETS))
+            sq, st, ops = ref.alignments(arr)
+            out["align"][mode] = {"rc": int(rc), "score": score.tolist(), "endQ": eq.tolist(), "endT": et.tolist(),
+                                  "startQ": sq.tolist(), "startT": st.tolist(),
+                                  "ops": ["".join(str(b) for b in o) for o in ops]}
     if case.get("char_sw"):
         rc, score, sset = ref.char_sw(query, seqs, case["gap_open"], case["gap_ext"], matrix)
         out["char_sw"] = {"rc": int(rc), "score": score.tolist(), "scoreSet": sset.tolist()}

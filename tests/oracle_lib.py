@@ -125,6 +125,22 @@ class OpalABI:
         f = lambda name: np.array([getattr(arr[i], name) for i in range(n)], dtype=np.int32)
         return rc, f("score"), f("endLocationQuery"), f("endLocationTarget"), f("scoreSet"), (arr, rptrs)
 
+    def alignments(self, arr):
+        """(startQ, startT, [ops bytes]) from result structs after an OPAL_SEARCH_ALIGNMENT search; frees them."""
+        libc = C.CDLL(None)
+        libc.free.argtypes = [C.c_void_p]
+        sq, st, ops = [], [], []
+        for r in arr:
+            sq.append(r.startLocationQuery); st.append(r.startLocationTarget)
+            if r.alignment and r.alignmentLength > 0:
+                ops.append(bytes(bytearray(r.alignment[:r.alignmentLength])))
+            else:
+                ops.append(b"")
+            if r.alignment:
+                libc.free(C.cast(r.alignment, C.c_void_p))
+                r.alignment = None
+        return np.array(sq, np.int32), np.array(st, np.int32), ops
+
     def char_sw(self, query, seqs, gap_open, gap_ext, matrix):
         q = _as_u8(query)
         keep, ptrs, lens = _db_pointers(seqs)

@@ -1,0 +1,128 @@
+"""CPU-only tests of the host side of the library: the C-ABI surface, the loud no-GPU failure, and
+the host traceback (opalx_find_alignments) against the reference's recorded alignments."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import cases
+import oracle_lib
+from oracle_lib import MODES, OpalSearchResult
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "opal_amd", "csrc", "libopal.so")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(LIB), reason="libopal.so not built (run __graft_entry__.build())")
+
+
+def _declared_functions(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(opalx?_?[A-Za-z0-9_]*|opal[A-Z][A-Za-z0-9]*)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(LIB)
+    names = _declared_functions("opal.h") + _declared_functions("opal_hip.h")
+    assert {"opalSearchDatabase", "opalSearchDatabaseCharSW", "opalInitSearchResult", "opalSearchResultIsEmpty",
+            "opalSearchResultSetScore", "opal_hip_launch", "opalx_search_device", "opalx_find_alignments"} <= set(names)
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/ but not exported by libopal.so"
+
+
+def test_struct_layout_matches_reference_abi():
+    # reference src/opal.h:47-74: 40 bytes, offsets 0/4/8/12/16/20/24/32
+    assert C.sizeof(OpalSearchResult) == 40
+    offs = [getattr(OpalSearchResult, f).offset for f, _ in OpalSearchResult._fields_]
+    assert offs == [0, 4, 8, 12, 16, 20, 24, 32]
+
+
+def test_result_helpers():
+    abi = oracle_lib.OpalABI(LIB)
+    r = OpalSearchResult()
+    r.score = 99; r.scoreSet = 1; r.alignmentLength = 7
+    abi.f_init(C.byref(r))
+    assert (r.scoreSet, r.endLocationQuery, r.endLocationTarget, r.startLocationQuery, r.startLocationTarget) == (0, -1, -1, -1, -1)
+    assert r.alignmentLength == 0 and not r.alignment and r.score == 99  # score is left alone (opal.cpp:1549-1555)
+    assert abi.f_empty(r) == 1
+    abi.f_set(C.byref(r), 5)
+    assert abi.f_empty(r) == 0 and r.score == 5 and r.scoreSet == 1
+
+
+def test_fails_loudly_without_a_gpu(capfd):
+    """No CPU fallback: without a device the search returns OPAL_ERR_NO_SIMD_SUPPORT and says so."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    abi = oracle_lib.OpalABI(LIB)
+    q, db, m = cases.materialise(cases.CASES["readme_example"])
+    rc, s, eq, et, sset, _ = abi.search(q, db, 3, 1, m, 0, MODES["SW"])
+    assert rc == 2 and (sset == 0).all()
+    assert "no usable HIP device" in capfd.readouterr().err
+    rc, *_ = abi.search(q, db, 3, 1, m, 0, 9)
+    assert rc == 3  # invalid mode is reported before anything else
+
+
+def _traceback(lib, q, db, go, ge, m, mode, score, eq, et):
+    n = len(db)
+    arr = (OpalSearchResult * n)()
+    ptrs = (C.POINTER(OpalSearchResult) * n)()
+    for i in range(n):
+        arr[i].scoreSet = 1; arr[i].score = int(score[i])
+        arr[i].endLocationQuery = int(eq[i]); arr[i].endLocationTarget = int(et[i])
+        arr[i].startLocationQuery = arr[i].startLocationTarget = -1
+        ptrs[i] = C.pointer(arr[i])
+    keep, dptrs, lens = oracle_lib._db_pointers(db)
+    qq = np.ascontiguousarray(q, np.uint8); mm = np.ascontiguousarray(m, np.int32)
+    rc = lib.opalx_find_alignments(qq.ctypes.data_as(C.POINTER(C.c_ubyte)), len(qq), dptrs, n,
+                                   lens.ctypes.data_as(C.POINTER(C.c_int)), int(go), int(ge),
+                                   mm.ctypes.data_as(C.POINTER(C.c_int)), mm.shape[0], ptrs, int(mode))
+    assert rc == 0
+    return arr
+
+
+ALIGN_CASES = sorted(n for n, c in cases.CASES.items() if c.get("align"))
+
+
+@pytest.mark.parametrize("name", ALIGN_CASES)
+def test_traceback_matches_reference_alignments(name, oracle, golden):
+    """Scores/end cells from the oracle -> host traceback -> start cells and operation strings equal to the
+    ones the reference produced (tests/golden), and every alignment re-scores to its score."""
+    lib = C.CDLL(LIB)
+    abi = oracle_lib.OpalABI(LIB)
+    case = cases.CASES[name]
+    q, db, m = cases.materialise(case)
+    for mode in case["modes"]:
+        rc, s, eq, et = oracle.search(q, db, case["gap_open"], case["gap_ext"], m, 1, MODES[mode])
+        arr = _traceback(lib, q, db, case["gap_open"], case["gap_ext"], m, MODES[mode], s, eq, et)
+        ends = [(arr[i].endLocationQuery, arr[i].endLocationTarget) for i in range(len(db))]
+        sq, st, ops = abi.alignments(arr)
+        want = golden[name]["align"][mode]
+        for i in range(len(db)):
+            if mode == "SW" and s[i] == 0:
+                assert (sq[i], st[i], ops[i]) == (-1, -1, b"") and ends[i] == (-1, -1)
+                continue
+            assert "".join(str(b) for b in ops[i]) == want["ops"][i], f"{name} {mode} #{i} operations"
+            assert (sq[i], st[i]) == (want["startQ"][i], want["startT"][i]), f"{name} {mode} #{i} start"
+            assert oracle.check_alignment(q, db[i], case["gap_open"], case["gap_ext"], m, s[i], sq[i], st[i],
+                                          eq[i], et[i], np.frombuffer(ops[i], np.uint8)) == 0
+
+
+@pytest.mark.skipif(not oracle_lib.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("mode", cases.ALL_MODES)
+def test_traceback_vs_live_reference(mode, oracle):
+    """test.cpp-shaped data (4 letters, match 3 / mismatch -1, gaps 11/1): alignments equal the reference's."""
+    lib = C.CDLL(LIB)
+    abi = oracle_lib.OpalABI(LIB)
+    ref = oracle_lib.RefLib()
+    q, db = cases.random4(4242, 300, 12, 4, 200, 900)
+    m = cases.simple_matrix(4, 3, -1)
+    rc, s, eq, et, sset, (rarr, _) = ref.search(q, db, 11, 1, m, 2, MODES[mode], 0)
+    rsq, rst, rops = ref.alignments(rarr)
+    arr = _traceback(lib, q, db, 11, 1, m, MODES[mode], s, eq, et)
+    sq, st, ops = abi.alignments(arr)
+    np.testing.assert_array_equal(sq, rsq)
+    np.testing.assert_array_equal(st, rst)
+    assert ops == rops
