@@ -98,12 +98,12 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    from opal_amd import synth
+    from opal_amd import shard, synth
     from opal_amd.api import MODES, PreparedDb
     from opal_amd.score_matrix import blosum50
 
     n = args.seqs
-    res, offs, lens = synth.database(n, seed=42, first=rank * n)  # this rank's shard of the same database
+    res, offs, lens = shard.synthetic_shard(n, rank, seed=42)  # this rank's shard of the same database
     query = synth.query(args.qlen, seed=7)
     matrix = blosum50()[1]
     mode = MODES[args.mode]
@@ -114,7 +114,6 @@ def main():
     score = torch.zeros(n, dtype=torch.int32, device=dev)
     endq = torch.zeros(n, dtype=torch.int32, device=dev) if args.search_type else None
     endt = torch.zeros(n, dtype=torch.int32, device=dev) if args.search_type else None
-    gathered = [torch.empty_like(score) for _ in range(world)] if (world > 1 and rank == 0) else None
     kernel_ms = []
 
     def step():
@@ -123,8 +122,7 @@ def main():
         if rc != 0:
             raise SystemExit(f"search failed rc={rc}")
         kernel_ms.append(kms)
-        if world > 1:
-            dist.gather(score, gathered, dst=0)  # the path's only exchange: per-sequence results to rank 0
+        shard.gather_results(score, world, rank)  # the path's only exchange: per-sequence scores to rank 0
 
     def fence():
         if world > 1:
