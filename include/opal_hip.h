@@ -67,6 +67,15 @@ typedef struct OpalHipLaunch {
     int* overflow_items;  /* capacity >= 2*num_pairs */
     void* stream;         /* hipStream_t or NULL */
     int priority;         /* 0..3: wave issue priority (s_setprio) of this launch's waves */
+    /* Queries too long for one wave (lanes_per_seq*rows_per_lane < query_length) run as several launches
+       over consecutive row chunks, top to bottom. chunk_flags == 0 means "single launch covers the query".
+       bit0: a chunk above exists (its bottom row is read from `boundary`), bit1: a chunk below exists
+       (this chunk's bottom row is written to `boundary`). SW/HW/OV: only the FIRST chunk may be shorter
+       than lanes_per_seq*rows_per_lane; NW: only the LAST one. */
+    int chunk_flags;
+    int chunk_row0, chunk_rows;
+    void* boundary;       /* 16 bytes per token of the packed database */
+    int* scratch;         /* [2 * number of sequences] carried across chunks (OV) */
 } OpalHipLaunch;
 
 #define OPAL_HIP_MAX_ROWS 40
@@ -85,7 +94,8 @@ void opal_hip_stream_destroy(void* stream);
 int opal_hip_stream_wait_event(void* stream, void* event);
 /* Enqueue one DP kernel. 0 on success, non-zero if the shape is not launchable. */
 int opal_hip_launch(const OpalHipLaunch* args);
-/* Smallest rows_per_lane >= min_rows for which this kernel variant is instantiated (0: none). */
+/* Smallest rows_per_lane >= min_rows for which this kernel variant is instantiated (0: none).
+   want_end bit0: the SW end-location pass; bit1: the multi-chunk (chunk_flags != 0) variants. */
 int opal_hip_rows_supported(int width, int mode, int want_end, int min_rows);
 /* Bytes of LDS the launch would need (query profile), for the scheduler's shape choice. */
 size_t opal_hip_lds_bytes(int width, int lanes_per_seq, int rows_per_lane, int alphabet_length);

@@ -33,6 +33,7 @@
 
 #define FLAG_SWEND 1  // SW second pass: locate the end cell of a known score
 #define FLAG_WRAP 2   // width 32 SW: detect 32-bit wrap of ulH + P (reference opal.cpp:302-303,339-351)
+#define FLAG_MULTI 4  // the query is processed in several row chunks; the boundary row travels through HBM
 
 #define WAVES_PER_BLOCK 4
 
@@ -52,6 +53,11 @@ struct KParams {
     int* ovfCount;
     int* ovfItems;
     int prio;
+    // FLAG_MULTI only: this launch covers query rows [q0, q0+chunkRows); chunkFlags bit0 = a chunk above
+    // exists (read its bottom row from `bnd`), bit1 = a chunk below exists (write ours to `bnd`).
+    int q0, chunkRows, chunkFlags;
+    uint2* bnd;    // per column {H, F-input} of the chunk boundary: width 16 [tokOff+c], width 32 [2*(tokOff+c)+half]
+    int* scratch;  // [2N] OV only: last-column maximum and its row carried across chunks
 };
 
 typedef void (*KernelFn)(const KParams);
@@ -155,6 +161,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
     constexpr int LANE_BYTES = SPAD * ES;  // one lane's segment of a profile row
     constexpr bool SWEND = (FLAGS & FLAG_SWEND) != 0;
     constexpr bool WRAP = (FLAGS & FLAG_WRAP) != 0;
+    constexpr bool MULTI = (FLAGS & FLAG_MULTI) != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int log2G = p.log2G;
@@ -165,7 +172,12 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
     // feed a real row). SW/HW/OV pad ABOVE it: a virtual row with profile 0, H[r][-1] = 0 and
     // E = -Go reproduces the zero top boundary exactly (H = 0, F passed down = -Go), and puts query row
     // Q-1 in the last register of the last lane, where it is read without a register select.
-    const int padTop = (MODE == MODE_NW) ? 0 : (G * S - Q);
+    // With FLAG_MULTI the launch covers CR query rows starting at q0; only the first chunk (SW/HW/OV) or the
+    // last one (NW) is partial, so the padding rule is unchanged.
+    const int q0 = MULTI ? p.q0 : 0;
+    const int CR = MULTI ? p.chunkRows : Q;
+    const bool hasPrev = MULTI && (p.chunkFlags & 1), hasNext = MULTI && (p.chunkFlags & 2);
+    const int padTop = (MODE == MODE_NW || hasPrev) ? 0 : (G * S - CR);
 
     // ---- stage the query profile in LDS: QP[letter][k][j] = M[query[k*S+j-padTop]][letter]; letter A = padding
     {
@@ -176,10 +188,10 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
             const int rem = idx - letter * perLetter;
             const int k = rem / SPAD;
             const int j = rem - k * SPAD;
-            const int r = k * S + j - padTop;
-            int v = V::NEG;    // pad residue, and (NW) rows below the query
-            if (r < 0) v = 0;  // virtual rows above the query: transparent
-            else if (letter < A && j < S && r < Q) v = p.matrix[(int)p.query[r] * A + letter];
+            const int lr = k * S + j - padTop;  // row within this chunk
+            int v = V::NEG;     // pad residue, and (NW) rows below the query
+            if (lr < 0) v = 0;  // virtual rows above the query: transparent
+            else if (letter < A && j < S && lr < CR) v = p.matrix[(int)p.query[q0 + lr] * A + letter];
             *reinterpret_cast<elem*>(lds + letter * stride + k * LANE_BYTES + j * ES) = (elem)v;
         }
     }
@@ -237,7 +249,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
     // ---- per-lane DP state
     const int Go = p.Go, Ge = p.Ge;
     const reg Qv = V::splat(Go), Rv = V::splat(Ge);
-    const int r0 = k * S - padTop;  // query row held in register 0 (negative: virtual rows)
+    const int r0 = q0 + k * S - padTop;  // query row held in register 0 (negative: virtual rows)
     reg Hp[S], En[S];               // H[r][c-1] and E[r][c] for my rows
 #pragma unroll
     for (int j = 0; j < S; j++) {
@@ -255,6 +267,8 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
     if ((MODE == MODE_NW || MODE == MODE_HW) && r0 + S - 1 >= 0)
         outH = V::splat(V::clampv(-(long long)Go - (long long)(r0 + S - 1) * Ge));
     reg diagIn = 0;  // H[r0-1][c-1]; H[-1][-1] = 0 in every mode
+    if (hasPrev && (MODE == MODE_NW || MODE == MODE_HW))  // H[q0-1][-1] for the first lane of a lower chunk
+        diagIn = V::splat(V::clampv(-(long long)Go - (long long)(q0 - 1) * Ge));
     const unsigned padOff = (unsigned)(A * stride);
     unsigned offv[NH];
 #pragma unroll
@@ -273,20 +287,26 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
         endCol[h] = INT_MAX; endRow[h] = -1;
     }
     // where query row Q-1 lives: NW: lane kLast, register jLast; otherwise last register of lane G-1
-    const int kLast = (MODE == MODE_NW) ? (Q - 1) / S : G - 1;
-    const int jLast = (MODE == MODE_NW) ? (Q - 1) - kLast * S : S - 1;
+    const int kLast = (MODE == MODE_NW) ? (CR - 1) / S : G - 1;
+    const int jLast = (MODE == MODE_NW) ? (CR - 1) - kLast * S : S - 1;
     // my registers [jlo, jhi) hold real query rows
-    int jlo = -r0, jhi = Q - r0;
+    int jlo = padTop - k * S, jhi = CR + padTop - k * S;
     jlo = jlo < 0 ? 0 : (jlo > S ? S : jlo);
     jhi = jhi < 0 ? 0 : (jhi > S ? S : jhi);
 
     // token prefetch (one step ahead)
     unsigned tokNext = 0;
     if (0 < slotLen) tokNext = p.tokens[tokBase];
+    // chunk boundary prefetch (one step ahead): {H, F-input} of the row above my chunk at the next column
+    auto bndIdx = [&](int c) -> uint64_t { return WIDTH == 16 ? tokBase + (uint64_t)c : 2 * (tokBase + (uint64_t)c) + (uint64_t)half0; };
+    uint2 bndNext = make_uint2(0u, 0u);
+    if (hasPrev && 0 < slotLen) bndNext = p.bnd[bndIdx(0)];
 
     for (int s = 0; s < nsteps; s++) {
         const unsigned tok = tokNext;
         if (s + 1 < slotLen) tokNext = p.tokens[tokBase + (uint64_t)(s + 1)];
+        const uint2 bndCur = bndNext;
+        if (hasPrev && s + 1 < slotLen) bndNext = p.bnd[bndIdx(s + 1)];
 
         // ---- inputs of this column: from the boundary (lane 0 of the slot) or from the lane above
         reg topH = 0;
@@ -294,8 +314,13 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
         reg inH = (reg)shr1((unsigned)outH, 0u);
         reg inF = (reg)shr1((unsigned)outF, 0u);
         if (k == 0) {
-            inH = topH;
-            inF = (MODE == MODE_SW) ? V::subu(topH, Qv) : V::subs(topH, Qv);
+            if (hasPrev) {
+                inH = (reg)bndCur.x;
+                inF = (reg)bndCur.y;
+            } else {
+                inH = topH;
+                inF = (MODE == MODE_SW) ? V::subu(topH, Qv) : V::subs(topH, Qv);
+            }
         }
 #pragma unroll
         for (int h = 0; h < NH; h++) {
@@ -363,6 +388,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
             }
             outH = h;
             outF = f;
+            if (hasNext && k == G - 1 && c >= 0 && c < slotLen) p.bnd[bndIdx(c)] = make_uint2((unsigned)outH, (unsigned)outF);
 
             if (MODE == MODE_SW && SWEND) {
                 // rare: this column holds a cell equal to the known score -> record the first (col, row)
@@ -386,7 +412,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
                 // final cell: once per sequence, on the lane/register holding query row Q-1
                 bool fin = false;
 #pragma unroll
-                for (int hh = 0; hh < NH; hh++) fin |= (k == kLast && c == len[hh] - 1);
+                for (int hh = 0; hh < NH; hh++) fin |= (k == kLast && c == len[hh] - 1 && !hasNext);
                 if (fin) {
                     const reg hl = SelectRow<reg, S, 0, S>::get(Hp, jLast);
 #pragma unroll
@@ -394,7 +420,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
                         if (c == len[hh] - 1) best[hh] = V::half(hl, hh);
                 }
             }
-            if ((MODE == MODE_HW || MODE == MODE_OV) && k == kLast) {
+            if ((MODE == MODE_HW || MODE == MODE_OV) && k == kLast && !hasNext) {
                 // last query row = last register of the last lane = this column's outH
 #pragma unroll
                 for (int hh = 0; hh < NH; hh++) {
@@ -436,10 +462,15 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
 #pragma unroll
             for (int hh = 0; hh < NH; hh++) {
                 if (seq[hh] < 0) continue;
-                const int sc = V::half(mx, hh);
+                int sc = V::half(mx, hh);
+                int prev = 0;
+                if (hasPrev) { prev = p.outScore[seq[hh]]; sc = sc > prev ? sc : prev; }  // maximum over the chunks so far
                 if (WIDTH == 16 && sc >= V::SATMAX) {  // saturated (opal.cpp:364-370): hand over to width 32
-                    const int at = atomicAdd(p.ovfCount, 1);
-                    p.ovfItems[at] = pairIdx * 2 + half0 + hh;
+                    if (!(hasPrev && prev >= V::SATMAX)) {
+                        const int at = atomicAdd(p.ovfCount, 1);
+                        p.ovfItems[at] = pairIdx * 2 + half0 + hh;
+                    }
+                    if (MULTI) p.outScore[seq[hh]] = V::SATMAX;  // marker for the chunks below
                 } else if (WIDTH == 32 && WRAP && wrapped) {
                     atomicAdd(p.ovfCount, 1);  // 32-bit overflow: the host returns OPAL_ERR_OVERFLOW
                 } else {
@@ -459,6 +490,10 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
                 if (ocol < col || (ocol == col && osrc < src)) { col = ocol; row = orow; src = osrc; }
             }
             if (k == 0 && seq[hh] >= 0 && target[hh] > 0) {
+                if (hasPrev) {  // an upper chunk (smaller rows) keeps the cell unless ours lies in an earlier column
+                    const int pc = p.outEndT[seq[hh]], pr = p.outEndQ[seq[hh]];
+                    if (pc >= 0 && !(col != INT_MAX && col < pc)) { col = pc; row = pr; }
+                }
                 p.outEndQ[seq[hh]] = (col == INT_MAX) ? -1 : row;
                 p.outEndT[seq[hh]] = (col == INT_MAX) ? -1 : col;
             }
@@ -475,9 +510,16 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
                     const int ov = __shfl_xor(v, d, 64), orow = __shfl_xor(r, d, 64);
                     if (ov > v || (ov == v && orow >= 0 && (r < 0 || orow < r))) { v = ov; r = orow; }
                 }
+                if (MULTI && seq[hh] >= 0) {  // carry the last-column maximum across chunks (upper rows win ties)
+                    if (hasPrev) {
+                        const int pv = p.scratch[2 * seq[hh]], pr = p.scratch[2 * seq[hh] + 1];
+                        if (pv >= v) { v = pv; r = pr; }
+                    }
+                    if (hasNext && k == 0) { p.scratch[2 * seq[hh]] = v; p.scratch[2 * seq[hh] + 1] = r; }
+                }
                 if (k == kLast && v > prevBest[hh]) { sc = v; et = len[hh] - 1; eq = r; }
             }
-            if (k == kLast && seq[hh] >= 0) {
+            if (k == kLast && seq[hh] >= 0 && !hasNext) {
                 p.outScore[seq[hh]] = sc;
                 if (p.outEndQ) { p.outEndQ[seq[hh]] = eq; p.outEndT[seq[hh]] = et; }
             }
@@ -489,3 +531,5 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
 KernelFn opal_kernel_sw16(int rows);                      // width 16, SW, score only: rows 1..40
 KernelFn opal_kernel_w16(int mode, int flags, int rows);  // width 16, the other variants: rows 4,8,..,40
 KernelFn opal_kernel_w32(int mode, int flags, int rows);  // width 32: rows 8,16,24,32,40
+KernelFn opal_kernel_w16_multi(int mode, int flags, int rows);  // FLAG_MULTI variants
+KernelFn opal_kernel_w32_multi(int mode, int flags, int rows);

@@ -18,3 +18,15 @@ KernelFn opal_kernel_w16(int mode, int flags, int rows) {
     }
     return nullptr;
 }
+
+// Multi-chunk variants (queries longer than one wave can hold): every mode, rows in steps of 4.
+KernelFn opal_kernel_w16_multi(int mode, int flags, int rows) {
+    using Seq = std::make_integer_sequence<int, 10>;
+    switch (mode) {
+    case MODE_NW: return pick<MODE_NW, FLAG_MULTI>(rows, Seq{});
+    case MODE_HW: return pick<MODE_HW, FLAG_MULTI>(rows, Seq{});
+    case MODE_OV: return pick<MODE_OV, FLAG_MULTI>(rows, Seq{});
+    case MODE_SW: return (flags & FLAG_SWEND) ? pick<MODE_SW, FLAG_SWEND | FLAG_MULTI>(rows, Seq{}) : pick<MODE_SW, FLAG_MULTI>(rows, Seq{});
+    }
+    return nullptr;
+}

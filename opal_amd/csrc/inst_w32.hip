@@ -21,3 +21,17 @@ KernelFn opal_kernel_w32(int mode, int flags, int rows) {
     }
     return nullptr;
 }
+
+KernelFn opal_kernel_w32_multi(int mode, int flags, int rows) {
+    using Seq = std::make_integer_sequence<int, 5>;
+    switch (mode) {
+    case MODE_NW: return pick<MODE_NW, FLAG_MULTI>(rows, Seq{});
+    case MODE_HW: return pick<MODE_HW, FLAG_MULTI>(rows, Seq{});
+    case MODE_OV: return pick<MODE_OV, FLAG_MULTI>(rows, Seq{});
+    case MODE_SW:
+        if (flags & FLAG_SWEND) return pick<MODE_SW, FLAG_SWEND | FLAG_MULTI>(rows, Seq{});
+        if (flags & FLAG_WRAP) return pick<MODE_SW, FLAG_WRAP | FLAG_MULTI>(rows, Seq{});
+        return pick<MODE_SW, FLAG_MULTI>(rows, Seq{});
+    }
+    return nullptr;
+}

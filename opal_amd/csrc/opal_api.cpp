@@ -94,6 +94,9 @@ struct OpalxDb {
     int* dOvfCount = nullptr;  // [2] counters: width-16 overflow list length, width-32 wrap count
     int* dOvfItems = nullptr;  // [2P]
     int* dWork = nullptr;      // [2P] scratch work list
+    size_t numTokens = 0;
+    void* dBoundary = nullptr; // 16 B per token: chunk-boundary rows of long queries (allocated on first use)
+    int* dScratch = nullptr;   // [2N] per-sequence values carried across query chunks
     unsigned char* dQuery = nullptr;
     int* dMatrix = nullptr;
     size_t queryCap = 0, matrixCap = 0;
@@ -138,6 +141,7 @@ static OpalxDb* upload(HostPack& hp) {
     db->pairLen = hp.pairLen;
     db->pairSeq = hp.pairSeq;
     db->emptySeqs = hp.emptySeqs;
+    db->numTokens = hp.tokens.size();
     const size_t P = hp.pairOff.size();
     db->dTokens = (uint16_t*)opal_hip_malloc(hp.tokens.size() * sizeof(uint16_t));
     db->dPairOff = (uint64_t*)opal_hip_malloc(P * sizeof(uint64_t));
@@ -241,6 +245,60 @@ static std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass,
     return out;
 }
 
+// Queries that no single wave geometry can hold (more than 64 lanes x 40 rows, or a query profile
+// beyond the 160 KiB of LDS): the query is cut into row chunks processed top to bottom by one launch each;
+// the bottom row of a chunk (H and the F input of the next row, per column) travels through HBM.
+static int launch_chunked(const SearchCtx& c, int width, int swEndPass, int detectWrap, const int* work, int firstItem,
+                          int numItems, int* ovfCounter) {
+    int bestG = 0, bestS = 0;
+    for (int G = 64; G >= 1; G /= 2)
+        for (int S = OPAL_HIP_MAX_ROWS; S >= 1; S--) {
+            if (opal_hip_rows_supported(width, c.mode, swEndPass | 2, S) != S) continue;
+            if (opal_hip_lds_bytes(width, G, S, c.A) > 160 * 1024) continue;
+            if ((long long)G * S > (long long)bestG * bestS) { bestG = G; bestS = S; }
+            break;  // largest S for this G
+        }
+    if (const char* geo = getenv("OPAL_HIP_CHUNK_GEOMETRY")) {  // "G,S": test hook to force small chunks
+        int g = 0, r = 0;
+        if (sscanf(geo, "%d,%d", &g, &r) == 2 && opal_hip_rows_supported(width, c.mode, swEndPass | 2, r) == r &&
+            opal_hip_lds_bytes(width, g, r, c.A) <= 160 * 1024) { bestG = g; bestS = r; }
+    }
+    if (!bestG) {
+        fprintf(stderr, "[opal] alphabet of %d letters does not fit the on-chip query profile at width %d\n", c.A, width);
+        return OPAL_ERR_NO_SIMD_SUPPORT;
+    }
+    OpalxDb* db = c.db;
+    if (!db->dBoundary) db->dBoundary = opal_hip_malloc(16 * (db->numTokens + 8));
+    if (!db->dScratch) db->dScratch = (int*)opal_hip_malloc(2 * sizeof(int) * (size_t)std::max(db->numSeqs, 1));
+    if (!db->dBoundary || !db->dScratch) return OPAL_ERR_NO_SIMD_SUPPORT;
+    const int cap = bestG * bestS;
+    const int nchunks = (c.Q + cap - 1) / cap;
+    const int firstRows = c.Q - (nchunks - 1) * cap;  // SW/HW/OV: the partial chunk is the first one
+    for (int ch = 0; ch < nchunks; ch++) {
+        int row0, rows;
+        if (c.mode == OPAL_MODE_NW) { row0 = ch * cap; rows = std::min(cap, c.Q - row0); }
+        else { row0 = ch == 0 ? 0 : firstRows + (ch - 1) * cap; rows = ch == 0 ? firstRows : cap; }
+        OpalHipLaunch a;
+        memset(&a, 0, sizeof a);
+        a.width = width; a.mode = c.mode; a.want_end = swEndPass; a.detect_wrap = detectWrap;
+        a.lanes_per_seq = bestG; a.rows_per_lane = bestS;
+        a.query = db->dQuery; a.query_length = c.Q; a.score_matrix = db->dMatrix; a.alphabet_length = c.A;
+        a.gap_open = c.Go; a.gap_ext = c.Ge;
+        a.tokens = db->dTokens; a.pair_token_offset = db->dPairOff; a.pair_len = db->dPairLen; a.pair_seq = db->dPairSeq;
+        a.work = work; a.first_item = firstItem; a.num_items = numItems;
+        a.out_score = c.dScore; a.out_end_query = c.wantEnd ? c.dEndQ : nullptr; a.out_end_target = c.wantEnd ? c.dEndT : nullptr;
+        a.overflow_count = ovfCounter; a.overflow_items = db->dOvfItems;
+        a.chunk_flags = (ch > 0 ? 1 : 0) | (ch < nchunks - 1 ? 2 : 0);
+        a.chunk_row0 = row0; a.chunk_rows = rows;
+        a.boundary = db->dBoundary; a.scratch = db->dScratch;
+        if (getenv("OPAL_HIP_DEBUG"))
+            fprintf(stderr, "[opal] chunk %d/%d rows [%d,+%d) width=%d mode=%d end=%d G=%d rows/lane=%d\n", ch + 1, nchunks, row0,
+                    rows, width, c.mode, swEndPass, bestG, bestS);
+        if (opal_hip_launch(&a)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    }
+    return 0;
+}
+
 template <typename LenOf>
 static int launch_range(const SearchCtx& c, int width, int swEndPass, int detectWrap, const int* work, int firstItem,
                         int numItems, LenOf lenOf, int* ovfCounter) {
@@ -253,11 +311,8 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
     } else {
         classes = plan_classes(width, c.mode, swEndPass, c.Q, c.A, lenOf, firstItem, numItems);
     }
-    if (classes.empty()) {
-        fprintf(stderr, "[opal] query of %d residues (alphabet %d) does not fit the on-chip query profile at width %d\n",
-                c.Q, c.A, width);
-        return OPAL_ERR_NO_SIMD_SUPPORT;
-    }
+    if (classes.empty() || getenv("OPAL_HIP_FORCE_CHUNKS"))
+        return launch_chunked(c, width, swEndPass, detectWrap, work, firstItem, numItems, ovfCounter);
     // The last class (the bulk of the database) runs on the null stream; the classes of long
     // sequences run beside it on up to three side streams (one hardware queue each), forked from and
     // joined back into the null stream with events, longest sequences enqueued first.
@@ -496,6 +551,7 @@ extern "C" void opalx_db_destroy(OpalxDb* db) {
     opal_hip_free(db->dTokens); opal_hip_free(db->dPairOff); opal_hip_free(db->dPairLen); opal_hip_free(db->dPairSeq);
     opal_hip_free(db->dOvfCount); opal_hip_free(db->dOvfItems); opal_hip_free(db->dWork);
     opal_hip_free(db->dQuery); opal_hip_free(db->dMatrix);
+    opal_hip_free(db->dBoundary); opal_hip_free(db->dScratch);
     for (void* st : db->streams) opal_hip_stream_destroy(st);
     for (void* ev : db->events) opal_hip_event_destroy(ev);
     delete db;

@@ -96,6 +96,11 @@ extern "C" size_t opal_hip_lds_bytes(int width, int lanes_per_seq, int rows_per_
 }
 
 static KernelFn pick_kernel(int width, int mode, int flags, int rows) {
+    if (flags & FLAG_MULTI) {
+        if (width == 16) return opal_kernel_w16_multi(mode, flags, rows);
+        if (width == 32) return opal_kernel_w32_multi(mode, flags, rows);
+        return nullptr;
+    }
     if (width == 16) return opal_kernel_w16(mode, flags, rows);
     if (width == 32) return opal_kernel_w32(mode, flags, rows);
     return nullptr;
@@ -105,13 +110,15 @@ static int launch_flags(const OpalHipLaunch* a) {
     int flags = 0;
     if (a->mode == MODE_SW && a->want_end) flags |= FLAG_SWEND;
     if (a->mode == MODE_SW && a->width == 32 && a->detect_wrap && !a->want_end) flags |= FLAG_WRAP;
+    if (a->chunk_flags) flags |= FLAG_MULTI;
     return flags;
 }
 
 extern "C" int opal_hip_rows_supported(int width, int mode, int want_end, int min_rows) {
     OpalHipLaunch a;
     memset(&a, 0, sizeof a);
-    a.width = width; a.mode = mode; a.want_end = want_end;
+    a.width = width; a.mode = mode; a.want_end = want_end & 1;
+    a.chunk_flags = (want_end & 2) ? 1 : 0;  /* bit1 of want_end: ask about the multi-chunk variants */
     for (int r = min_rows < 1 ? 1 : min_rows; r <= OPAL_HIP_MAX_ROWS; r++)
         if (pick_kernel(width, mode, launch_flags(&a), r)) return r;
     return 0;
@@ -124,7 +131,9 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
     if (a->mode < 0 || a->mode > 3) { snprintf(g_err, sizeof g_err, "bad mode %d", a->mode); return 3; }
     KernelFn fn = nullptr;
     if ((1 << log2G) == G && G <= 64 && a->rows_per_lane >= 1 && a->rows_per_lane <= OPAL_HIP_MAX_ROWS &&
-        (long long)G * a->rows_per_lane >= a->query_length && a->query_length >= 1)
+        (long long)G * a->rows_per_lane >= (a->chunk_flags ? a->chunk_rows : a->query_length) && a->query_length >= 1 &&
+        (!a->chunk_flags || (a->boundary && a->chunk_rows >= 1 && a->chunk_row0 >= 0 &&
+                             a->chunk_row0 + a->chunk_rows <= a->query_length)))
         fn = pick_kernel(a->width, a->mode, launch_flags(a), a->rows_per_lane);
     if (!fn) {
         snprintf(g_err, sizeof g_err, "unlaunchable shape: width=%d mode=%d G=%d rows=%d Q=%d", a->width, a->mode, G,
@@ -142,6 +151,11 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
     p.outScore = a->out_score; p.outEndQ = a->out_end_query; p.outEndT = a->out_end_target;
     p.ovfCount = a->overflow_count; p.ovfItems = a->overflow_items;
     p.prio = a->priority;
+    p.q0 = a->chunk_flags ? a->chunk_row0 : 0;
+    p.chunkRows = a->chunk_flags ? a->chunk_rows : a->query_length;
+    p.chunkFlags = a->chunk_flags;
+    p.bnd = (uint2*)a->boundary;
+    p.scratch = a->scratch;
     const int slots = 64 / G;
     const int jobs = (a->num_items + slots - 1) / slots;
     const int blocks = (jobs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;

@@ -206,3 +206,52 @@ def test_dropin_cli_output_equals_reference_cli(mode, level):
         # score-0 rows have undefined end locations in the reference; none occur for this pair
         pass
     assert la == lb
+
+
+@pytest.mark.parametrize("geometry", ["2,8", "8,8", "1,16", "64,8", "4,40"])
+@pytest.mark.parametrize("mode", ["SW", "NW", "HW", "OV"])
+def test_query_chunks_forced(geometry, mode, ours, oracle, monkeypatch):
+    """Long-query path on short inputs: force the query to be cut into many row chunks (boundary row through
+    HBM) and compare with the oracle, 16-bit and 32-bit kernels, score and end locations."""
+    from opal_amd import synth
+    from opal_amd.score_matrix import blosum50
+    res, offs, lens = synth.database(90, seed=321)
+    db = [res[offs[i]:offs[i + 1]] for i in range(90)]
+    q = synth.query(203, seed=11)
+    m = blosum50()[1]
+    monkeypatch.setenv("OPAL_HIP_FORCE_CHUNKS", "1")
+    monkeypatch.setenv("OPAL_HIP_CHUNK_GEOMETRY", geometry)
+    got = ours.search(q, db, 3, 1, m, 1, MODES[mode])[:4]
+    _check(got, oracle.search(q, db, 3, 1, m, 1, MODES[mode]), mode, f"chunks {geometry} {mode}")
+    # 32-bit kernels: scores beyond int16
+    m32 = m * 300
+    got = ours.search(q, db[:30], 900, 300, m32, 1, MODES[mode])[:4]
+    _check(got, oracle.search(q, db[:30], 900, 300, m32, 1, MODES[mode]), mode, f"chunks32 {geometry} {mode}")
+
+
+@pytest.mark.parametrize("mode", ["SW", "NW", "HW", "OV"])
+def test_query_longer_than_one_wave(mode, ours, oracle):
+    """3000-residue query: more rows than 64 lanes x 40 registers, so it runs as two chunks."""
+    from opal_amd import synth
+    from opal_amd.score_matrix import blosum50
+    res, offs, lens = synth.database(40, seed=77)
+    db = [res[offs[i]:offs[i + 1]] for i in range(40)]
+    q = synth.query(3000, seed=5)
+    db.append(q[100:2900].copy())  # a long near-identical target: high scores across the chunk boundary
+    m = blosum50()[1]
+    got = ours.search(q, db, 3, 1, m, 1, MODES[mode])[:4]
+    _check(got, oracle.search(q, db, 3, 1, m, 1, MODES[mode]), mode, f"Q=3000 {mode}")
+
+
+def test_large_alphabet_profile_exceeds_lds(ours, oracle):
+    """200-letter alphabet: the query profile of a 700-residue query does not fit LDS in one piece."""
+    from opal_amd import synth
+    A = 200
+    rnd = lambda seed, n: (synth.splitmix64(seed, 0, n) % np.uint64(A)).astype(np.uint8)
+    q = rnd(1, 700)
+    db = [rnd(10 + i, 50 + 37 * i) for i in range(25)] + [q[50:650].copy()]
+    m = ((synth.splitmix64(99, 0, A * A) % np.uint64(9)).astype(np.int32) - 5).reshape(A, A)
+    np.fill_diagonal(m, 6)
+    for mode in ("SW", "HW"):
+        got = ours.search(q, db, 4, 1, m, 1, MODES[mode])[:4]
+        _check(got, oracle.search(q, db, 4, 1, m, 1, MODES[mode]), mode, f"A=200 {mode}")
