@@ -154,6 +154,13 @@ def main():
         alg_bytes = cells * 8.0
         achieved = alg_bytes / (kms * 1e-3) / 1e9
         kernel_gcups = cells / (kms * 1e-3) / 1e9
+        traffic = None
+        try:  # HBM bytes per step measured offline with rocprofv3 PMC passes (scripts/prof_hbm.sh), same workload only
+            if (args.qlen, n, args.mode, args.search_type, args.gap_open) == (300, 100000, "SW", 0, 11):
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as fh:
+                    traffic = json.load(fh)["hbm_bytes_per_step"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
         out = {
             "metric": "GCUPS (DP cell updates/s), SW score-only, 1 query vs synthetic protein DB",
             "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -165,7 +172,8 @@ def main():
                                    f"{args.gap_open}/{args.gap_ext}, packed int16 first rung",
                        "cells_per_step_per_gpu": cells, "parallelism": f"db-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch group (PMC, profiles/r01_pmc_hbm.json)", "algorithmic_bytes": alg_bytes,
                          "note": "algorithmic bytes = 8 B/cell of a column-streaming int16 design; this kernel keeps "
                                  "the column in VGPRs, so it is VALU-issue bound, see valu_roofline"},
             "valu_roofline": {"bound": "valu-issue", "kernel_gcups": round(kernel_gcups, 1), "kernel_ms": round(kms, 4),
