@@ -28,10 +28,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-# VALU issue bound of the width-16 kernel (profiles/r01_ubench_valu_*.txt): v_pk_*_i16 and v_perm_b32 issue one
-# wave-instruction per 4 clocks per SIMD; a row of a column costs 10 of them and covers 64 lanes x 2 sequences.
-SIMDS, CLOCK_HZ, INSTR_PER_ROW, CLK_PER_INSTR, CELLS_PER_INSTR_ROW = 1024, 2.4e9, 10.0, 4.0, 128.0
-VALU_PEAK_GCUPS = SIMDS * CLOCK_HZ / (INSTR_PER_ROW * CLK_PER_INSTR / CELLS_PER_INSTR_ROW) / 1e9
+# VALU issue bound of the plain-16-bit kernel (profiles/r01_ubench_valu_*.txt): v_add_u16 / v_sub_u16 clamp /
+# v_max_i16 issue one wave-instruction per 2 clocks per SIMD; a cell costs 9 of them, a wave-instruction covers
+# 64 lanes = 64 cells. (The packed-int16 kernel: 10 instructions x 4 clocks per 128 cells, i.e. 10% lower.)
+SIMDS, CLOCK_HZ, INSTR_PER_CELL, CLK_PER_INSTR, LANES = 1024, 2.4e9, 9.0, 2.0, 64.0
+VALU_PEAK_GCUPS = SIMDS * CLOCK_HZ / (INSTR_PER_CELL * CLK_PER_INSTR / LANES) / 1e9
 
 
 def cpu_baseline(query, res, offs, lens, matrix, gap_open, gap_ext):
@@ -169,7 +170,7 @@ def main():
             "config": {"workload": f"{args.qlen}-aa query (seed 7) vs {n} synthetic protein seqs per GPU (seed 42, "
                                    f"mean {float(offs[-1]) / n:.0f} aa), {args.mode} "
                                    f"{'score-only' if not args.search_type else 'score+end'}, BLOSUM50, gaps "
-                                   f"{args.gap_open}/{args.gap_ext}, packed int16 first rung",
+                                   f"{args.gap_open}/{args.gap_ext}, plain 16-bit first rung",
                        "cells_per_step_per_gpu": cells, "parallelism": f"db-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -178,7 +179,7 @@ def main():
                                  "the column in VGPRs, so it is VALU-issue bound, see valu_roofline"},
             "valu_roofline": {"bound": "valu-issue", "kernel_gcups": round(kernel_gcups, 1), "kernel_ms": round(kms, 4),
                               "peak_gcups": round(VALU_PEAK_GCUPS, 0), "frac": round(kernel_gcups / VALU_PEAK_GCUPS, 4),
-                              "model": "1024 SIMDs x 2.4 GHz / (10 packed instr x 4 clk per 128 cells)"},
+                              "model": "1024 SIMDs x 2.4 GHz x 64 lanes / (9 full-rate 16-bit instr x 2 clk per cell)"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(query, res, offs, lens, matrix, args.gap_open, args.gap_ext)

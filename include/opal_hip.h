@@ -34,7 +34,8 @@ extern "C" {
 /* One kernel launch over `num_items` work items. All pointers are device pointers. */
 typedef struct OpalHipLaunch {
     /* what to compute */
-    int width;        /* 16: two sequences per lane as packed int16; 32: one sequence per lane, int32 */
+    int width;        /* 16: two sequences per lane as packed int16; 17: one sequence per lane, plain 16-bit
+                         (full-rate VALU); 32: one sequence per lane, int32 */
     int mode;         /* OPAL_MODE_* */
     int want_end;     /* 0: score only; 1: also end locations (SW: second pass, needs out_score filled) */
     int detect_wrap;  /* width 32, SW only: test ulH+P for 32-bit wrap (reference opal.cpp:302-303) */
@@ -54,7 +55,7 @@ typedef struct OpalHipLaunch {
     const int* pair_len;         /* [2*num_pairs] lengths of A and B (0 = absent) */
     const int* pair_seq;         /* [2*num_pairs] caller index of A and B (-1 = absent) */
     /* work list: item i is work[i] if work != NULL else first_item + i.
-       width 16: an item is a pair index; width 32: an item is pair*2 + half */
+       width 16: an item is a pair index; width 17 and 32: an item is pair*2 + half */
     const int* work;
     int first_item;
     int num_items;
@@ -75,6 +76,9 @@ typedef struct OpalHipLaunch {
     int chunk_flags;
     int chunk_row0, chunk_rows;
     void* boundary;       /* 16 bytes per token of the packed database */
+    /* width 17 only: additions wrap, so scores >= sat_limit (= 32767 - largest matrix entry) are handed to
+       the re-run list; neg_pad is the profile value of padding columns (SW: -sat_limit, else 0) */
+    int sat_limit, neg_pad;
     int* scratch;         /* [2 * number of sequences] carried across chunks (OV) */
 } OpalHipLaunch;
 

@@ -58,6 +58,7 @@ struct KParams {
     int q0, chunkRows, chunkFlags;
     uint2* bnd;    // per column {H, F-input} of the chunk boundary: width 16 [tokOff+c], width 32 [2*(tokOff+c)+half]
     int* scratch;  // [2N] OV only: last-column maximum and its row carried across chunks
+    int satLimit, negPad;  // width 17 only
 };
 
 typedef void (*KernelFn)(const KParams);
@@ -105,6 +106,58 @@ template <> struct Vec<32> {  // one int32 score per register
     static __device__ __forceinline__ int half(reg a, int) { return a; }
     static __device__ __forceinline__ int clampv(long long v) {
         return v < -(1LL << 30) ? -(1 << 30) : (v > (1LL << 30) ? (1 << 30) : (int)v);
+    }
+};
+
+// Width "17": ONE sequence per lane in plain (non-packed) 16-bit arithmetic. On gfx950 the packed
+// v_pk_*_i16 instructions and v_perm_b32 issue every 4 clocks, the scalar 16-bit v_add_u16 / v_sub_u16
+// (clamp) / v_max_i16 every 2 (profiles/r01_ubench_valu_survey.txt), and one sequence per lane needs no
+// v_perm to pair profile values: 9 full-rate instructions per cell instead of 10 half-rate ones per two.
+// The instructions are pinned with inline asm because hipcc would fuse two v_max_i16 into one
+// v_max3_i16, which issues every 8 clocks. Values live in the low 16 bits of a VGPR. Additions wrap, so
+// the host passes a limit below which no wrap can have happened (satLimit = 32767 - max matrix entry);
+// scores at or above it are re-run at 32 bits.
+template <> struct Vec<17> {
+    typedef unsigned int reg;
+    typedef int elem;  // LDS profile entries are 4 bytes wide (value in the low half): no unpacking
+    static constexpr int NH = 1;
+    static constexpr int NEG = -32768;  // replaced by KParams::negPad
+    static constexpr int SATMAX = 32767;
+    static __device__ __forceinline__ reg splat(int v) { return (unsigned)v & 0xffffu; }
+    static __device__ __forceinline__ reg adds(reg a, reg b) { reg r; asm("v_add_u16_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+    static __device__ __forceinline__ reg subs(reg a, reg b) { reg r; asm("v_sub_u16_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+    static __device__ __forceinline__ reg subu(reg a, reg b) { reg r; asm("v_sub_u16_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
+    static __device__ __forceinline__ reg maxs(reg a, reg b) { reg r; asm("v_max_i16_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+    static __device__ __forceinline__ int half(reg a, int) { return (int)(short)(a & 0xffffu); }
+    static __device__ __forceinline__ int clampv(long long v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : (int)v); }
+    // One row of one column as ONE asm block (hipcc pads every asm statement with a wait state and cannot
+    // coalesce registers through it, so the block is as large as the data flow allows). d = H(diag) + P.
+    // SW: E and F stay >= 0 through the unsigned clamp, so H >= 0 without a max against 0.
+    static __device__ __forceinline__ void row_sw(reg d, reg& e, reg& f, reg& acc, reg& h, reg Qv, reg Rv) {
+        reg hq;
+        asm("v_max_i16_e32 %0, %5, %1\n\t"
+            "v_max_i16_e32 %0, %0, %2\n\t"
+            "v_sub_u16_e64 %1, %1, %7 clamp\n\t"
+            "v_sub_u16_e64 %4, %0, %6 clamp\n\t"
+            "v_sub_u16_e64 %2, %2, %7 clamp\n\t"
+            "v_max_i16_e32 %3, %3, %0\n\t"
+            "v_max_i16_e32 %1, %1, %4\n\t"
+            "v_max_i16_e32 %2, %2, %4"
+            : "=&v"(h), "+v"(e), "+v"(f), "+v"(acc), "=&v"(hq)
+            : "v"(d), "v"(Qv), "v"(Rv));
+    }
+    // NW/HW/OV: signed, wrapping (the host proves a-priori that nothing leaves the 16-bit range)
+    static __device__ __forceinline__ void row_global(reg d, reg& e, reg& f, reg& h, reg Qv, reg Rv) {
+        reg hq;
+        asm("v_max_i16_e32 %0, %4, %1\n\t"
+            "v_max_i16_e32 %0, %0, %2\n\t"
+            "v_sub_u16_e32 %1, %1, %6\n\t"
+            "v_sub_u16_e32 %3, %0, %5\n\t"
+            "v_sub_u16_e32 %2, %2, %6\n\t"
+            "v_max_i16_e32 %1, %1, %3\n\t"
+            "v_max_i16_e32 %2, %2, %3"
+            : "=&v"(h), "+v"(e), "+v"(f), "=&v"(hq)
+            : "v"(d), "v"(Qv), "v"(Rv));
     }
 };
 
@@ -174,6 +227,8 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
     // Q-1 in the last register of the last lane, where it is read without a register select.
     // With FLAG_MULTI the launch covers CR query rows starting at q0; only the first chunk (SW/HW/OV) or the
     // last one (NW) is partial, so the padding rule is unchanged.
+    const int satLimit = (WIDTH == 17) ? p.satLimit : V::SATMAX;  // scores >= this are re-run at 32 bits
+    const int negPad = (WIDTH == 17) ? p.negPad : V::NEG;         // profile value of pad residues / pad rows
     const int q0 = MULTI ? p.q0 : 0;
     const int CR = MULTI ? p.chunkRows : Q;
     const bool hasPrev = MULTI && (p.chunkFlags & 1), hasNext = MULTI && (p.chunkFlags & 2);
@@ -189,7 +244,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
             const int k = rem / SPAD;
             const int j = rem - k * SPAD;
             const int lr = k * S + j - padTop;  // row within this chunk
-            int v = V::NEG;     // pad residue, and (NW) rows below the query
+            int v = negPad;     // pad residue, and (NW) rows below the query
             if (lr < 0) v = 0;  // virtual rows above the query: transparent
             else if (letter < A && j < S && lr < CR) v = p.matrix[(int)p.query[q0 + lr] * A + letter];
             *reinterpret_cast<elem*>(lds + letter * stride + k * LANE_BYTES + j * ES) = (elem)v;
@@ -218,8 +273,8 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
     if (valid) {
         const int w = p.firstItem + itemIdx;
         const int item = p.work ? p.work[w] : w;
-        pairIdx = (WIDTH == 16) ? item : (item >> 1);
-        half0 = (WIDTH == 16) ? 0 : (item & 1);
+        pairIdx = (NH == 2) ? item : (item >> 1);
+        half0 = (NH == 2) ? 0 : (item & 1);
         tokBase = p.pairOff[pairIdx];
 #pragma unroll
         for (int h = 0; h < NH; h++) {
@@ -241,7 +296,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
 #pragma unroll
         for (int h = 0; h < NH; h++) {
             int t = (seq[h] >= 0) ? p.outScore[seq[h]] : 0;
-            if (WIDTH == 16 && t >= V::SATMAX) t = 0;  // the width-32 re-run owns this one
+            if (WIDTH != 32 && t >= satLimit) t = 0;  // the width-32 re-run owns this one
             target[h] = t;
         }
     }
@@ -298,7 +353,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
     unsigned tokNext = 0;
     if (0 < slotLen) tokNext = p.tokens[tokBase];
     // chunk boundary prefetch (one step ahead): {H, F-input} of the row above my chunk at the next column
-    auto bndIdx = [&](int c) -> uint64_t { return WIDTH == 16 ? tokBase + (uint64_t)c : 2 * (tokBase + (uint64_t)c) + (uint64_t)half0; };
+    auto bndIdx = [&](int c) -> uint64_t { return NH == 2 ? tokBase + (uint64_t)c : 2 * (tokBase + (uint64_t)c) + (uint64_t)half0; };
     uint2 bndNext = make_uint2(0u, 0u);
     if (hasPrev && 0 < slotLen) bndNext = p.bnd[bndIdx(0)];
 
@@ -325,7 +380,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
 #pragma unroll
         for (int h = 0; h < NH; h++) {
             unsigned mine;
-            if (WIDTH == 16) mine = (h == 0) ? (tok & 0xffu) : ((tok >> 8) & 0xffu);
+            if (NH == 2) mine = (h == 0) ? (tok & 0xffu) : ((tok >> 8) & 0xffu);
             else mine = half0 ? ((tok >> 8) & 0xffu) : (tok & 0xffu);
             mine = (s < len[h]) ? mine * (unsigned)stride : padOff;
             const unsigned shifted = shr1(offv[h], 0u) + (unsigned)LANE_BYTES;
@@ -338,6 +393,32 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
             reg f = inF;
             reg h = 0;
             reg cm = 0;  // SW second pass: this column's maximum over my rows
+            if constexpr (WIDTH == 17) {
+                // Plain 16-bit path: profile reads run one block of 4 rows ahead, the diagonal add of row
+                // j+1 is issued before row j's block so that H[j][c-1]'s register is free for H[j][c].
+                int4 pc = *reinterpret_cast<const int4*>(__builtin_assume_aligned(lds + offv[0], 16));
+                reg d = V::adds(diag, (reg)pc.x);
+#pragma unroll
+                for (int rb = 0; rb < SPAD / RB; rb++) {
+                    int4 pn = pc;
+                    if (rb + 1 < SPAD / RB)
+                        pn = *reinterpret_cast<const int4*>(__builtin_assume_aligned(lds + offv[0] + (rb + 1) * RB * ES, 16));
+                    const reg P[RB + 1] = {(reg)pc.x, (reg)pc.y, (reg)pc.z, (reg)pc.w, (reg)pn.x};
+#pragma unroll
+                    for (int i = 0; i < RB; i++) {
+                        const int j = rb * RB + i;
+                        if (j < S) {
+                            reg dn = 0;
+                            if (j + 1 < S) dn = V::adds(Hp[j], P[i + 1]);  // diagonal of the next row: last use of H[j][c-1]
+                            if (MODE == MODE_SW) V::row_sw(d, En[j], f, SWEND ? cm : mx, h, Qv, Rv);
+                            else V::row_global(d, En[j], f, h, Qv, Rv);
+                            Hp[j] = h;
+                            d = dn;
+                        }
+                    }
+                    pc = pn;
+                }
+            } else {
 #pragma unroll
             for (int rb = 0; rb < SPAD / RB; rb++) {
                 reg P[RB];
@@ -385,6 +466,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
                         Hp[j] = h;
                     }
                 }
+            }
             }
             outH = h;
             outF = f;
@@ -465,12 +547,12 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
                 int sc = V::half(mx, hh);
                 int prev = 0;
                 if (hasPrev) { prev = p.outScore[seq[hh]]; sc = sc > prev ? sc : prev; }  // maximum over the chunks so far
-                if (WIDTH == 16 && sc >= V::SATMAX) {  // saturated (opal.cpp:364-370): hand over to width 32
-                    if (!(hasPrev && prev >= V::SATMAX)) {
+                if (WIDTH != 32 && sc >= satLimit) {  // saturated (opal.cpp:364-370): hand over to width 32
+                    if (!(hasPrev && prev >= satLimit)) {
                         const int at = atomicAdd(p.ovfCount, 1);
                         p.ovfItems[at] = pairIdx * 2 + half0 + hh;
                     }
-                    if (MULTI) p.outScore[seq[hh]] = V::SATMAX;  // marker for the chunks below
+                    if (MULTI) p.outScore[seq[hh]] = satLimit;  // marker for the chunks below
                 } else if (WIDTH == 32 && WRAP && wrapped) {
                     atomicAdd(p.ovfCount, 1);  // 32-bit overflow: the host returns OPAL_ERR_OVERFLOW
                 } else {
@@ -531,5 +613,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
 KernelFn opal_kernel_sw16(int rows);                      // width 16, SW, score only: rows 1..40
 KernelFn opal_kernel_w16(int mode, int flags, int rows);  // width 16, the other variants: rows 4,8,..,40
 KernelFn opal_kernel_w32(int mode, int flags, int rows);  // width 32: rows 8,16,24,32,40
+KernelFn opal_kernel_s16sw(int rows);                     // width 17, SW, score only: rows 1..40
+KernelFn opal_kernel_s16(int mode, int flags, int rows);  // width 17, other variants incl. FLAG_MULTI: rows 4,8,..,40
 KernelFn opal_kernel_w16_multi(int mode, int flags, int rows);  // FLAG_MULTI variants
 KernelFn opal_kernel_w32_multi(int mode, int flags, int rows);

@@ -169,11 +169,15 @@ struct SearchCtx {
     OpalxDb* db;
     int Q, A, Go, Ge, mode, wantEnd;
     int* dScore; int* dEndQ; int* dEndT;
+    int satLimit, negPad;  // width 17 (plain 16-bit) parameters
 };
 
 // Measured on MI355X (profiles/r01_ubench_*): packed-int16 and 32-bit max/min issue one wave
 // instruction per ~4 clocks per SIMD. A lane's column step costs about (12*rows + 25) instructions.
-static double step_clocks(int rows) { return 4.3 * (12.0 * rows + 25.0); }
+static double step_clocks(int width, int rows) {
+    if (width == 17) return 2.15 * 9.5 * rows + 90.0;  // full-rate scalar 16-bit ops, fixed per-step overhead
+    return 4.3 * (11.0 * rows + 12.0);
+}
 
 /*
  * Split the item range [first, first+count) (sorted by length, longest first) into classes of
@@ -203,7 +207,7 @@ static std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass,
         if (!rows) continue;
         if (opal_hip_lds_bytes(width, G, rows, A) > 160 * 1024) continue;
         if (G > 1 && (G / 2) * rows >= Q && !(forceG && *forceG)) continue;  // half the lanes would hold padding only
-        const double eff = ((double)Q / (G * rows)) * (12.0 * rows / (12.0 * rows + 25.0)) * (lavg / (lavg + G - 1));
+        const double eff = ((double)Q / (G * rows)) * (rows / step_clocks(width, rows)) * (lavg / (lavg + G - 1));
         cands.push_back({G, rows, eff});
     }
     if (cands.empty()) return out;
@@ -213,13 +217,13 @@ static std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass,
     // time of the whole range at the base geometry if the machine were perfectly filled
     const double simds = 1024.0;
     const int slotsBase = 64 / cands[base].G;
-    const double totalClocks = lenSum * sample / slotsBase * step_clocks(cands[base].rows) / simds;
+    const double totalClocks = lenSum * sample / slotsBase * step_clocks(width, cands[base].rows) / simds;
     const char* budEnv = getenv("OPAL_HIP_TAIL_FRACTION");
     const double budget = std::max(totalClocks * (budEnv && *budEnv ? atof(budEnv) : 0.35), 20000.0);
     // walk from the longest item: the smallest geometry (>= base) whose lone-wave time fits the budget
     size_t ci = cands.size() - 1;
     int start = first;
-    auto fits = [&](size_t c, int len) { return (len + cands[c].G - 1) * step_clocks(cands[c].rows) <= budget; };
+    auto fits = [&](size_t c, int len) { return (len + cands[c].G - 1) * step_clocks(width, cands[c].rows) <= budget; };
     int i = first;
     while (i < first + count) {
         const int len = lenOf(i);
@@ -288,6 +292,7 @@ static int launch_chunked(const SearchCtx& c, int width, int swEndPass, int dete
         a.work = work; a.first_item = firstItem; a.num_items = numItems;
         a.out_score = c.dScore; a.out_end_query = c.wantEnd ? c.dEndQ : nullptr; a.out_end_target = c.wantEnd ? c.dEndT : nullptr;
         a.overflow_count = ovfCounter; a.overflow_items = db->dOvfItems;
+        a.sat_limit = c.satLimit; a.neg_pad = c.negPad;
         a.chunk_flags = (ch > 0 ? 1 : 0) | (ch < nchunks - 1 ? 2 : 0);
         a.chunk_row0 = row0; a.chunk_rows = rows;
         a.boundary = db->dBoundary; a.scratch = db->dScratch;
@@ -334,6 +339,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
         a.work = work; a.first_item = k.first; a.num_items = k.count;
         a.out_score = c.dScore; a.out_end_query = c.wantEnd ? c.dEndQ : nullptr; a.out_end_target = c.wantEnd ? c.dEndT : nullptr;
         a.overflow_count = ovfCounter; a.overflow_items = c.db->dOvfItems;
+        a.sat_limit = c.satLimit; a.neg_pad = c.negPad;
         const bool side = (int)ki < nside;
         a.stream = side ? c.db->stream((int)ki) : nullptr;
         a.priority = side ? 1 : 0;
@@ -447,7 +453,23 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
     for (int i = 0; i < A * A; i++) { maxS = std::max<long long>(maxS, M[i]); minS = std::min<long long>(minS, M[i]); }
     const bool fits16 = Go <= 32767 && Ge <= 32767 && maxS <= 32767 && minS >= -32768;
 
-    SearchCtx c{db, Q, A, Go, Ge, mode, wantEnd, dScore, dEndQ, dEndT};
+    // Narrow rung: 17 = plain 16-bit, one sequence per lane (full-rate VALU, 4-byte LDS profile entries);
+    // 16 = packed pairs (half-rate VALU, 2-byte entries: used when the wider profile does not fit LDS).
+    int narrow = 17;
+    if (const char* e = getenv("OPAL_HIP_NARROW")) narrow = atoi(e) == 16 ? 16 : 17;
+    {
+        bool fits17 = false;  // does some single-launch geometry hold the query with 4-byte profile entries?
+        for (int G = 1; G <= 64 && !fits17; G *= 2) {
+            const int need = (Q + G - 1) / G;
+            if (need > OPAL_HIP_MAX_ROWS) continue;
+            const int rows = opal_hip_rows_supported(17, mode, 0, need);
+            fits17 = rows && opal_hip_lds_bytes(17, G, rows, A) <= 160 * 1024;
+        }
+        if (!fits17) narrow = 16;
+    }
+    const int satLimit = narrow == 17 ? (int)(32767 - maxS) : 32767;
+    SearchCtx c{db, Q, A, Go, Ge, mode, wantEnd, dScore, dEndQ, dEndT, satLimit, mode == OPAL_MODE_SW ? -satLimit : 0};
+    const int nNarrow = narrow == 16 ? P : 2 * P;  // items of the narrow rung: pairs or sequences
     auto pairLenOf = [db](int p) { return db->pairLen[2 * (size_t)p]; };   // width-16 items are pairs
     auto seqLenOf = [db](int it) { return db->pairLen[(size_t)it]; };      // width-32 items are pair*2+half
     void* evStart = kernelMs ? opal_hip_event_create() : nullptr;
@@ -460,7 +482,9 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
         const int* work32 = nullptr;
         int first32 = 0;
         if (fits16) {
-            if ((rc = launch_range(c, 16, 0, 0, nullptr, 0, P, pairLenOf, db->dOvfCount))) return rc;
+            if (narrow == 16) rc = launch_range(c, 16, 0, 0, nullptr, 0, nNarrow, pairLenOf, db->dOvfCount);
+            else rc = launch_range(c, 17, 0, 0, nullptr, 0, nNarrow, seqLenOf, db->dOvfCount);
+            if (rc) return rc;
             int cnt = 0;
             if (opal_hip_memcpy_d2h(&cnt, db->dOvfCount, sizeof(int), nullptr) || opal_hip_stream_sync(nullptr))
                 return OPAL_ERR_NO_SIMD_SUPPORT;
@@ -482,7 +506,11 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
         }
         if (wantEnd && rc == 0) {
             // end locations: second pass that looks for the known score (first column, then first row)
-            if (fits16 && (rc = launch_range(c, 16, 1, 0, nullptr, 0, P, pairLenOf, db->dOvfCount))) return rc;
+            if (fits16) {
+                if (narrow == 16) rc = launch_range(c, 16, 1, 0, nullptr, 0, nNarrow, pairLenOf, db->dOvfCount);
+                else rc = launch_range(c, 17, 1, 0, nullptr, 0, nNarrow, seqLenOf, db->dOvfCount);
+                if (rc) return rc;
+            }
             if (n32 > 0 && (rc = launch_range(c, 32, 1, 0, work32, first32, n32, seqLenOf, db->dOvfCount + 1))) return rc;
         }
     } else {
@@ -494,7 +522,7 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
         else {
             while (p32 < P) {
                 const long long L = db->pairLen[2 * (size_t)p32];
-                const long long lo = 3LL * Go + (Q + L + 2) * (long long)Ge;
+                const long long lo = 3LL * Go + (Q + L + 2) * (long long)Ge - minS;  // -minS: diag + P must not wrap either
                 const long long hi = std::min<long long>(Q, L) * maxS;
                 if (lo < 32768 - 1 && hi < 32767) break;
                 p32++;
@@ -516,8 +544,11 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
         if (2 * p32 > nBad &&
             launch_range(c, 32, 0, 0, nullptr, nBad, 2 * p32 - nBad, seqLenOf, db->dOvfCount + 1))
             return OPAL_ERR_NO_SIMD_SUPPORT;
-        if (P > p32 && launch_range(c, 16, 0, 0, nullptr, p32, P - p32, pairLenOf, db->dOvfCount))
-            return OPAL_ERR_NO_SIMD_SUPPORT;
+        if (P > p32) {
+            const int e = narrow == 16 ? launch_range(c, 16, 0, 0, nullptr, p32, P - p32, pairLenOf, db->dOvfCount)
+                                       : launch_range(c, 17, 0, 0, nullptr, 2 * p32, 2 * (P - p32), seqLenOf, db->dOvfCount);
+            if (e) return OPAL_ERR_NO_SIMD_SUPPORT;
+        }
     }
     if (evStop) opal_hip_event_record(evStop, nullptr);
     if (opal_hip_stream_sync(nullptr)) return OPAL_ERR_NO_SIMD_SUPPORT;

@@ -87,7 +87,7 @@ extern "C" float opal_hip_event_elapsed_ms(void* start, void* stop) {
 }
 
 static size_t lds_bytes(int width, int G, int rows, int A) {
-    const int es = width == 16 ? 2 : 4;
+    const int es = width == 16 ? 2 : 4;  // width 17 keeps 4-byte profile entries (value in the low half)
     return (size_t)(A + 1) * (size_t)opal_profile_stride(es, G, rows) + 16;
 }
 
@@ -98,9 +98,11 @@ extern "C" size_t opal_hip_lds_bytes(int width, int lanes_per_seq, int rows_per_
 static KernelFn pick_kernel(int width, int mode, int flags, int rows) {
     if (flags & FLAG_MULTI) {
         if (width == 16) return opal_kernel_w16_multi(mode, flags, rows);
+        if (width == 17) return opal_kernel_s16(mode, flags, rows);
         if (width == 32) return opal_kernel_w32_multi(mode, flags, rows);
         return nullptr;
     }
+    if (width == 17) return opal_kernel_s16(mode, flags, rows);
     if (width == 16) return opal_kernel_w16(mode, flags, rows);
     if (width == 32) return opal_kernel_w32(mode, flags, rows);
     return nullptr;
@@ -156,6 +158,8 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
     p.chunkFlags = a->chunk_flags;
     p.bnd = (uint2*)a->boundary;
     p.scratch = a->scratch;
+    p.satLimit = a->sat_limit;
+    p.negPad = a->neg_pad;
     const int slots = 64 / G;
     const int jobs = (a->num_items + slots - 1) / slots;
     const int blocks = (jobs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
