@@ -95,9 +95,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the measured path)")
+    # Test hooks for the multi-rank path on a single-GPU box (never used by the driver): all ranks on device 0,
+    # results gathered through gloo on host copies. The default is one GPU per rank and RCCL.
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if os.environ.get("BENCH_SHARE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from opal_amd import shard, synth
     from opal_amd.api import MODES, PreparedDb
@@ -123,7 +131,8 @@ def main():
         if rc != 0:
             raise SystemExit(f"search failed rc={rc}")
         kernel_ms.append(kms)
-        shard.gather_results(score, world, rank)  # the path's only exchange: per-sequence scores to rank 0
+        # the path's only exchange: per-sequence scores to rank 0 (one gather)
+        shard.gather_results(score if backend == "nccl" else score.cpu(), world, rank)
 
     def fence():
         if world > 1:
@@ -139,8 +148,9 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    tcells = torch.tensor([cells], dtype=torch.float64, device=dev)
+    rdev = dev if backend == "nccl" else torch.device("cpu")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
+    tcells = torch.tensor([cells], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tcells, op=dist.ReduceOp.SUM)

@@ -17,7 +17,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 #include "opal.h"
@@ -39,6 +41,19 @@ struct HostPack {
     int numSeqs = 0;
 };
 
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static bool debug_on() {
+    const char* e = getenv("OPAL_HIP_DEBUG");
+    return e && *e && *e != '0';
+}
+static unsigned host_threads() {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (const char* e = getenv("OPAL_HOST_THREADS")) nt = (unsigned)atoi(e);
+    return std::max(1u, std::min(nt, 32u));
+}
+
 template <typename GetSeq>
 static void pack_sequences(int n, const int* lens, GetSeq getSeq, HostPack& out) {
     out.numSeqs = n;
@@ -59,21 +74,43 @@ static void pack_sequences(int n, const int* lens, GetSeq getSeq, HostPack& out)
         out.pairOff[p] = total;
         total += (uint64_t)lens[order[2 * p]];  // A is the longer one
     }
-    out.tokens.assign(total + 8, 0);
+    out.tokens.resize(total + 8);
     for (int p = 0; p < P; p++) {
         const int a = order[2 * p];
         const int b = (2 * p + 1 < m) ? order[2 * p + 1] : -1;
-        const int la = lens[a], lb = b >= 0 ? lens[b] : 0;
-        out.pairSeq[2 * p] = a; out.pairLen[2 * p] = la;
-        out.pairSeq[2 * p + 1] = b; out.pairLen[2 * p + 1] = lb;
-        const unsigned char* sa = getSeq(a);
-        const unsigned char* sb = b >= 0 ? getSeq(b) : nullptr;
-        uint16_t* t = out.tokens.data() + out.pairOff[p];
-        int c = 0;
-        for (; c < lb; c++) t[c] = (uint16_t)(sa[c] | (sb[c] << 8));
-        for (; c < la; c++) t[c] = (uint16_t)sa[c];
-        out.residues += la + lb;
+        out.pairSeq[2 * p] = a; out.pairLen[2 * p] = lens[a];
+        out.pairSeq[2 * p + 1] = b; out.pairLen[2 * p + 1] = b >= 0 ? lens[b] : 0;
+        out.residues += out.pairLen[2 * p] + out.pairLen[2 * p + 1];
     }
+    // interleave the residues of each pair into its token stream; pairs are independent -> host threads,
+    // each taking a contiguous range of pairs with about the same number of tokens
+    auto fill = [&](int p0, int p1) {
+        for (int p = p0; p < p1; p++) {
+            const int a = out.pairSeq[2 * p], b = out.pairSeq[2 * p + 1];
+            const int la = out.pairLen[2 * p], lb = out.pairLen[2 * p + 1];
+            const unsigned char* sa = getSeq(a);
+            const unsigned char* sb = b >= 0 ? getSeq(b) : nullptr;
+            uint16_t* t = out.tokens.data() + out.pairOff[p];
+            int c = 0;
+            for (; c < lb; c++) t[c] = (uint16_t)(sa[c] | (sb[c] << 8));
+            for (; c < la; c++) t[c] = (uint16_t)sa[c];
+        }
+    };
+    const unsigned nt = total > (1u << 20) ? host_threads() : 1u;
+    if (nt <= 1) { fill(0, P); }
+    else {
+        std::vector<std::thread> pool;
+        int p0 = 0;
+        for (unsigned t = 0; t < nt; t++) {
+            const uint64_t goal = total * (t + 1) / nt;
+            int p1 = p0;
+            while (p1 < P && (t + 1 == nt || out.pairOff[p1] < goal)) p1++;
+            pool.emplace_back(fill, p0, p1);
+            p0 = p1;
+        }
+        for (auto& th : pool) th.join();
+    }
+    for (size_t i = total; i < out.tokens.size(); i++) out.tokens[i] = 0;
 }
 
 }  // namespace
@@ -296,7 +333,7 @@ static int launch_chunked(const SearchCtx& c, int width, int swEndPass, int dete
         a.chunk_flags = (ch > 0 ? 1 : 0) | (ch < nchunks - 1 ? 2 : 0);
         a.chunk_row0 = row0; a.chunk_rows = rows;
         a.boundary = db->dBoundary; a.scratch = db->dScratch;
-        if (getenv("OPAL_HIP_DEBUG"))
+        if (debug_on())
             fprintf(stderr, "[opal] chunk %d/%d rows [%d,+%d) width=%d mode=%d end=%d G=%d rows/lane=%d\n", ch + 1, nchunks, row0,
                     rows, width, c.mode, swEndPass, bestG, bestS);
         if (opal_hip_launch(&a)) return OPAL_ERR_NO_SIMD_SUPPORT;
@@ -343,7 +380,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
         const bool side = (int)ki < nside;
         a.stream = side ? c.db->stream((int)ki) : nullptr;
         a.priority = side ? 1 : 0;
-        if (getenv("OPAL_HIP_DEBUG"))
+        if (debug_on())
             fprintf(stderr, "[opal] launch width=%d mode=%d end=%d items=[%d,+%d) G=%d rows=%d%s\n", width, c.mode, swEndPass,
                     k.first, k.count, k.G, k.rows, side ? " (side stream)" : "");
         if (side && opal_hip_stream_wait_event(a.stream, fork)) return OPAL_ERR_NO_SIMD_SUPPORT;
@@ -670,15 +707,19 @@ extern "C" int opalSearchDatabase(unsigned char query[], int queryLength, unsign
         const int n = (int)todo.size();
         std::vector<int> lens((size_t)n);
         for (int i = 0; i < n; i++) lens[i] = dbSeqLengths[todo[i]];
+        const double t0 = now_ms();
         HostPack hp;
         pack_sequences(n, lens.data(), [&](int i) { return (const unsigned char*)db[todo[i]]; }, hp);
+        const double t1 = now_ms();
         OpalxDb* pdb = upload(hp);
         if (!pdb) return OPAL_ERR_NO_SIMD_SUPPORT;
+        const double t2 = now_ms();
         const int st = searchType == OPAL_SEARCH_SCORE ? OPAL_SEARCH_SCORE : OPAL_SEARCH_SCORE_END;
         // INT_MIN marks "not written by the search" (a sequence the search had to give up on)
         std::vector<int> score((size_t)n, INT_MIN), endQ((size_t)n, -1), endT((size_t)n, -1);
         rc = opalx_search_host(pdb, query, queryLength, gapOpen, gapExt, scoreMatrix, alphabetLength, st, mode,
                                overflowMethod, score.data(), endQ.data(), endT.data());
+        const double t3 = now_ms();
         opalx_db_destroy(pdb);
         if (rc == OPAL_ERR_NO_SIMD_SUPPORT || rc == OPAL_ERR_INVALID_MODE) return rc;
         for (int i = 0; i < n; i++) {
@@ -688,6 +729,9 @@ extern "C" int opalSearchDatabase(unsigned char query[], int queryLength, unsign
             r->endLocationQuery = endQ[i];
             r->endLocationTarget = endT[i];
         }
+        if (debug_on())
+            fprintf(stderr, "[opal] opalSearchDatabase: pack %.2f ms, upload %.2f ms, search+download %.2f ms, free+scatter %.2f ms\n",
+                    t1 - t0, t2 - t1, t3 - t2, now_ms() - t3);
     } else if (!args_fit_int32(gapOpen, gapExt, scoreMatrix, alphabetLength)) {
         rc = OPAL_ERR_OVERFLOW;
     }
