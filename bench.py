@@ -77,8 +77,8 @@ def cpu_baseline(query, res, offs, lens, matrix, gap_open, gap_ext):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--seqs", type=int, default=100000, help="database sequences per GPU")
     ap.add_argument("--qlen", type=int, default=300)
     ap.add_argument("--gap-open", type=int, default=11)

@@ -5,7 +5,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libopal.so")
+LIB_PATH = os.environ.get("OPAL_LIB_PATH") or os.path.join(_HERE, "csrc", "libopal.so")
 
 _lib = None
 

@@ -35,7 +35,8 @@
 #define FLAG_WRAP 2   // width 32 SW: detect 32-bit wrap of ulH + P (reference opal.cpp:302-303,339-351)
 #define FLAG_MULTI 4  // the query is processed in several row chunks; the boundary row travels through HBM
 
-#define WAVES_PER_BLOCK 4
+#define WAVES_PER_BLOCK 4      // default waves per block (the launch may use fewer or more, up to MAX)
+#define MAX_WAVES_PER_BLOCK 8
 
 struct KParams {
     const unsigned char* query;
@@ -203,7 +204,7 @@ __host__ __device__ inline int opal_profile_stride(int es, int G, int S) {
 
 // ------------------------------------------------------------------ the DP kernel
 template <int WIDTH, int MODE, int FLAGS, int S>
-__global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KParams p) {
+__global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const KParams p) {
     using V = Vec<WIDTH>;
     using reg = typename V::reg;
     using elem = typename V::elem;
@@ -258,7 +259,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int slots = 64 >> log2G;
-    const int job = (int)blockIdx.x * WAVES_PER_BLOCK + wave;
+    const int job = (int)blockIdx.x * (int)(blockDim.x >> 6) + wave;
     const int k = lane & (G - 1);
     const int slot = lane >> log2G;
     const int itemIdx = job * slots + slot;
@@ -357,6 +358,7 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
     uint2 bndNext = make_uint2(0u, 0u);
     if (hasPrev && 0 < slotLen) bndNext = p.bnd[bndIdx(0)];
 
+    int topHv = V::clampv(-(long long)Go);  // NW: H[-1][0]
     for (int s = 0; s < nsteps; s++) {
         const unsigned tok = tokNext;
         if (s + 1 < slotLen) tokNext = p.tokens[tokBase + (uint64_t)(s + 1)];
@@ -365,7 +367,11 @@ __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64) opal_dp_kernel(const KPa
 
         // ---- inputs of this column: from the boundary (lane 0 of the slot) or from the lane above
         reg topH = 0;
-        if (MODE == MODE_NW) topH = V::splat(V::clampv(-(long long)Go - (long long)s * Ge));  // H[-1][c] (opal.cpp:686-689)
+        if (MODE == MODE_NW) {  // H[-1][c] = -Go - c*Ge (opal.cpp:686-689), kept incrementally and clamped to the type
+            topH = V::splat(topHv);
+            const int nxt = topHv - Ge;
+            topHv = (nxt < V::clampv(LLONG_MIN / 2) || nxt > topHv) ? V::clampv(LLONG_MIN / 2) : nxt;
+        }
         reg inH = (reg)shr1((unsigned)outH, 0u);
         reg inF = (reg)shr1((unsigned)outF, 0u);
         if (k == 0) {

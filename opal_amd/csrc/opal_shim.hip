@@ -3,6 +3,7 @@
 // no scheduling here: the kernels are in dp_kernel.hpp, the scheduler in opal_api.cpp.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "dp_kernel.hpp"
@@ -162,7 +163,9 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
     p.negPad = a->neg_pad;
     const int slots = 64 / G;
     const int jobs = (a->num_items + slots - 1) / slots;
-    const int blocks = (jobs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    int wpb = WAVES_PER_BLOCK;
+    if (const char* e = getenv("OPAL_HIP_WAVES_PER_BLOCK")) { wpb = atoi(e); if (wpb < 1 || wpb > MAX_WAVES_PER_BLOCK) wpb = WAVES_PER_BLOCK; }
+    const int blocks = (jobs + wpb - 1) / wpb;
     const size_t lds = lds_bytes(a->width, G, a->rows_per_lane, a->alphabet_length);
     if (lds > 160 * 1024) {
         snprintf(g_err, sizeof g_err, "query profile needs %zu bytes of LDS (>160 KiB)", lds);
@@ -173,7 +176,7 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
         hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail("hipFuncSetAttribute", e);
     }
-    hipLaunchKernelGGL(fn, dim3(blocks), dim3(WAVES_PER_BLOCK * 64), lds, (hipStream_t)a->stream, p);
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(wpb * 64), lds, (hipStream_t)a->stream, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("kernel launch", e);
 }
