@@ -255,3 +255,33 @@ def test_large_alphabet_profile_exceeds_lds(ours, oracle):
     for mode in ("SW", "HW"):
         got = ours.search(q, db, 4, 1, m, 1, MODES[mode])[:4]
         _check(got, oracle.search(q, db, 4, 1, m, 1, MODES[mode]), mode, f"A=200 {mode}")
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomized_differential(seed, ours, oracle):
+    """Seeded random shapes: alphabet size, matrix, gap penalties, query/target lengths, mode, search type;
+    each drawn configuration is compared with the oracle (bit-exact)."""
+    rng = np.random.RandomState(1000 + seed)
+    for _ in range(6):
+        A = int(rng.choice([2, 4, 5, 20, 24, 31, 64]))
+        m = rng.randint(-9, 12, size=(A, A)).astype(np.int32)
+        if rng.rand() < 0.5:
+            m = ((m + m.T) // 2).astype(np.int32)
+            np.fill_diagonal(m, rng.randint(1, 14))
+        go = int(rng.randint(0, 16)); ge = int(rng.randint(0, go + 1)) if rng.rand() < 0.8 else int(rng.randint(0, 20))
+        qlen = int(rng.choice([1, 2, 7, 39, 40, 41, 80, 81, 159, 320, 333, 641, 900]))
+        n = int(rng.randint(1, 70))
+        lens = np.maximum(1, (rng.lognormal(4.5, 1.0, size=n)).astype(int)); lens = np.minimum(lens, 1500)
+        if rng.rand() < 0.3:
+            lens[rng.randint(0, n)] = int(rng.randint(1500, 4000))
+        q = rng.randint(0, A, size=qlen).astype(np.uint8)
+        db = [rng.randint(0, A, size=int(L)).astype(np.uint8) for L in lens]
+        if rng.rand() < 0.5:  # plant related sequences so scores are not all tiny
+            for i in range(0, n, 3):
+                L = len(db[i]); k = min(L, qlen)
+                db[i][:k] = np.where(rng.rand(k) < 0.8, q[:k], db[i][:k])
+        mode = str(rng.choice(["SW", "NW", "HW", "OV"])); st = int(rng.randint(0, 2))
+        got = ours.search(q, db, go, ge, m, st, MODES[mode], int(rng.randint(0, 2)))[:4]
+        want = oracle.search(q, db, go, ge, m, st, MODES[mode])
+        _check(got, want, mode, f"seed {seed}: A={A} Q={qlen} n={n} gaps {go}/{ge} {mode} st={st}")
+        assert (got[2] == want[2]).all() and (got[3] == want[3]).all()  # including the defined SW score-0 ends
