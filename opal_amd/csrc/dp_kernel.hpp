@@ -5,22 +5,26 @@
 // one database sequence per SIMD lane and streams a whole H/E column through memory; here a
 // wavefront is a 64-lane systolic array and the column never leaves the register file.
 //
-// Mapping (DESIGN.md "kernel"):
-//   * A wave holds 64/G "slots"; a slot is G adjacent lanes working on one PAIR of database
-//     sequences (width 16: two sequences packed as 2 x int16 in every VGPR, v_pk_* saturating
-//     math) or on one sequence (width 32). G = 1 is the pure lane-owns-a-sequence mapping.
+// Mapping:
+//   * A wave holds 64/G "slots"; a slot is G adjacent lanes working on ONE database sequence
+//     (width 17: plain 16-bit arithmetic on full-rate VALU instructions, the default; width 32:
+//     int32) or on a PAIR of sequences packed 2 x int16 per VGPR (width 16, v_pk_* math; used when
+//     the 4-byte profile entries of width 17 do not fit LDS). G = 1 is the pure
+//     lane-owns-a-sequence mapping.
 //   * Lane k of a slot owns S consecutive query rows and keeps their H and E values in VGPRs for
 //     the whole sequence (S is a template parameter: the row loop is straight-line code).
 //   * At step s lane k computes column c = s-k. The bottom H and F of lane k-1 and the LDS
 //     profile address of that column's residues arrive through one wave_shr:1 DPP shift each.
 //   * The query profile QP[target letter][query row] = scoreMatrix[query[row]][letter] is staged
-//     once per block in LDS, laid out [letter][lane k][row j], so a lane fetches 4 rows of one
-//     letter with one ds_read_b64 (width 16) / ds_read_b128 (width 32); lanes that hold the same
-//     letter broadcast, different letters fall in different banks (odd letter stride).
+//     once per block in LDS, laid out [letter][lane k][row j]; every read is one naturally aligned
+//     ds_read_b128 (8 rows of int16, 4 rows of 4-byte entries); lanes that hold the same letter
+//     broadcast, different letters fall in different 16-byte bank slots (odd letter stride).
 //   * Database residues stream from HBM as 16-bit tokens (low byte: sequence A, high byte: B).
-//   * Width 16 hands saturated local scores to a re-run list that the host schedules at width 32
-//     (the 16 -> 32 bit rung of the reference's precision ladder, opal.cpp:496-535 / :983-1021;
-//     gfx950 has no packed 8-bit VALU, so an 8-bit rung would only add work).
+//   * The 16-bit kernels hand scores at their limit to a re-run list that the host schedules at
+//     width 32 (the 16 -> 32 bit rung of the reference's precision ladder, opal.cpp:496-535 /
+//     :983-1021; gfx950 has no packed 8-bit VALU, so an 8-bit rung would only add work).
+//   * FLAG_MULTI: queries longer than G*S rows run as several launches over consecutive row chunks;
+//     the bottom row of a chunk travels through HBM (KParams::bnd).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <limits.h>

@@ -18,7 +18,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
-#include <numeric>
 #include <thread>
 #include <vector>
 
@@ -130,7 +129,6 @@ struct OpalxDb {
     int* dPairSeq = nullptr;
     int* dOvfCount = nullptr;  // [2] counters: width-16 overflow list length, width-32 wrap count
     int* dOvfItems = nullptr;  // [2P]
-    int* dWork = nullptr;      // [2P] scratch work list
     size_t numTokens = 0;
     void* dBoundary = nullptr; // 16 B per token: chunk-boundary rows of long queries (allocated on first use)
     int* dScratch = nullptr;   // [2N] per-sequence values carried across query chunks
@@ -186,8 +184,7 @@ static OpalxDb* upload(HostPack& hp) {
     db->dPairSeq = (int*)opal_hip_malloc(2 * P * sizeof(int));
     db->dOvfCount = (int*)opal_hip_malloc(2 * sizeof(int));
     db->dOvfItems = (int*)opal_hip_malloc(2 * P * sizeof(int));
-    db->dWork = (int*)opal_hip_malloc(2 * P * sizeof(int));
-    bool ok = db->dTokens && db->dPairOff && db->dPairLen && db->dPairSeq && db->dOvfCount && db->dOvfItems && db->dWork;
+    bool ok = db->dTokens && db->dPairOff && db->dPairLen && db->dPairSeq && db->dOvfCount && db->dOvfItems;
     if (ok && P) {
         ok = !opal_hip_memcpy_h2d(db->dTokens, hp.tokens.data(), hp.tokens.size() * sizeof(uint16_t), nullptr) &&
              !opal_hip_memcpy_h2d(db->dPairOff, hp.pairOff.data(), P * sizeof(uint64_t), nullptr) &&
@@ -617,7 +614,7 @@ extern "C" OpalxDb* opalx_db_create_flat(const unsigned char* residues, const in
 extern "C" void opalx_db_destroy(OpalxDb* db) {
     if (!db) return;
     opal_hip_free(db->dTokens); opal_hip_free(db->dPairOff); opal_hip_free(db->dPairLen); opal_hip_free(db->dPairSeq);
-    opal_hip_free(db->dOvfCount); opal_hip_free(db->dOvfItems); opal_hip_free(db->dWork);
+    opal_hip_free(db->dOvfCount); opal_hip_free(db->dOvfItems);
     opal_hip_free(db->dQuery); opal_hip_free(db->dMatrix);
     opal_hip_free(db->dBoundary); opal_hip_free(db->dScratch);
     for (void* st : db->streams) opal_hip_stream_destroy(st);
