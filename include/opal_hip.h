@@ -96,6 +96,10 @@ int opal_hip_stream_sync(void* stream);
 void* opal_hip_stream_create(void);       /* non-blocking stream: ordered only through events */
 void opal_hip_stream_destroy(void* stream);
 int opal_hip_stream_wait_event(void* stream, void* event);
+/* Interleave raw residues into the packed token streams on the device: for every pair p and column c,
+   tokens[pair_off[p] + c] = raw[raw_off[2p] + c] | (c < pair_len[2p+1] ? raw[raw_off[2p+1] + c] : 0) << 8. */
+int opal_hip_pack_tokens(const unsigned char* raw, const uint64_t* raw_off, const uint64_t* pair_off,
+                         const int* pair_len, int num_pairs, uint16_t* tokens, uint64_t tokens_capacity, void* stream);
 /* Enqueue one DP kernel. 0 on success, non-zero if the shape is not launchable. */
 int opal_hip_launch(const OpalHipLaunch* args);
 /* Smallest rows_per_lane >= min_rows for which this kernel variant is instantiated (0: none).

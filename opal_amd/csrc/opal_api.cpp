@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -30,12 +31,18 @@ namespace {
 // Sequences sorted by length (descending), paired up neighbour with neighbour. A pair is the unit a
 // wave slot works on at width 16 (two sequences packed in one register); its residues are stored
 // column by column as 16-bit tokens (low byte A, high byte B) so one 2-byte load feeds both.
+// The host only decides the order and gathers the residues into one buffer; the interleaving into
+// tokens is done on the device (opal_hip_pack_tokens) at HBM speed.
 struct HostPack {
-    std::vector<uint16_t> tokens;
-    std::vector<uint64_t> pairOff;  // [P]
+    std::vector<uint64_t> pairOff;  // [P] start of each pair's token stream
     std::vector<int> pairLen;       // [2P]
     std::vector<int> pairSeq;       // [2P] caller index, -1 = absent
+    std::vector<uint64_t> rawOff;   // [2P] where each sequence's residues start in the raw buffer
     std::vector<int> emptySeqs;     // caller indices of zero-length sequences (handled on the host)
+    std::unique_ptr<unsigned char[]> gathered;  // raw residues in pair order (pointer-array inputs only)
+    const unsigned char* raw = nullptr;   // the buffer to upload: `gathered` or the caller's flat buffer
+    uint64_t rawBytes = 0;
+    uint64_t numTokens = 0;
     int64_t residues = 0;
     int numSeqs = 0;
 };
@@ -53,63 +60,74 @@ static unsigned host_threads() {
     return std::max(1u, std::min(nt, 32u));
 }
 
-template <typename GetSeq>
-static void pack_sequences(int n, const int* lens, GetSeq getSeq, HostPack& out) {
+// Order and pairing (no residue is touched): stable sort by length, longest first.
+static void pack_order(int n, const int* lens, HostPack& out) {
     out.numSeqs = n;
+    int maxLen = 0;
+    for (int i = 0; i < n; i++) maxLen = std::max(maxLen, lens[i]);
     std::vector<int> order;
-    order.reserve(n);
-    for (int i = 0; i < n; i++) {
-        if (lens[i] > 0) order.push_back(i);
-        else out.emptySeqs.push_back(i);
+    if (maxLen <= (1 << 22)) {  // counting sort
+        std::vector<int> start((size_t)maxLen + 2, 0);
+        for (int i = 0; i < n; i++) if (lens[i] > 0) start[(size_t)maxLen - lens[i] + 1]++;
+        for (size_t b = 1; b < start.size(); b++) start[b] += start[b - 1];
+        order.resize((size_t)start[(size_t)maxLen]);
+        for (int i = 0; i < n; i++) {
+            if (lens[i] > 0) order[(size_t)start[(size_t)maxLen - lens[i]]++] = i;
+            else out.emptySeqs.push_back(i);
+        }
+    } else {
+        for (int i = 0; i < n; i++) {
+            if (lens[i] > 0) order.push_back(i);
+            else out.emptySeqs.push_back(i);
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lens[a] > lens[b]; });
     }
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lens[a] > lens[b]; });
     const int m = (int)order.size();
     const int P = (m + 1) / 2;
-    out.pairOff.resize(P);
+    out.pairOff.resize((size_t)P);
     out.pairLen.assign(2 * (size_t)P, 0);
     out.pairSeq.assign(2 * (size_t)P, -1);
     uint64_t total = 0;
     for (int p = 0; p < P; p++) {
+        const int a = order[2 * (size_t)p];
+        const int b = (2 * p + 1 < m) ? order[2 * (size_t)p + 1] : -1;
+        out.pairSeq[2 * (size_t)p] = a; out.pairLen[2 * (size_t)p] = lens[a];
+        out.pairSeq[2 * (size_t)p + 1] = b; out.pairLen[2 * (size_t)p + 1] = b >= 0 ? lens[b] : 0;
         out.pairOff[p] = total;
-        total += (uint64_t)lens[order[2 * p]];  // A is the longer one
+        total += (uint64_t)lens[a];  // A is the longer one
+        out.residues += lens[a] + (b >= 0 ? lens[b] : 0);
     }
-    out.tokens.resize(total + 8);
-    for (int p = 0; p < P; p++) {
-        const int a = order[2 * p];
-        const int b = (2 * p + 1 < m) ? order[2 * p + 1] : -1;
-        out.pairSeq[2 * p] = a; out.pairLen[2 * p] = lens[a];
-        out.pairSeq[2 * p + 1] = b; out.pairLen[2 * p + 1] = b >= 0 ? lens[b] : 0;
-        out.residues += out.pairLen[2 * p] + out.pairLen[2 * p + 1];
-    }
-    // interleave the residues of each pair into its token stream; pairs are independent -> host threads,
-    // each taking a contiguous range of pairs with about the same number of tokens
-    auto fill = [&](int p0, int p1) {
-        for (int p = p0; p < p1; p++) {
-            const int a = out.pairSeq[2 * p], b = out.pairSeq[2 * p + 1];
-            const int la = out.pairLen[2 * p], lb = out.pairLen[2 * p + 1];
-            const unsigned char* sa = getSeq(a);
-            const unsigned char* sb = b >= 0 ? getSeq(b) : nullptr;
-            uint16_t* t = out.tokens.data() + out.pairOff[p];
-            int c = 0;
-            for (; c < lb; c++) t[c] = (uint16_t)(sa[c] | (sb[c] << 8));
-            for (; c < la; c++) t[c] = (uint16_t)sa[c];
-        }
+    out.numTokens = total;
+}
+
+// Residues given as separate host allocations: gather them (pair order) into one buffer, on host threads.
+template <typename GetSeq>
+static void gather_residues(GetSeq getSeq, HostPack& out) {
+    const size_t n2 = out.pairSeq.size();
+    out.rawOff.resize(n2);
+    uint64_t total = 0;
+    for (size_t i = 0; i < n2; i++) { out.rawOff[i] = total; total += (uint64_t)out.pairLen[i]; }
+    out.gathered.reset(new unsigned char[total + 16]);  // uninitialised on purpose: every byte below `total` is copied
+    auto copy = [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; i++)
+            if (out.pairSeq[i] >= 0) memcpy(out.gathered.get() + out.rawOff[i], getSeq(out.pairSeq[i]), (size_t)out.pairLen[i]);
     };
     const unsigned nt = total > (1u << 20) ? host_threads() : 1u;
-    if (nt <= 1) { fill(0, P); }
+    if (nt <= 1) copy(0, n2);
     else {
         std::vector<std::thread> pool;
-        int p0 = 0;
+        size_t i0 = 0;
         for (unsigned t = 0; t < nt; t++) {
             const uint64_t goal = total * (t + 1) / nt;
-            int p1 = p0;
-            while (p1 < P && (t + 1 == nt || out.pairOff[p1] < goal)) p1++;
-            pool.emplace_back(fill, p0, p1);
-            p0 = p1;
+            size_t i1 = i0;
+            while (i1 < n2 && (t + 1 == nt || out.rawOff[i1] < goal)) i1++;
+            pool.emplace_back(copy, i0, i1);
+            i0 = i1;
         }
         for (auto& th : pool) th.join();
     }
-    for (size_t i = total; i < out.tokens.size(); i++) out.tokens[i] = 0;
+    out.raw = out.gathered.get();
+    out.rawBytes = total;
 }
 
 }  // namespace
@@ -132,6 +150,7 @@ struct OpalxDb {
     size_t numTokens = 0;
     void* dBoundary = nullptr; // 16 B per token: chunk-boundary rows of long queries (allocated on first use)
     int* dScratch = nullptr;   // [2N] per-sequence values carried across query chunks
+    int* dResults = nullptr;   // [3N] device staging of host-array searches (opalx_search_host)
     unsigned char* dQuery = nullptr;
     int* dMatrix = nullptr;
     size_t queryCap = 0, matrixCap = 0;
@@ -176,22 +195,28 @@ static OpalxDb* upload(HostPack& hp) {
     db->pairLen = hp.pairLen;
     db->pairSeq = hp.pairSeq;
     db->emptySeqs = hp.emptySeqs;
-    db->numTokens = hp.tokens.size();
+    db->numTokens = hp.numTokens + 8;
     const size_t P = hp.pairOff.size();
-    db->dTokens = (uint16_t*)opal_hip_malloc(hp.tokens.size() * sizeof(uint16_t));
+    db->dTokens = (uint16_t*)opal_hip_malloc(db->numTokens * sizeof(uint16_t));
     db->dPairOff = (uint64_t*)opal_hip_malloc(P * sizeof(uint64_t));
     db->dPairLen = (int*)opal_hip_malloc(2 * P * sizeof(int));
     db->dPairSeq = (int*)opal_hip_malloc(2 * P * sizeof(int));
     db->dOvfCount = (int*)opal_hip_malloc(2 * sizeof(int));
     db->dOvfItems = (int*)opal_hip_malloc(2 * P * sizeof(int));
-    bool ok = db->dTokens && db->dPairOff && db->dPairLen && db->dPairSeq && db->dOvfCount && db->dOvfItems;
+    unsigned char* dRaw = (unsigned char*)opal_hip_malloc(hp.rawBytes + 16);
+    uint64_t* dRawOff = (uint64_t*)opal_hip_malloc(2 * P * sizeof(uint64_t));
+    bool ok = db->dTokens && db->dPairOff && db->dPairLen && db->dPairSeq && db->dOvfCount && db->dOvfItems && dRaw && dRawOff;
     if (ok && P) {
-        ok = !opal_hip_memcpy_h2d(db->dTokens, hp.tokens.data(), hp.tokens.size() * sizeof(uint16_t), nullptr) &&
+        ok = !opal_hip_memcpy_h2d(dRaw, hp.raw, hp.rawBytes, nullptr) &&
+             !opal_hip_memcpy_h2d(dRawOff, hp.rawOff.data(), 2 * P * sizeof(uint64_t), nullptr) &&
              !opal_hip_memcpy_h2d(db->dPairOff, hp.pairOff.data(), P * sizeof(uint64_t), nullptr) &&
              !opal_hip_memcpy_h2d(db->dPairLen, hp.pairLen.data(), 2 * P * sizeof(int), nullptr) &&
              !opal_hip_memcpy_h2d(db->dPairSeq, hp.pairSeq.data(), 2 * P * sizeof(int), nullptr) &&
+             !opal_hip_pack_tokens(dRaw, dRawOff, db->dPairOff, db->dPairLen, (int)P, db->dTokens, db->numTokens, nullptr) &&
              !opal_hip_stream_sync(nullptr);
     }
+    opal_hip_free(dRaw);
+    opal_hip_free(dRawOff);
     if (!ok) { opalx_db_destroy(db); return nullptr; }
     return db;
 }
@@ -598,7 +623,8 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
 extern "C" OpalxDb* opalx_db_create(unsigned char* const db[], int db_length, const int db_seq_lengths[]) {
     if (!device_ok()) return nullptr;
     HostPack hp;
-    pack_sequences(db_length, db_seq_lengths, [&](int i) { return (const unsigned char*)db[i]; }, hp);
+    pack_order(db_length, db_seq_lengths, hp);
+    gather_residues([&](int i) { return (const unsigned char*)db[i]; }, hp);
     return upload(hp);
 }
 
@@ -607,7 +633,12 @@ extern "C" OpalxDb* opalx_db_create_flat(const unsigned char* residues, const in
     std::vector<int> lens((size_t)db_length);
     for (int i = 0; i < db_length; i++) lens[i] = (int)(offsets[i + 1] - offsets[i]);
     HostPack hp;
-    pack_sequences(db_length, lens.data(), [&](int i) { return residues + offsets[i]; }, hp);
+    pack_order(db_length, lens.data(), hp);
+    // already contiguous: upload as it is, the device packer reads each sequence at its offset
+    hp.rawOff.resize(hp.pairSeq.size());
+    for (size_t i = 0; i < hp.pairSeq.size(); i++) hp.rawOff[i] = hp.pairSeq[i] >= 0 ? (uint64_t)offsets[hp.pairSeq[i]] : 0;
+    hp.raw = residues;
+    hp.rawBytes = (uint64_t)offsets[db_length];
     return upload(hp);
 }
 
@@ -616,7 +647,7 @@ extern "C" void opalx_db_destroy(OpalxDb* db) {
     opal_hip_free(db->dTokens); opal_hip_free(db->dPairOff); opal_hip_free(db->dPairLen); opal_hip_free(db->dPairSeq);
     opal_hip_free(db->dOvfCount); opal_hip_free(db->dOvfItems);
     opal_hip_free(db->dQuery); opal_hip_free(db->dMatrix);
-    opal_hip_free(db->dBoundary); opal_hip_free(db->dScratch);
+    opal_hip_free(db->dBoundary); opal_hip_free(db->dScratch); opal_hip_free(db->dResults);
     for (void* st : db->streams) opal_hip_stream_destroy(st);
     for (void* ev : db->events) opal_hip_event_destroy(ev);
     delete db;
@@ -644,7 +675,8 @@ extern "C" int opalx_search_host(OpalxDb* db, const unsigned char* query, int qu
     const int n = db->numSeqs;
     const int wantEnd = search_type != OPAL_SEARCH_SCORE;
     const size_t bytes = (size_t)std::max(n, 1) * sizeof(int);
-    int* d = (int*)opal_hip_malloc(3 * bytes);
+    if (!db->dResults) db->dResults = (int*)opal_hip_malloc(3 * bytes);  // kept for the life of the handle
+    int* d = db->dResults;
     if (!d) return OPAL_ERR_NO_SIMD_SUPPORT;
     int* dS = d; int* dQ = d + std::max(n, 1); int* dT = d + 2 * (size_t)std::max(n, 1);
     // pre-load the caller's values so that sequences the search does not write keep them
@@ -662,7 +694,6 @@ extern "C" int opalx_search_host(OpalxDb* db, const unsigned char* query, int qu
         e |= opal_hip_stream_sync(nullptr);
         if (e) rc = OPAL_ERR_NO_SIMD_SUPPORT;
     }
-    opal_hip_free(d);
     return rc;
 }
 
@@ -706,7 +737,8 @@ extern "C" int opalSearchDatabase(unsigned char query[], int queryLength, unsign
         for (int i = 0; i < n; i++) lens[i] = dbSeqLengths[todo[i]];
         const double t0 = now_ms();
         HostPack hp;
-        pack_sequences(n, lens.data(), [&](int i) { return (const unsigned char*)db[todo[i]]; }, hp);
+        pack_order(n, lens.data(), hp);
+        gather_residues([&](int i) { return (const unsigned char*)db[todo[i]]; }, hp);
         const double t1 = now_ms();
         OpalxDb* pdb = upload(hp);
         if (!pdb) return OPAL_ERR_NO_SIMD_SUPPORT;

@@ -87,6 +87,39 @@ extern "C" float opal_hip_event_elapsed_ms(void* start, void* stop) {
     return ms;
 }
 
+// One wave per pair: column c of the pair's token stream = residue of A | residue of B << 8.
+__global__ void __launch_bounds__(256) opal_pack_tokens_kernel(const unsigned char* __restrict__ raw,
+                                                               const uint64_t* __restrict__ rawOff,
+                                                               const uint64_t* __restrict__ pairOff,
+                                                               const int* __restrict__ pairLen, int numPairs,
+                                                               uint16_t* __restrict__ tokens) {
+    const int lane = threadIdx.x & 63;
+    const int pair = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (pair >= numPairs) return;
+    const int la = pairLen[2 * pair], lb = pairLen[2 * pair + 1];
+    const unsigned char* a = raw + rawOff[2 * pair];
+    const unsigned char* b = raw + rawOff[2 * pair + 1];
+    uint16_t* t = tokens + pairOff[pair];
+    for (int c = lane; c < la; c += 64) {
+        unsigned v = a[c];
+        if (c < lb) v |= (unsigned)b[c] << 8;
+        t[c] = (uint16_t)v;
+    }
+}
+
+extern "C" int opal_hip_pack_tokens(const unsigned char* raw, const uint64_t* raw_off, const uint64_t* pair_off,
+                                    const int* pair_len, int num_pairs, uint16_t* tokens, uint64_t tokens_capacity,
+                                    void* stream) {
+    hipError_t e = hipMemsetAsync(tokens, 0, tokens_capacity * sizeof(uint16_t), (hipStream_t)stream);
+    if (e != hipSuccess) return fail("hipMemsetAsync(tokens)", e);
+    if (num_pairs <= 0) return 0;
+    const int wpb = 4;
+    hipLaunchKernelGGL(opal_pack_tokens_kernel, dim3((num_pairs + wpb - 1) / wpb), dim3(wpb * 64), 0, (hipStream_t)stream, raw,
+                       raw_off, pair_off, pair_len, num_pairs, tokens);
+    e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("pack kernel launch", e);
+}
+
 static size_t lds_bytes(int width, int G, int rows, int A) {
     const int es = width == 16 ? 2 : 4;  // width 17 keeps 4-byte profile entries (value in the low half)
     return (size_t)(A + 1) * (size_t)opal_profile_stride(es, G, rows) + 16;
