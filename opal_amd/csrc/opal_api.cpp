@@ -170,21 +170,23 @@ struct OpalxDb {
 
 namespace {
 
-static int g_deviceChecked = 0;  // 0 unknown, 1 ok, -1 none
-
+// The HIP "current device" is a per-thread setting, so the check (and the optional OPAL_HIP_DEVICE
+// selection) is done once per calling thread. Without OPAL_HIP_DEVICE the thread's current device is
+// used as it is (bench.py sets it through torch before calling in).
 static bool device_ok() {
-    if (g_deviceChecked == 0) {
+    static thread_local int checked = 0;  // 0 unknown, 1 ok, -1 none
+    if (checked == 0) {
         if (opal_hip_device_count() > 0) {
-            g_deviceChecked = 1;
+            checked = 1;
             const char* env = getenv("OPAL_HIP_DEVICE");
-            if (env && *env && opal_hip_set_device(atoi(env)) != 0) g_deviceChecked = -1;
+            if (env && *env && opal_hip_set_device(atoi(env)) != 0) checked = -1;
         } else {
-            g_deviceChecked = -1;
+            checked = -1;
         }
-        if (g_deviceChecked < 0)
+        if (checked < 0)
             fprintf(stderr, "[opal] no usable HIP device (gfx950 required); there is no CPU fallback\n");
     }
-    return g_deviceChecked > 0;
+    return checked > 0;
 }
 
 static OpalxDb* upload(HostPack& hp) {

@@ -285,3 +285,30 @@ def test_randomized_differential(seed, ours, oracle):
         want = oracle.search(q, db, go, ge, m, st, MODES[mode])
         _check(got, want, mode, f"seed {seed}: A={A} Q={qlen} n={n} gaps {go}/{ge} {mode} st={st}")
         assert (got[2] == want[2]).all() and (got[3] == want[3]).all()  # including the defined SW score-0 ends
+
+
+def test_reentrant_from_host_threads(ours, oracle):
+    """The reference entry point is re-entrant (SURVEY.md 8b "Threading"); so is ours: four host threads search
+    four different databases at once and every result matches the oracle."""
+    import threading
+    from opal_amd import synth
+    from opal_amd.score_matrix import blosum50
+    m = blosum50()[1]
+    jobs = []
+    for t in range(4):
+        res, offs, lens = synth.database(150 + 40 * t, seed=500 + t)
+        db = [res[offs[i]:offs[i + 1]] for i in range(len(lens))]
+        q = synth.query(100 + 57 * t, seed=t)
+        jobs.append((q, db, ["SW", "NW", "HW", "OV"][t]))
+    out = [None] * 4
+
+    def run(i):
+        q, db, mode = jobs[i]
+        for _ in range(3):
+            out[i] = ours.search(q, db, 3, 1, m, 1, MODES[mode])[:4]
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(4)]
+    for th in threads: th.start()
+    for th in threads: th.join()
+    for i, (q, db, mode) in enumerate(jobs):
+        _check(out[i], oracle.search(q, db, 3, 1, m, 1, MODES[mode]), mode, f"thread {i} {mode}")
