@@ -550,25 +550,31 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
         if (WRAP) {
             for (int d = 1; d < G; d <<= 1) wrapped |= __shfl_xor(wrapped, d, 64);
         }
-        if (k == 0) {
+        // Every lane evaluates its slot's result (lane 0 of the slot is the writer). Saturated scores are
+        // collected with one __ballot per wave: the wave reserves popcount(ballot) entries of the re-run
+        // list with a single atomic, each flagged lane takes the entry given by its rank in the ballot.
 #pragma unroll
-            for (int hh = 0; hh < NH; hh++) {
-                if (seq[hh] < 0) continue;
-                int sc = V::half(mx, hh);
-                int prev = 0;
-                if (hasPrev) { prev = p.outScore[seq[hh]]; sc = sc > prev ? sc : prev; }  // maximum over the chunks so far
-                if (WIDTH != 32 && sc >= satLimit) {  // saturated (opal.cpp:364-370): hand over to width 32
-                    if (!(hasPrev && prev >= satLimit)) {
-                        const int at = atomicAdd(p.ovfCount, 1);
-                        p.ovfItems[at] = pairIdx * 2 + half0 + hh;
-                    }
-                    if (MULTI) p.outScore[seq[hh]] = satLimit;  // marker for the chunks below
-                } else if (WIDTH == 32 && WRAP && wrapped) {
-                    atomicAdd(p.ovfCount, 1);  // 32-bit overflow: the host returns OPAL_ERR_OVERFLOW
-                } else {
-                    p.outScore[seq[hh]] = sc;
-                    if (p.outEndQ) { p.outEndQ[seq[hh]] = -1; p.outEndT[seq[hh]] = -1; }
-                }
+        for (int hh = 0; hh < NH; hh++) {
+            const bool writer = (k == 0) && seq[hh] >= 0;
+            int sc = V::half(mx, hh);
+            int prev = 0;
+            if (writer && hasPrev) { prev = p.outScore[seq[hh]]; sc = sc > prev ? sc : prev; }  // maximum over the chunks so far
+            const bool sat = writer && WIDTH != 32 && sc >= satLimit;             // (opal.cpp:364-370): hand over to width 32
+            const bool append = sat && !(hasPrev && prev >= satLimit);            // not yet listed by an upper chunk
+            const unsigned long long ballot = __ballot(append);
+            if (ballot) {
+                int base = 0;
+                if (lane == __builtin_ctzll(ballot)) base = atomicAdd(p.ovfCount, (int)__builtin_popcountll(ballot));
+                base = __shfl(base, __builtin_ctzll(ballot), 64);
+                if (append) p.ovfItems[base + (int)__builtin_popcountll(ballot & ((1ull << lane) - 1ull))] = pairIdx * 2 + half0 + hh;
+            }
+            if (sat) {
+                if (MULTI) p.outScore[seq[hh]] = satLimit;  // marker for the chunks below
+            } else if (writer && WIDTH == 32 && WRAP && wrapped) {
+                atomicAdd(p.ovfCount, 1);  // 32-bit overflow: the host returns OPAL_ERR_OVERFLOW
+            } else if (writer) {
+                p.outScore[seq[hh]] = sc;
+                if (p.outEndQ) { p.outEndQ[seq[hh]] = -1; p.outEndT[seq[hh]] = -1; }
             }
         }
     }

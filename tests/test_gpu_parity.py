@@ -312,3 +312,25 @@ def test_reentrant_from_host_threads(ours, oracle):
     for th in threads: th.join()
     for i, (q, db, mode) in enumerate(jobs):
         _check(out[i], oracle.search(q, db, 3, 1, m, 1, MODES[mode]), mode, f"thread {i} {mode}")
+
+
+@pytest.mark.parametrize("narrow", ["16", "17"])
+def test_many_saturated_scores_rerun(narrow, ours, oracle, monkeypatch):
+    """Most of the database exceeds the 16-bit rung: the ballot-built re-run list must hold every one of them
+    exactly once (scores and end locations come from the 32-bit kernels), the rest stays at 16 bit."""
+    monkeypatch.setenv("OPAL_HIP_NARROW", narrow)
+    rng = np.random.RandomState(5)
+    q = rng.randint(0, 4, size=900).astype(np.uint8)
+    m = cases.simple_matrix(4, 60, -40)
+    db = []
+    for i in range(150):
+        if i % 3 == 0:
+            db.append(rng.randint(0, 4, size=int(rng.randint(20, 900))).astype(np.uint8))  # unrelated: small score
+        else:
+            t = q[: int(rng.randint(600, 900))].copy()                                       # near copy: > 32767
+            t[rng.randint(0, len(t), size=5)] = rng.randint(0, 4, size=5)
+            db.append(t)
+    got = ours.search(q, db, 30, 5, m, 1, MODES["SW"])[:4]
+    want = oracle.search(q, db, 30, 5, m, 1, MODES["SW"])
+    assert (want[1] > 32767).sum() > 80 and (want[1] < 20000).sum() > 30
+    _check(got, want, "SW", f"many overflows narrow={narrow}")
