@@ -79,6 +79,9 @@ typedef struct OpalHipLaunch {
     /* width 17 only: additions wrap, so scores >= sat_limit (= 32767 - largest matrix entry) are handed to
        the re-run list; neg_pad is the profile value of padding columns (SW: -sat_limit, else 0) */
     int sat_limit, neg_pad;
+    /* width 17, NW/HW/OV, single launch: use the diagonal-skewed kernels (values grow by up to
+       (rows_per_lane + steps) * gap_ext; the caller guarantees they stay below 32767) */
+    int skew;
     int* scratch;         /* [2 * number of sequences] carried across chunks (OV) */
 } OpalHipLaunch;
 

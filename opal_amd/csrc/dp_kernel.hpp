@@ -38,6 +38,7 @@
 #define FLAG_SWEND 1  // SW second pass: locate the end cell of a known score
 #define FLAG_WRAP 2   // width 32 SW: detect 32-bit wrap of ulH + P (reference opal.cpp:302-303,339-351)
 #define FLAG_MULTI 4  // the query is processed in several row chunks; the boundary row travels through HBM
+#define FLAG_SKEW 8   // width 17, NW/HW/OV: diagonal-skewed values, no gap-extension subtractions (see row_skew)
 
 #define WAVES_PER_BLOCK 4      // default waves per block (the launch may use fewer or more, up to MAX)
 #define MAX_WAVES_PER_BLOCK 8
@@ -151,6 +152,19 @@ template <> struct Vec<17> {
             : "=&v"(h), "+v"(e), "+v"(f), "+v"(acc), "=&v"(hq)
             : "v"(d), "v"(Qv), "v"(Rv));
     }
+    // NW/HW/OV in the skewed representation X' = X + (j + s)*Ge (j: register index, s: step): a gap
+    // extension costs nothing any more, E' = max(E', g), F' = max(F', g) with g = H' - (Go - Ge); the profile
+    // carries the +2*Ge the diagonal needs. 6 instructions per cell with the add, instead of 8.
+    static __device__ __forceinline__ void row_skew(reg d, reg& e, reg& f, reg& h, reg GQv) {
+        reg g;
+        asm("v_max_i16_e32 %0, %4, %1\n\t"
+            "v_max_i16_e32 %0, %0, %2\n\t"
+            "v_sub_u16_e32 %3, %0, %5\n\t"
+            "v_max_i16_e32 %1, %1, %3\n\t"
+            "v_max_i16_e32 %2, %2, %3"
+            : "=&v"(h), "+v"(e), "+v"(f), "=&v"(g)
+            : "v"(d), "v"(GQv));
+    }
     // NW/HW/OV: signed, wrapping (the host proves a-priori that nothing leaves the 16-bit range)
     static __device__ __forceinline__ void row_global(reg d, reg& e, reg& f, reg& h, reg Qv, reg Rv) {
         reg hq;
@@ -220,6 +234,7 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
     constexpr bool SWEND = (FLAGS & FLAG_SWEND) != 0;
     constexpr bool WRAP = (FLAGS & FLAG_WRAP) != 0;
     constexpr bool MULTI = (FLAGS & FLAG_MULTI) != 0;
+    constexpr bool SKEW = (FLAGS & FLAG_SKEW) != 0 && WIDTH == 17 && MODE != MODE_SW && !MULTI;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int log2G = p.log2G;
@@ -252,6 +267,7 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
             int v = negPad;     // pad residue, and (NW) rows below the query
             if (lr < 0) v = 0;  // virtual rows above the query: transparent
             else if (letter < A && j < S && lr < CR) v = p.matrix[(int)p.query[q0 + lr] * A + letter];
+            if (SKEW) v += 2 * p.Ge;  // skewed diagonal: H'(j,s) = H'(j-1,s-1) + P + 2*Ge
             *reinterpret_cast<elem*>(lds + letter * stride + k * LANE_BYTES + j * ES) = (elem)v;
         }
     }
@@ -309,6 +325,8 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
     // ---- per-lane DP state
     const int Go = p.Go, Ge = p.Ge;
     const reg Qv = V::splat(Go), Rv = V::splat(Ge);
+    const reg GQv = V::splat(Go - Ge);           // SKEW: g = H' - (Go - Ge)
+    const reg SR1v = V::splat((S - 1) * Ge);     // SKEW: frame change between the last register of a lane and register 0 of the next
     const int r0 = q0 + k * S - padTop;  // query row held in register 0 (negative: virtual rows)
     reg Hp[S], En[S];               // H[r][c-1] and E[r][c] for my rows
 #pragma unroll
@@ -320,13 +338,18 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
             Hp[j] = V::splat(V::clampv(hb));
             En[j] = V::splat(V::clampv(hb - Go));
         }
+        if (SKEW) {  // my first column runs at step k: H(j) is read as the diagonal of step k, E(j) at step k
+            Hp[j] = V::adds(Hp[j], V::splat((j + k - 1) * Ge));
+            En[j] = V::adds(En[j], V::splat((j + k) * Ge));
+        }
     }
     // what the lane below reads: H and next-row F of my last row. Before my first column it must be
     // H[last row][-1] (the diagonal input of the lane below at its first column).
     reg outH = 0, outF = 0;
     if ((MODE == MODE_NW || MODE == MODE_HW) && r0 + S - 1 >= 0)
         outH = V::splat(V::clampv(-(long long)Go - (long long)(r0 + S - 1) * Ge));
-    reg diagIn = 0;  // H[r0-1][c-1]; H[-1][-1] = 0 in every mode
+    if (SKEW) outH = V::adds(outH, V::splat((S - 1 + k - 1) * Ge));  // as if produced at the end of step k-1
+    reg diagIn = SKEW ? V::splat(-2 * Ge) : 0;  // H[r0-1][c-1]; H[-1][-1] = 0 in every mode (frame (-1)+(-1) when skewed)
     if (hasPrev && (MODE == MODE_NW || MODE == MODE_HW))  // H[q0-1][-1] for the first lane of a lower chunk
         diagIn = V::splat(V::clampv(-(long long)Go - (long long)(q0 - 1) * Ge));
     const unsigned padOff = (unsigned)(A * stride);
@@ -363,6 +386,7 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
     if (hasPrev && 0 < slotLen) bndNext = p.bnd[bndIdx(0)];
 
     int topHv = V::clampv(-(long long)Go);  // NW: H[-1][0]
+    reg sRv = 0;                             // SKEW: s*Ge as a 16-bit value
     for (int s = 0; s < nsteps; s++) {
         const unsigned tok = tokNext;
         if (s + 1 < slotLen) tokNext = p.tokens[tokBase + (uint64_t)(s + 1)];
@@ -378,7 +402,16 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
         }
         reg inH = (reg)shr1((unsigned)outH, 0u);
         reg inF = (reg)shr1((unsigned)outF, 0u);
-        if (k == 0) {
+        if (SKEW) {
+            inH = V::subs(inH, SR1v);
+            inF = V::subs(inF, SR1v);
+            if (k == 0) {
+                // top boundary in my frame: H[-1][c] + (s-1)*Ge (read as a diagonal one step later) and
+                // F[0][c] + s*Ge = H[-1][c] - Go + s*Ge; NW: H[-1][c] = -Go - s*Ge, HW/OV: 0
+                if (MODE == MODE_NW) { inH = V::splat(-Go - Ge); inF = V::splat(-2 * Go); }
+                else { inH = V::subs(sRv, Rv); inF = V::subs(sRv, Qv); }
+            }
+        } else if (k == 0) {
             if (hasPrev) {
                 inH = (reg)bndCur.x;
                 inF = (reg)bndCur.y;
@@ -421,6 +454,7 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
                             reg dn = 0;
                             if (j + 1 < S) dn = V::adds(Hp[j], P[i + 1]);  // diagonal of the next row: last use of H[j][c-1]
                             if (MODE == MODE_SW) V::row_sw(d, En[j], f, SWEND ? cm : mx, h, Qv, Rv);
+                            else if (SKEW) V::row_skew(d, En[j], f, h, GQv);
                             else V::row_global(d, En[j], f, h, Qv, Rv);
                             Hp[j] = h;
                             d = dn;
@@ -509,14 +543,14 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
                     const reg hl = SelectRow<reg, S, 0, S>::get(Hp, jLast);
 #pragma unroll
                     for (int hh = 0; hh < NH; hh++)
-                        if (c == len[hh] - 1) best[hh] = V::half(hl, hh);
+                        if (c == len[hh] - 1) best[hh] = V::half(SKEW ? V::subs(hl, V::splat((jLast + s) * Ge)) : hl, hh);
                 }
             }
             if ((MODE == MODE_HW || MODE == MODE_OV) && k == kLast && !hasNext) {
                 // last query row = last register of the last lane = this column's outH
 #pragma unroll
                 for (int hh = 0; hh < NH; hh++) {
-                    const int v = V::half(outH, hh);
+                    const int v = V::half(SKEW ? V::subs(outH, V::adds(sRv, SR1v)) : outH, hh);
                     if (c < len[hh]) {
                         if (c == len[hh] - 1) prevBest[hh] = best[hh];
                         if (v > best[hh]) { best[hh] = v; bestCol[hh] = c; }  // strict >: first column wins (opal.cpp:824-834)
@@ -533,7 +567,7 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
                         if (c == len[hh] - 1) {
 #pragma unroll
                             for (int j = S - 1; j >= 0; j--) {
-                                const int v = V::half(Hp[j], hh);
+                                const int v = V::half(SKEW ? V::subs(Hp[j], V::splat((j + s) * Ge)) : Hp[j], hh);
                                 if (j >= jlo && j < jhi && v >= lcMax[hh]) { lcMax[hh] = v; lcRow[hh] = r0 + j; }
                             }
                         }
@@ -542,6 +576,7 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
             }
         }
         diagIn = inH;
+        if (SKEW) sRv = V::adds(sRv, Rv);
     }
 
     // ---- results

@@ -231,6 +231,7 @@ struct SearchCtx {
     int Q, A, Go, Ge, mode, wantEnd;
     int* dScore; int* dEndQ; int* dEndT;
     int satLimit, negPad;  // width 17 (plain 16-bit) parameters
+    long long maxScore;    // largest matrix entry (>= 0)
 };
 
 // Measured on MI355X (profiles/r01_ubench_*): packed-int16 and 32-bit max/min issue one wave
@@ -401,6 +402,13 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
         a.out_score = c.dScore; a.out_end_query = c.wantEnd ? c.dEndQ : nullptr; a.out_end_target = c.wantEnd ? c.dEndT : nullptr;
         a.overflow_count = ovfCounter; a.overflow_items = c.db->dOvfItems;
         a.sat_limit = c.satLimit; a.neg_pad = c.negPad;
+        if (width == 17 && c.mode != OPAL_MODE_SW && !work && !getenv("OPAL_HIP_NO_SKEW")) {
+            // skewed kernels add up to (rows + steps) * Ge to every value: allowed when even the longest
+            // sequence of the class stays inside the 16-bit range
+            const long long L0 = lenOf(k.first);
+            const long long top = std::min<long long>(c.Q, L0) * c.maxScore + (OPAL_HIP_MAX_ROWS + L0 + 64 + 4) * (long long)c.Ge;
+            a.skew = top < 32000;
+        }
         const bool side = (int)ki < nside;
         a.stream = side ? c.db->stream((int)ki) : nullptr;
         a.priority = side ? 1 : 0;
@@ -529,12 +537,16 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
         if (!fits17) narrow = 16;
     }
     const int satLimit = narrow == 17 ? (int)(32767 - maxS) : 32767;
-    SearchCtx c{db, Q, A, Go, Ge, mode, wantEnd, dScore, dEndQ, dEndT, satLimit, mode == OPAL_MODE_SW ? -satLimit : 0};
+    SearchCtx c{db, Q, A, Go, Ge, mode, wantEnd, dScore, dEndQ, dEndT, satLimit, mode == OPAL_MODE_SW ? -satLimit : 0, maxS};
     const int nNarrow = narrow == 16 ? P : 2 * P;  // items of the narrow rung: pairs or sequences
     auto pairLenOf = [db](int p) { return db->pairLen[2 * (size_t)p]; };   // width-16 items are pairs
     auto seqLenOf = [db](int it) { return db->pairLen[(size_t)it]; };      // width-32 items are pair*2+half
-    void* evStart = kernelMs ? opal_hip_event_create() : nullptr;
-    void* evStop = kernelMs ? opal_hip_event_create() : nullptr;
+    struct Events {  // timing events around every DP launch of this call, released on every return path
+        void* start = nullptr; void* stop = nullptr;
+        ~Events() { opal_hip_event_destroy(start); opal_hip_event_destroy(stop); }
+    } ev;
+    if (kernelMs) { ev.start = opal_hip_event_create(); ev.stop = opal_hip_event_create(); }
+    void* const evStart = ev.start; void* const evStop = ev.stop;
     if (evStart) opal_hip_event_record(evStart, nullptr);
 
     if (mode == OPAL_MODE_SW) {
@@ -614,8 +626,6 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
     if (evStop) opal_hip_event_record(evStop, nullptr);
     if (opal_hip_stream_sync(nullptr)) return OPAL_ERR_NO_SIMD_SUPPORT;
     if (kernelMs && evStart && evStop) *kernelMs = opal_hip_event_elapsed_ms(evStart, evStop);
-    opal_hip_event_destroy(evStart);
-    opal_hip_event_destroy(evStop);
     return rc;
 }
 

@@ -147,6 +147,7 @@ static int launch_flags(const OpalHipLaunch* a) {
     if (a->mode == MODE_SW && a->want_end) flags |= FLAG_SWEND;
     if (a->mode == MODE_SW && a->width == 32 && a->detect_wrap && !a->want_end) flags |= FLAG_WRAP;
     if (a->chunk_flags) flags |= FLAG_MULTI;
+    if (a->skew && a->width == 17 && a->mode != MODE_SW && !a->chunk_flags) flags |= FLAG_SKEW;
     return flags;
 }
 

@@ -334,3 +334,21 @@ def test_many_saturated_scores_rerun(narrow, ours, oracle, monkeypatch):
     want = oracle.search(q, db, 30, 5, m, 1, MODES["SW"])
     assert (want[1] > 32767).sum() > 80 and (want[1] < 20000).sum() > 30
     _check(got, want, "SW", f"many overflows narrow={narrow}")
+
+
+@pytest.mark.parametrize("mode", ["NW", "HW", "OV"])
+def test_unskewed_16bit_kernels_still_match(mode, ours, oracle, monkeypatch):
+    """NW/HW/OV normally run in the diagonal-skewed representation; the plain one (used when the skew would
+    leave the 16-bit range) must give the same answers."""
+    q, db, m = cases.materialise(cases.CASES["synth_q300_db2000_o3"])
+    db = db[:400]
+    monkeypatch.setenv("OPAL_HIP_NO_SKEW", "1")
+    got = ours.search(q, db, 3, 1, m, 1, MODES[mode])[:4]
+    _check(got, oracle.search(q, db, 3, 1, m, 1, MODES[mode]), mode, f"no-skew {mode}")
+    monkeypatch.delenv("OPAL_HIP_NO_SKEW")
+    # large extension penalty: the skew bound fails for the long targets, holds for the short ones
+    _, dbl = cases.random4(91, 10, 30, 4, 30, 2500)
+    q4 = (np.arange(150) % 4).astype(np.uint8)
+    m4 = cases.simple_matrix(4, 5, -4)
+    got = ours.search(q4, dbl, 12, 9, m4, 1, MODES[mode])[:4]
+    _check(got, oracle.search(q4, dbl, 12, 9, m4, 1, MODES[mode]), mode, f"mixed skew {mode}")
