@@ -37,7 +37,7 @@ typedef struct OpalHipLaunch {
     int width;        /* 16: two sequences per lane as packed int16; 17: one sequence per lane, plain 16-bit
                          (full-rate VALU); 32: one sequence per lane, int32 */
     int mode;         /* OPAL_MODE_* */
-    int want_end;     /* 0: score only; 1: also end locations (SW: second pass, needs out_score filled) */
+    int want_end;     /* 0: score only; 1: also end locations (out_end_query / out_end_target must be set) */
     int detect_wrap;  /* width 32, SW only: test ulH+P for 32-bit wrap (reference opal.cpp:302-303) */
     /* wave geometry: each sequence (pair) is spread over `lanes_per_seq` adjacent lanes, each lane
        holding `rows_per_lane` consecutive query rows in registers */

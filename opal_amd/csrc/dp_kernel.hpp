@@ -35,7 +35,7 @@
 #define MODE_OV 2
 #define MODE_SW 3
 
-#define FLAG_SWEND 1  // SW second pass: locate the end cell of a known score
+#define FLAG_SWEND 1  // SW with end location: the lane also records where its running maximum was first reached
 #define FLAG_WRAP 2   // width 32 SW: detect 32-bit wrap of ulH + P (reference opal.cpp:302-303,339-351)
 #define FLAG_MULTI 4  // the query is processed in several row chunks; the boundary row travels through HBM
 #define FLAG_SKEW 8   // width 17, NW/HW/OV: diagonal-skewed values, no gap-extension subtractions (see row_skew)
@@ -309,19 +309,6 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
     const int maxLen = __builtin_amdgcn_readfirstlane(wave_max_i32(slotLen));
     const int nsteps = maxLen > 0 ? maxLen + G - 1 : 0;
 
-    // SW second pass: the score to look for (from the first pass); 0 or saturated: nothing to do
-    int target[NH];
-#pragma unroll
-    for (int h = 0; h < NH; h++) target[h] = 0;
-    if (SWEND) {
-#pragma unroll
-        for (int h = 0; h < NH; h++) {
-            int t = (seq[h] >= 0) ? p.outScore[seq[h]] : 0;
-            if (WIDTH != 32 && t >= satLimit) t = 0;  // the width-32 re-run owns this one
-            target[h] = t;
-        }
-    }
-
     // ---- per-lane DP state
     const int Go = p.Go, Ge = p.Ge;
     const reg Qv = V::splat(Go), Rv = V::splat(Ge);
@@ -517,21 +504,27 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
             if (hasNext && k == G - 1 && c >= 0 && c < slotLen) p.bnd[bndIdx(c)] = make_uint2((unsigned)outH, (unsigned)outF);
 
             if (MODE == MODE_SW && SWEND) {
-                // rare: this column holds a cell equal to the known score -> record the first (col, row)
-                bool hit = false;
+                // End location in the same pass. cm = this column's maximum over my rows. Only a STRICT
+                // improvement of my running maximum can be the first cell holding the final score
+                // (smallest column first, opal.h:44-45); the row scan below runs for those columns only.
+                const reg nm = V::maxs(mx, cm);
+                bool improved = false;
 #pragma unroll
-                for (int hh = 0; hh < NH; hh++)
-                    hit |= (target[hh] > 0 && endCol[hh] == INT_MAX && V::half(cm, hh) == target[hh]);
-                if (hit) {
+                for (int hh = 0; hh < NH; hh++) improved |= V::half(nm, hh) != V::half(mx, hh);
+                if (improved) {
 #pragma unroll
                     for (int hh = 0; hh < NH; hh++) {
-                        if (target[hh] > 0 && endCol[hh] == INT_MAX && V::half(cm, hh) == target[hh]) {
+                        const int cv = V::half(cm, hh);
+                        if (cv > V::half(mx, hh)) {
+                            int r = 0;
 #pragma unroll
                             for (int j = S - 1; j >= 0; j--)
-                                if (j >= jlo && j < jhi && V::half(Hp[j], hh) == target[hh]) endRow[hh] = r0 + j;
-                            if (endRow[hh] >= 0) endCol[hh] = c;
+                                if (V::half(Hp[j], hh) == cv) r = j;  // smallest row of the column holding it
+                            endRow[hh] = r0 + r;
+                            endCol[hh] = c;
                         }
                     }
+                    mx = nm;
                 }
             }
             if (MODE == MODE_NW) {
@@ -580,8 +573,7 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
     }
 
     // ---- results
-    if (MODE == MODE_SW && !SWEND) {
-        for (int d = 1; d < G; d <<= 1) mx = V::maxs(mx, (reg)__shfl_xor((int)mx, d, 64));  // maximum over the slot
+    if (MODE == MODE_SW) {
         if (WRAP) {
             for (int d = 1; d < G; d <<= 1) wrapped |= __shfl_xor(wrapped, d, 64);
         }
@@ -590,10 +582,29 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
         // list with a single atomic, each flagged lane takes the entry given by its rank in the ballot.
 #pragma unroll
         for (int hh = 0; hh < NH; hh++) {
+            // best cell over the slot's lanes: highest score, then smallest column, then smallest lane (= rows)
+            int sc = V::half(mx, hh), col = endCol[hh], row = endRow[hh], src = k;
+            for (int d = 1; d < G; d <<= 1) {
+                const int osc = __shfl_xor(sc, d, 64);
+                if (SWEND) {
+                    const int ocol = __shfl_xor(col, d, 64), orow = __shfl_xor(row, d, 64), osrc = __shfl_xor(src, d, 64);
+                    if (osc > sc || (osc == sc && (ocol < col || (ocol == col && osrc < src)))) { sc = osc; col = ocol; row = orow; src = osrc; }
+                } else {
+                    sc = osc > sc ? osc : sc;
+                }
+            }
             const bool writer = (k == 0) && seq[hh] >= 0;
-            int sc = V::half(mx, hh);
             int prev = 0;
-            if (writer && hasPrev) { prev = p.outScore[seq[hh]]; sc = sc > prev ? sc : prev; }  // maximum over the chunks so far
+            if (writer && hasPrev) {  // chunks above hold smaller rows: they keep the cell unless ours is better
+                prev = p.outScore[seq[hh]];
+                bool keepPrev = prev > sc;
+                if (SWEND && prev == sc) {
+                    const int pc = p.outEndT[seq[hh]];
+                    keepPrev = (pc < 0 ? INT_MAX : pc) <= col;
+                }
+                if (!SWEND && prev == sc) keepPrev = true;
+                if (keepPrev) { sc = prev; if (SWEND) { col = p.outEndT[seq[hh]]; row = p.outEndQ[seq[hh]]; if (col < 0) col = INT_MAX; } }
+            }
             const bool sat = writer && WIDTH != 32 && sc >= satLimit;             // (opal.cpp:364-370): hand over to width 32
             const bool append = sat && !(hasPrev && prev >= satLimit);            // not yet listed by an upper chunk
             const unsigned long long ballot = __ballot(append);
@@ -609,26 +620,11 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
                 atomicAdd(p.ovfCount, 1);  // 32-bit overflow: the host returns OPAL_ERR_OVERFLOW
             } else if (writer) {
                 p.outScore[seq[hh]] = sc;
-                if (p.outEndQ) { p.outEndQ[seq[hh]] = -1; p.outEndT[seq[hh]] = -1; }
-            }
-        }
-    }
-    if (MODE == MODE_SW && SWEND) {
-        // smallest column, then smallest lane (= smallest rows) over the slot
-#pragma unroll
-        for (int hh = 0; hh < NH; hh++) {
-            int col = endCol[hh], row = endRow[hh], src = k;
-            for (int d = 1; d < G; d <<= 1) {
-                const int ocol = __shfl_xor(col, d, 64), orow = __shfl_xor(row, d, 64), osrc = __shfl_xor(src, d, 64);
-                if (ocol < col || (ocol == col && osrc < src)) { col = ocol; row = orow; src = osrc; }
-            }
-            if (k == 0 && seq[hh] >= 0 && target[hh] > 0) {
-                if (hasPrev) {  // an upper chunk (smaller rows) keeps the cell unless ours lies in an earlier column
-                    const int pc = p.outEndT[seq[hh]], pr = p.outEndQ[seq[hh]];
-                    if (pc >= 0 && !(col != INT_MAX && col < pc)) { col = pc; row = pr; }
+                if (p.outEndQ) {
+                    const bool none = !SWEND || sc <= 0 || col == INT_MAX;  // score 0: no cell (test.cpp:242-243)
+                    p.outEndQ[seq[hh]] = none ? -1 : row;
+                    p.outEndT[seq[hh]] = none ? -1 : col;
                 }
-                p.outEndQ[seq[hh]] = (col == INT_MAX) ? -1 : row;
-                p.outEndT[seq[hh]] = (col == INT_MAX) ? -1 : col;
             }
         }
     }
@@ -665,6 +661,7 @@ KernelFn opal_kernel_sw16(int rows);                      // width 16, SW, score
 KernelFn opal_kernel_w16(int mode, int flags, int rows);  // width 16, the other variants: rows 4,8,..,40
 KernelFn opal_kernel_w32(int mode, int flags, int rows);  // width 32: rows 8,16,24,32,40
 KernelFn opal_kernel_s16sw(int rows);                     // width 17, SW, score only: rows 1..40
+KernelFn opal_kernel_s16swend(int rows);                  // width 17, SW, score + end location: rows 1..40
 KernelFn opal_kernel_s16(int mode, int flags, int rows);  // width 17, other variants incl. FLAG_MULTI: rows 4,8,..,40
 KernelFn opal_kernel_w16_multi(int mode, int flags, int rows);  // FLAG_MULTI variants
 KernelFn opal_kernel_w32_multi(int mode, int flags, int rows);

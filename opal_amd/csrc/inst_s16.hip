@@ -17,7 +17,7 @@ KernelFn opal_kernel_s16(int mode, int flags, int rows) {
     case MODE_OV: return multi ? pick<MODE_OV, FLAG_MULTI>(rows, Seq{}) : skew ? pick<MODE_OV, FLAG_SKEW>(rows, Seq{}) : pick<MODE_OV, 0>(rows, Seq{});
     case MODE_SW:
         if (multi) return end ? pick<MODE_SW, FLAG_SWEND | FLAG_MULTI>(rows, Seq{}) : pick<MODE_SW, FLAG_MULTI>(rows, Seq{});
-        return end ? pick<MODE_SW, FLAG_SWEND>(rows, Seq{}) : opal_kernel_s16sw(rows);
+        return end ? opal_kernel_s16swend(rows) : opal_kernel_s16sw(rows);
     }
     return nullptr;
 }

@@ -15,6 +15,7 @@ KernelFn opal_kernel_w32(int mode, int flags, int rows) {
     case MODE_HW: return pick<MODE_HW, 0>(rows, Seq{});
     case MODE_OV: return pick<MODE_OV, 0>(rows, Seq{});
     case MODE_SW:
+        if ((flags & FLAG_SWEND) && (flags & FLAG_WRAP)) return pick<MODE_SW, FLAG_SWEND | FLAG_WRAP>(rows, Seq{});
         if (flags & FLAG_SWEND) return pick<MODE_SW, FLAG_SWEND>(rows, Seq{});
         if (flags & FLAG_WRAP) return pick<MODE_SW, FLAG_WRAP>(rows, Seq{});
         return pick<MODE_SW, 0>(rows, Seq{});
@@ -29,6 +30,7 @@ KernelFn opal_kernel_w32_multi(int mode, int flags, int rows) {
     case MODE_HW: return pick<MODE_HW, FLAG_MULTI>(rows, Seq{});
     case MODE_OV: return pick<MODE_OV, FLAG_MULTI>(rows, Seq{});
     case MODE_SW:
+        if ((flags & FLAG_SWEND) && (flags & FLAG_WRAP)) return pick<MODE_SW, FLAG_SWEND | FLAG_WRAP | FLAG_MULTI>(rows, Seq{});
         if (flags & FLAG_SWEND) return pick<MODE_SW, FLAG_SWEND | FLAG_MULTI>(rows, Seq{});
         if (flags & FLAG_WRAP) return pick<MODE_SW, FLAG_WRAP | FLAG_MULTI>(rows, Seq{});
         return pick<MODE_SW, FLAG_MULTI>(rows, Seq{});

@@ -550,13 +550,15 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
     if (evStart) opal_hip_event_record(evStart, nullptr);
 
     if (mode == OPAL_MODE_SW) {
-        // rung 1: everything at width 16 (if the inputs fit), saturated scores go to the re-run list
+        // rung 1: everything at 16 bits (if the inputs fit), saturated scores go to the re-run list.
+        // End locations are found in the same pass (the kernels record where a lane's running maximum
+        // was first reached).
         int n32 = 0;
         const int* work32 = nullptr;
         int first32 = 0;
         if (fits16) {
-            if (narrow == 16) rc = launch_range(c, 16, 0, 0, nullptr, 0, nNarrow, pairLenOf, db->dOvfCount);
-            else rc = launch_range(c, 17, 0, 0, nullptr, 0, nNarrow, seqLenOf, db->dOvfCount);
+            if (narrow == 16) rc = launch_range(c, 16, wantEnd, 0, nullptr, 0, nNarrow, pairLenOf, db->dOvfCount);
+            else rc = launch_range(c, 17, wantEnd, 0, nullptr, 0, nNarrow, seqLenOf, db->dOvfCount);
             if (rc) return rc;
             int cnt = 0;
             if (opal_hip_memcpy_d2h(&cnt, db->dOvfCount, sizeof(int), nullptr) || opal_hip_stream_sync(nullptr))
@@ -569,22 +571,13 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
         if (n32 > 0) {
             const long long maxLen = db->pairLen[0];
             const int detect = (double)std::min<long long>(Q, maxLen) * (double)maxS > (double)INT_MAX;
-            if ((rc = launch_range(c, 32, 0, detect, work32, first32, n32, seqLenOf, db->dOvfCount + 1))) return rc;
+            if ((rc = launch_range(c, 32, wantEnd, detect, work32, first32, n32, seqLenOf, db->dOvfCount + 1))) return rc;
             if (detect) {
                 int wraps = 0;
                 if (opal_hip_memcpy_d2h(&wraps, db->dOvfCount + 1, sizeof(int), nullptr) || opal_hip_stream_sync(nullptr))
                     return OPAL_ERR_NO_SIMD_SUPPORT;
                 if (wraps) rc = OPAL_ERR_OVERFLOW;
             }
-        }
-        if (wantEnd && rc == 0) {
-            // end locations: second pass that looks for the known score (first column, then first row)
-            if (fits16) {
-                if (narrow == 16) rc = launch_range(c, 16, 1, 0, nullptr, 0, nNarrow, pairLenOf, db->dOvfCount);
-                else rc = launch_range(c, 17, 1, 0, nullptr, 0, nNarrow, seqLenOf, db->dOvfCount);
-                if (rc) return rc;
-            }
-            if (n32 > 0 && (rc = launch_range(c, 32, 1, 0, work32, first32, n32, seqLenOf, db->dOvfCount + 1))) return rc;
         }
     } else {
         // NW/HW/OV: width 16 where an a-priori bound proves that no value leaves the 16-bit range,

@@ -145,7 +145,7 @@ static KernelFn pick_kernel(int width, int mode, int flags, int rows) {
 static int launch_flags(const OpalHipLaunch* a) {
     int flags = 0;
     if (a->mode == MODE_SW && a->want_end) flags |= FLAG_SWEND;
-    if (a->mode == MODE_SW && a->width == 32 && a->detect_wrap && !a->want_end) flags |= FLAG_WRAP;
+    if (a->mode == MODE_SW && a->width == 32 && a->detect_wrap) flags |= FLAG_WRAP;
     if (a->chunk_flags) flags |= FLAG_MULTI;
     if (a->skew && a->width == 17 && a->mode != MODE_SW && !a->chunk_flags) flags |= FLAG_SKEW;
     return flags;
