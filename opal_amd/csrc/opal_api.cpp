@@ -534,7 +534,8 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
             const int rows = opal_hip_rows_supported(17, mode, 0, need);
             fits17 = rows && opal_hip_lds_bytes(17, G, rows, A) <= 160 * 1024;
         }
-        if (!fits17) narrow = 16;
+        const char* force = getenv("OPAL_HIP_NARROW_FORCE");  // "17": run width 17 in row chunks rather than packed pairs
+        if (!fits17 && !(force && atoi(force) == 17)) narrow = 16;
     }
     const int satLimit = narrow == 17 ? (int)(32767 - maxS) : 32767;
     SearchCtx c{db, Q, A, Go, Ge, mode, wantEnd, dScore, dEndQ, dEndT, satLimit, mode == OPAL_MODE_SW ? -satLimit : 0, maxS};
