@@ -194,16 +194,18 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     return v;
 }
 
-// Register select with a wave-uniform runtime index (used once per sequence, NW only).
+// Register select with a wave-uniform runtime index (used once per sequence, NW only). A select chain
+// with an opaque barrier per step: a plain indexed read -- or a balanced tree of selects, which LLVM
+// turns back into one -- would move the whole register array to scratch memory.
 template <typename T, int S, int LO, int HI> struct SelectRow {
     static __device__ __forceinline__ T get(const T (&a)[S], int idx) {
-        if constexpr (LO + 1 == HI) {
-            return a[LO];
-        } else {
-            constexpr int MID = (LO + HI) / 2;
-            if (idx < MID) return SelectRow<T, S, LO, MID>::get(a, idx);
-            return SelectRow<T, S, MID, HI>::get(a, idx);
+        T r = a[LO];
+#pragma unroll
+        for (int j = LO + 1; j < HI; j++) {
+            r = (idx == j) ? a[j] : r;
+            asm volatile("" : "+v"(r));
         }
+        return r;
     }
 };
 
