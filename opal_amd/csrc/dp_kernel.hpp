@@ -560,11 +560,14 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
 #pragma unroll
                     for (int hh = 0; hh < NH; hh++) {
                         if (c == len[hh] - 1) {
+                            int bv = lcMax[hh], bj = -1;
 #pragma unroll
                             for (int j = S - 1; j >= 0; j--) {
                                 const int v = V::half(SKEW ? V::subs(Hp[j], V::splat((j + s) * Ge)) : Hp[j], hh);
-                                if (j >= jlo && j < jhi && v >= lcMax[hh]) { lcMax[hh] = v; lcRow[hh] = r0 + j; }
+                                if (j >= jlo && j < jhi && v >= bv) { bv = v; bj = j; }
+                                asm volatile("" : "+v"(bv), "+v"(bj));  // keep the scan a short serial chain (register pressure)
                             }
+                            if (bj >= 0) { lcMax[hh] = bv; lcRow[hh] = r0 + bj; }
                         }
                     }
                 }
