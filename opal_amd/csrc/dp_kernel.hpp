@@ -95,6 +95,7 @@ template <> struct Vec<16> {  // two int16 scores per register
         return __builtin_bit_cast(reg, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
     }
     static __device__ __forceinline__ int half(reg a, int h) { return h ? ((int)a >> 16) : (int)(short)(a & 0xffffu); }
+    static __device__ __forceinline__ bool same(reg a, reg b, int h) { return half(a, h) == half(b, h); }
     static __device__ __forceinline__ int clampv(long long v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : (int)v); }
 };
 
@@ -110,6 +111,7 @@ template <> struct Vec<32> {  // one int32 score per register
     static __device__ __forceinline__ reg subu(reg a, reg b) { return (int)__builtin_elementwise_sub_sat((unsigned)a, (unsigned)b); }
     static __device__ __forceinline__ reg maxs(reg a, reg b) { return a > b ? a : b; }
     static __device__ __forceinline__ int half(reg a, int) { return a; }
+    static __device__ __forceinline__ bool same(reg a, reg b, int) { return a == b; }
     static __device__ __forceinline__ int clampv(long long v) {
         return v < -(1LL << 30) ? -(1 << 30) : (v > (1LL << 30) ? (1 << 30) : (int)v);
     }
@@ -135,6 +137,7 @@ template <> struct Vec<17> {
     static __device__ __forceinline__ reg subu(reg a, reg b) { reg r; asm("v_sub_u16_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
     static __device__ __forceinline__ reg maxs(reg a, reg b) { reg r; asm("v_max_i16_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
     static __device__ __forceinline__ int half(reg a, int) { return (int)(short)(a & 0xffffu); }
+    static __device__ __forceinline__ bool same(reg a, reg b, int) { return (unsigned short)a == (unsigned short)b; }  // v_cmp_eq_u16
     static __device__ __forceinline__ int clampv(long long v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : (int)v); }
     // One row of one column as ONE asm block (hipcc pads every asm statement with a wait state and cannot
     // coalesce registers through it, so the block is as large as the data flow allows). d = H(diag) + P.
@@ -521,7 +524,7 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
                             int r = 0;
 #pragma unroll
                             for (int j = S - 1; j >= 0; j--)
-                                if (V::half(Hp[j], hh) == cv) r = j;  // smallest row of the column holding it
+                                if (V::same(Hp[j], cm, hh)) r = j;  // smallest row of the column holding it
                             endRow[hh] = r0 + r;
                             endCol[hh] = c;
                         }
