@@ -1,25 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- GCUPS of the database-search hot path on MI355X (driver contract in the task prompt).
 
-A "step" is one pass of the hot path over one batch: one 300-residue query against the whole
-synthetic protein database shard of this rank (BASELINE.json configs[1]: 100 000 sequences,
-~350 aa, Smith-Waterman score-only), database already packed and resident in HBM, scores written
-to a device buffer in caller order. With N GPUs every rank owns its own 100 000-sequence shard of
-the same synthetic database (weak scaling, no data-path collective) and the per-sequence scores are
-collected on rank 0 with ONE RCCL gather per step, inside the timed region.
+A "step" is one pass of the hot path over one batch: one query against the whole synthetic protein
+database shard of this rank, database already packed and resident in HBM, results written to device
+buffers in caller order, then ONE gather of the per-sequence results to rank 0 (the path's only exchange).
+
+Workloads (BASELINE.json `configs`):
+  c2 (default)  300-aa synthetic query x 100 000 synthetic sequences PER GPU, SW score-only, gaps 11/1  -> "weak"
+  c3            the c2 database, --mode NW|HW|OV|SW with end locations
+  c4            P18080 (513 aa) x 5 000 000 synthetic sequences in total, sharded over the GPUs        -> "strong"
+  c5            2000-aa synthetic query on the c4 database (16 -> 32 bit re-run ladder)                 -> "strong"
+The global database is dealt to the ranks in 64-sequence groups balancing the residue count
+(opal_amd/shard.py); rank 0 puts the gathered results back into database order.
+
+`--gpus N` with no RANK in the environment starts the N ranks itself (fresh child processes, before this
+process touches torch or the GPU) and relays rank 0's JSON line; under torchrun (RANK set) it runs as one rank.
 
 GCUPS = queryLength * sum(dbSeqLengths) / 1e9 / seconds (reference src/opal_aligner.cpp:203-207;
-cells of overflow re-runs are not counted).
-
-Prints ONE JSON line on rank 0.
+cells of overflow re-runs are not counted).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
-import threading
 import time
+import zlib
 
 import numpy as np
 
@@ -28,19 +36,85 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-# VALU issue bound of the plain-16-bit kernel (profiles/r01_ubench_valu_*.txt): v_add_u16 / v_sub_u16 clamp /
-# v_max_i16 issue one wave-instruction per 2 clocks per SIMD; a cell costs 9 of them, a wave-instruction covers
-# 64 lanes = 64 cells. (The packed-int16 kernel: 10 instructions x 4 clocks per 128 cells, i.e. 10% lower.)
-SIMDS, CLOCK_HZ, INSTR_PER_CELL, CLK_PER_INSTR, LANES = 1024, 2.4e9, 9.0, 2.0, 64.0
-VALU_PEAK_GCUPS = SIMDS * CLOCK_HZ / (INSTR_PER_CELL * CLK_PER_INSTR / LANES) / 1e9
+# VALU issue bound of the plain-16-bit kernel (profiles/r01_ubench_valu_*.txt, r02_ubench_bank.txt): v_add_u16 /
+# v_sub_u16 clamp / v_max_i16 issue one wave-instruction per 2 clocks per SIMD; a Smith-Waterman cell costs 9 of
+# them (6 for the skewed NW/HW/OV kernels), a wave-instruction covers 64 lanes = 64 cells.
+SIMDS, CLOCK_HZ, CLK_PER_INSTR, LANES = 1024, 2.4e9, 2.0, 64.0
 
 
-def cpu_baseline(query, res, offs, lens, matrix, gap_open, gap_ext):
+def valu_peak_gcups(instr_per_cell):
+    return SIMDS * CLOCK_HZ / (instr_per_cell * CLK_PER_INSTR / LANES) / 1e9
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--seqs", type=int, default=None, help="database sequences per GPU (weak scaling)")
+    ap.add_argument("--total-seqs", type=int, default=None, help="database sequences in total (strong scaling)")
+    ap.add_argument("--qlen", type=int, default=None)
+    ap.add_argument("--gap-open", type=int, default=11)
+    ap.add_argument("--gap-ext", type=int, default=1)
+    ap.add_argument("--mode", default="SW")
+    ap.add_argument("--search-type", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--query-fasta", default=None, help="use the first record of this FASTA file as the query")
+    args = ap.parse_args(argv)
+    wl = args.workload
+    if wl in ("c4", "c5") and args.total_seqs is None and args.seqs is None:
+        args.total_seqs = 5000000
+    if wl == "c4" and args.query_fasta is None and args.qlen is None:
+        args.query_fasta = os.path.join(ROOT, "tests", "golden", "data", "query_P18080.fasta")
+    if wl == "c5" and args.qlen is None:
+        args.qlen = 2000
+    if args.qlen is None:
+        args.qlen = 300
+    if args.search_type is None:
+        args.search_type = 1 if wl == "c3" else 0
+    if args.seqs is None and args.total_seqs is None:
+        args.seqs = 100000
+    big = (args.total_seqs or 0) >= 1000000
+    if args.steps is None:
+        args.steps = 5 if big else 100
+    if args.warmup is None:
+        args.warmup = 1 if big else 10
+    return args
+
+
+def spawn_ranks(n):
+    """Start the N ranks as fresh children of this process (which has not imported torch nor touched the GPU),
+    one per GPU, rendezvous on 127.0.0.1. Rank 0's stdout is relayed; any failing rank fails the run."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
+        sys.stdout.write(out0)
+        return 1
+    sys.stdout.write(out0)
+    return 0
+
+
+def cpu_baseline(query, res, offs, matrix, gap_open, gap_ext, mode_code):
     """The reference's own AVX2 path (oracle/_ref/libopal_ref.so, built from /root/reference in the build
     container) timed on this host's cores through a small pthread harness (oracle/ref_bench.c); falls back
     to the scalar oracle port if the reference build is absent. Bounded to ~10-30 s of CPU work."""
     import oracle_lib
-    n_all = len(lens)
+    n_all = len(offs) - 1
     cores = os.cpu_count() or 1
     bench_so = os.path.join(oracle_lib.ORACLE_DIR, "_ref", "libref_bench.so")
     if oracle_lib.have_ref() and os.path.exists(bench_so):
@@ -53,48 +127,77 @@ def cpu_baseline(query, res, offs, lens, matrix, gap_open, gap_ext):
 
         def run(n, threads):
             return lib.ref_bench_run(up(q), len(q), up(r), o.ctypes.data_as(C.POINTER(C.c_int64)), int(n), int(gap_open),
-                                     int(gap_ext), m.ctypes.data_as(C.POINTER(C.c_int)), int(m.shape[0]), 3, int(threads), None)
-        n1 = min(n_all, 30000)   # 1 thread (the reference's own methodology, aligner_comparison.md:11): ~0.5 s
+                                     int(gap_ext), m.ctypes.data_as(C.POINTER(C.c_int)), int(m.shape[0]), int(mode_code),
+                                     int(threads), None)
+        # bounded samples: a prefix of the shard (it is sorted longest first) holding ~5e9 cells for the one-thread
+        # run (the reference's own methodology, aligner_comparison.md:11) and at most 5e10 cells for all threads
+        csum = float(len(q)) * o[1:].astype(np.float64)
+        n1 = int(min(n_all, np.searchsorted(csum, 5e9) + 1))
+        n_mt = int(min(n_all, np.searchsorted(csum, 5e10) + 1))
         run(min(n_all, 2000), 1)  # warm-up
         t1 = min(run(n1, 1) for _ in range(2))
         one = float(len(q)) * float(o[n1]) / t1 / 1e9
         nt = min(cores, 256)
-        tall = min(run(n_all, nt) for _ in range(3))
-        allc = float(len(q)) * float(o[n_all]) / tall / 1e9
+        tall = min(run(n_mt, nt) for _ in range(3))
+        allc = float(len(q)) * float(o[n_mt]) / tall / 1e9
         return {"value": round(allc, 2), "unit": "GCUPS", "cores": nt, "kind": "reference",
-                "sample": f"whole workload ({n_all} sequences) on {nt} threads, best of 3; 1 thread on the first {n1}: "
-                          f"{one:.2f} GCUPS", "one_thread_value": round(one, 2)}
+                "sample": f"the {n_mt} longest of {n_all} sequences on {nt} threads, best of 3; 1 thread on the "
+                          f"{n1} longest: {one:.2f} GCUPS", "one_thread_value": round(one, 2)}
     orc = oracle_lib.Oracle()
     n = min(n_all, 400)
     seqs = [res[offs[i]:offs[i + 1]] for i in range(n)]
     t0 = time.perf_counter()
-    orc.search(query, seqs, gap_open, gap_ext, matrix, 0, 3)
+    orc.search(query, seqs, gap_open, gap_ext, matrix, 0, mode_code)
     t1 = time.perf_counter() - t0
     return {"value": round(float(len(query)) * float(offs[n]) / t1 / 1e9, 4), "unit": "GCUPS", "cores": 1, "kind": "port",
             "sample": f"scalar oracle on the first {n} sequences"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--seqs", type=int, default=100000, help="database sequences per GPU")
-    ap.add_argument("--qlen", type=int, default=300)
-    ap.add_argument("--gap-open", type=int, default=11)
-    ap.add_argument("--gap-ext", type=int, default=1)
-    ap.add_argument("--mode", default="SW")
-    ap.add_argument("--search-type", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--query-fasta", default=None, help="use the first record of this FASTA file as the query "
-                    "(e.g. tests/golden/data/query_P18080.fasta for BASELINE.json configs[3])")
-    args = ap.parse_args()
+def e2e_call(query, res_host, offs, matrix, gap_open, gap_ext, search_type, mode_code, want_scores):
+    """The call the reference's own timer brackets (opal_aligner.cpp:157-165): opalSearchDatabase with N separate
+    host pointers in and N result structs out, steady clock, best of 5. Returns (ms, scores_match)."""
+    from opal_amd import _lib
+    from opal_amd.api import OpalSearchResult
+    L = _lib.lib()
+    n = len(offs) - 1
+    q = np.ascontiguousarray(query, np.uint8)
+    m = np.ascontiguousarray(matrix, np.int32)
+    lens = np.ascontiguousarray(np.diff(offs), np.int32)
+    base = res_host.ctypes.data
+    ptrs = np.ascontiguousarray(base + np.asarray(offs[:-1], dtype=np.uint64), dtype=np.uint64)
+    arr = (OpalSearchResult * n)()
+    words = np.frombuffer(arr, dtype=np.int32).reshape(n, 10)
+    rptrs = np.ascontiguousarray(C.addressof(arr) + 40 * np.arange(n, dtype=np.uint64), dtype=np.uint64)
+    best = None
+    for _ in range(6):
+        words[:, 0] = 0            # scoreSet = 0 (opalInitSearchResult)
+        words[:, 2:6] = -1
+        t0 = time.perf_counter()
+        rc = L.opalSearchDatabase(q.ctypes.data_as(C.POINTER(C.c_ubyte)), len(q), C.c_void_p(ptrs.ctypes.data), n,
+                                  lens.ctypes.data_as(C.POINTER(C.c_int)), int(gap_open), int(gap_ext),
+                                  m.ctypes.data_as(C.POINTER(C.c_int)), int(m.shape[0]), C.c_void_p(rptrs.ctypes.data),
+                                  int(search_type), int(mode_code), 1)
+        dt = (time.perf_counter() - t0) * 1e3
+        if rc != 0:
+            raise SystemExit(f"opalSearchDatabase failed rc={rc}")
+        best = dt if best is None else min(best, dt)
+    ok = bool((words[:, 0] == 1).all() and (words[:, 1] == want_scores).all())
+    return best, ok
 
-    import torch
-    import torch.distributed as dist
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))  # nothing GPU-related has been imported or touched in this process
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the measured path)")
     # Test hooks for the multi-rank path on a single-GPU box (never used by the driver): all ranks on device 0,
@@ -103,9 +206,10 @@ def main():
     if os.environ.get("BENCH_SHARE_GPU") == "1":
         local = 0
     torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     if world > 1:
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
 
@@ -113,8 +217,8 @@ def main():
     from opal_amd.api import MODES, PreparedDb
     from opal_amd.score_matrix import blosum50
 
-    n = args.seqs
-    res, offs, lens = shard.synthetic_shard(n, rank, seed=42)  # this rank's shard of the same database
+    strong = args.total_seqs is not None
+    total = args.total_seqs if strong else args.seqs * world
     if args.query_fasta:
         from opal_amd.fasta import read_fasta
         query = read_fasta(args.query_fasta, blosum50()[0])[0]
@@ -123,23 +227,46 @@ def main():
         query = synth.query(args.qlen, seed=7)
     matrix = blosum50()[1]
     mode = MODES[args.mode]
-    pdb = PreparedDb(res, offs)
-    cells = float(args.qlen) * float(offs[-1])
 
-    dev = torch.device("cuda", local)
-    score = torch.zeros(n, dtype=torch.int32, device=dev)
-    endq = torch.zeros(n, dtype=torch.int32, device=dev) if args.search_type else None
-    endt = torch.zeros(n, dtype=torch.int32, device=dev) if args.search_type else None
+    # ---- this rank's shard of the one global database (dealt by residue count, opal_amd/shard.py)
+    all_lens = synth.lengths(42, 0, total)
+    owned_lists = shard.deal(all_lens, world)
+    owned = owned_lists[rank]
+    n = len(owned)
+    npad = max(len(o) for o in owned_lists)
+    lens = all_lens[owned]
+    d_res, offs = synth.residues_device(owned, lens, 42, dev)
+    torch.cuda.synchronize()
+    pdb = PreparedDb(None, offs, device_ptr=d_res.data_ptr())
+    cells = float(args.qlen) * float(offs[-1])
+    total_cells = float(args.qlen) * float(all_lens.astype(np.int64).sum())
+
+    want_end = args.search_type != 0
+    nres = 3 if want_end else 1
+    out = torch.zeros(nres * npad, dtype=torch.int32, device=dev)  # {score, endQ, endT} blocks, padded to the largest shard
+    score, endq, endt = out[:npad], (out[npad:2 * npad] if want_end else None), (out[2 * npad:] if want_end else None)
+    owned_dev = [torch.as_tensor(o, device=dev) for o in owned_lists] if rank == 0 else None
+    glob = torch.zeros(nres * total, dtype=torch.int32, device=dev) if rank == 0 else None
     kernel_ms = []
 
     def step():
         rc, kms = pdb.search_device(query, args.gap_open, args.gap_ext, matrix, args.search_type, mode, score.data_ptr(),
-                                    endq.data_ptr() if endq is not None else 0, endt.data_ptr() if endt is not None else 0)
+                                    endq.data_ptr() if want_end else 0, endt.data_ptr() if want_end else 0)
         if rc != 0:
             raise SystemExit(f"search failed rc={rc}")
         kernel_ms.append(kms)
-        # the path's only exchange: per-sequence scores to rank 0 (one gather)
-        shard.gather_results(score if backend == "nccl" else score.cpu(), world, rank)
+        if world > 1:
+            # the path's only exchange: ONE gather of the per-sequence result block to rank 0, which puts the
+            # blocks back into database order with the deal's permutation
+            got = shard.gather_results(out if backend == "nccl" else out.cpu(), world, rank)
+            if rank == 0:
+                for r, blk in enumerate(got):
+                    blk = blk.to(dev, non_blocking=True)
+                    for k in range(nres):
+                        glob[k * total:(k + 1) * total][owned_dev[r]] = blk[k * npad:k * npad + len(owned_lists[r])]
+        elif rank == 0:
+            for k in range(nres):
+                glob[k * total:(k + 1) * total][owned_dev[0]] = out[k * npad:k * npad + n]
 
     def fence():
         if world > 1:
@@ -157,48 +284,85 @@ def main():
     dt = time.perf_counter() - t0
     rdev = dev if backend == "nccl" else torch.device("cpu")
     tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
-    tcells = torch.tensor([cells], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tcells, op=dist.ReduceOp.SUM)
     dt = float(tmax.item())
-    total_cells = float(tcells.item())
 
+    status = 0
     if rank == 0:
         gcups = total_cells * args.steps / dt / 1e9
         kms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
-        # roofline of the dominant kernel (the width-16 DP kernel), per launch: algorithmic bytes =
-        # 4*w bytes per cell (read H,E + write H,E of a column-streaming design), w = 2
-        alg_bytes = cells * 8.0
-        achieved = alg_bytes / (kms * 1e-3) / 1e9
         kernel_gcups = cells / (kms * 1e-3) / 1e9
-        traffic = None
-        try:  # HBM bytes per step measured offline with rocprofv3 PMC passes (scripts/prof_hbm.sh), same workload only
-            if (args.qlen, n, args.mode, args.search_type, args.gap_open) == (300, 100000, "SW", 0, 11):
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as fh:
+        gscore = glob[:total].cpu().numpy()
+
+        # ---- verification: a fixed sample of the database against the CPU oracle (checker only, after the timed region)
+        import oracle_lib
+        oracle_lib.build_oracle()
+        rng = np.random.RandomState(1)
+        nsamp = min(total, 300 if args.qlen <= 600 else 120)
+        pick = np.sort(rng.choice(total, nsamp, replace=False))
+        sres, soffs, slens = synth.database_subset(pick, 42, lens=all_lens[pick])
+        sdb = [sres[soffs[i]:soffs[i + 1]] for i in range(nsamp)]
+        orc_rc, os_, oq, ot = oracle_lib.Oracle().search(query, sdb, args.gap_open, args.gap_ext, matrix, args.search_type, mode)
+        verified = bool(orc_rc == 0 and (gscore[pick] == os_).all())
+        if want_end:
+            verified = verified and bool((glob[total:2 * total].cpu().numpy()[pick] == oq).all() and
+                                         (glob[2 * total:].cpu().numpy()[pick] == ot).all())
+
+        instr_per_cell = 9.0 if args.mode == "SW" else 6.0
+        peak = valu_peak_gcups(instr_per_cell)
+        # compulsory HBM bytes of THIS design per step: 2-byte tokens (one per pair column), 24 B of pair metadata
+        # per pair, 4 B per result value. The 4*w B/cell of a column-streaming design is kept only as a
+        # labelled comparison: this kernel keeps the DP column in VGPRs and never moves those bytes.
+        sl = np.sort(lens)[::-1].astype(np.int64)
+        alg_bytes = float(2 * sl[0::2].sum() + 24 * ((n + 1) // 2) + 4 * nres * n)
+        traffic, traffic_src = None, None
+        try:  # HBM bytes per step measured offline with rocprofv3 PMC passes (scripts/prof_hbm.sh) on this same workload
+            if (args.workload, args.qlen, args.seqs, args.mode, args.search_type, args.gap_open, world) == ("c2", 300, 100000, "SW", 0, 11, 1):
+                with open(os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")) as fh:
                     traffic = json.load(fh)["hbm_bytes_per_step"]
+                    traffic_src = "offline: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r02_pmc_hbm.json)"
         except (OSError, KeyError, ValueError):
             traffic = None
-        out = {
+        hbm = {"peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes": alg_bytes,
+               "algorithmic_gbs": round(alg_bytes / (kms * 1e-3) / 1e9, 2),
+               "achieved": round(traffic / (kms * 1e-3) / 1e9, 2) if traffic else None,
+               "frac": round(traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
+               "column_streaming_model_bytes": cells * 8.0,
+               "note": "the DP column lives in VGPRs: HBM carries residue tokens in and results out only"}
+        res_line = {
             "metric": "GCUPS (DP cell updates/s), SW score-only, 1 query vs synthetic protein DB",
             "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "i16", "data": "synthetic",
-            "config": {"workload": f"{args.qlen}-aa query (seed 7) vs {n} synthetic protein seqs per GPU (seed 42, "
-                                   f"mean {float(offs[-1]) / n:.0f} aa), {args.mode} "
-                                   f"{'score-only' if not args.search_type else 'score+end'}, BLOSUM50, gaps "
-                                   f"{args.gap_open}/{args.gap_ext}, plain 16-bit first rung",
-                       "cells_per_step_per_gpu": cells, "parallelism": f"db-shard x{world}"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch group (PMC, profiles/r01_pmc_hbm.json)", "algorithmic_bytes": alg_bytes,
-                         "note": "algorithmic bytes = 8 B/cell of a column-streaming int16 design; this kernel keeps "
-                                 "the column in VGPRs, so it is VALU-issue bound, see valu_roofline"},
-            "valu_roofline": {"bound": "valu-issue", "kernel_gcups": round(kernel_gcups, 1), "kernel_ms": round(kms, 4),
-                              "peak_gcups": round(VALU_PEAK_GCUPS, 0), "frac": round(kernel_gcups / VALU_PEAK_GCUPS, 4),
-                              "model": "1024 SIMDs x 2.4 GHz x 64 lanes / (9 full-rate 16-bit instr x 2 clk per cell)"},
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "i16", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {args.qlen}-aa query ({'P18080' if args.query_fasta else 'seed 7'}) vs "
+                                   f"{total} synthetic protein seqs in total (seed 42, mean {float(all_lens.mean()):.0f} aa, "
+                                   f"{'fixed total' if strong else str(args.seqs) + ' per GPU'}), {args.mode} "
+                                   f"{'score-only' if not want_end else 'score+end'}, BLOSUM50, gaps "
+                                   f"{args.gap_open}/{args.gap_ext}, 16-bit first rung, 32-bit re-run",
+                       "cells_per_step": total_cells, "cells_per_step_rank0": cells,
+                       "parallelism": f"db-shard x{world} (64-seq groups dealt by residue count), 1 gather"},
+            "verified": verified,
+            "verify": {"sample": f"{nsamp} sequences (fixed seed) vs oracle/opal_oracle.c", "score_crc32": zlib.crc32(gscore.tobytes())},
+            "roofline": {"bound": "valu-issue", "achieved": round(kernel_gcups, 1), "peak": round(peak, 0), "unit": "GCUPS",
+                         "frac": round(kernel_gcups / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel_ms": round(kms, 4),
+                         "model": f"1024 SIMDs x 2.4 GHz x 64 lanes / ({instr_per_cell:.0f} full-rate 16-bit instr x 2 clk per cell); "
+                                  "kernel_ms = HIP events around all DP launches of a step on the launch stream (rank 0)",
+                         "hbm": hbm},
         }
-        if world == 1 and (args.mode, args.search_type) == ("SW", 0):
+        if not verified:
+            status = 3
+        if world == 1 and not args.no_e2e and total <= 1000000:
+            res_host = d_res.cpu().numpy()
+            e2e_ms, e2e_ok = e2e_call(query, res_host, offs, matrix, args.gap_open, args.gap_ext, args.search_type, mode,
+                                      gscore[owned])
+            res_line["e2e"] = {"ms": round(e2e_ms, 3), "gcups": round(cells / (e2e_ms * 1e-3) / 1e9, 1), "scores_match": e2e_ok,
+                               "what": "opalSearchDatabase (host pointers in, result structs out), steady clock, best of 6 calls"}
+            if not e2e_ok:
+                res_line["verified"] = False
+                status = 3
+        if world == 1 and args.workload == "c2" and (args.mode, args.search_type) == ("SW", 0):
             # SURVEY.md 8d asks for both gap settings of the workload; the other one is timed here, outside the
             # K timed steps (11/1: nothing exceeds the 8-bit range of the reference; 3/1: the reference's CLI default)
             other = 3 if args.gap_open == 11 else 11
@@ -206,13 +370,15 @@ def main():
             for _ in range(10):
                 rc, k = pdb.search_device(query, other, args.gap_ext, matrix, 0, mode, score.data_ptr())
                 ks.append(k)
-            out["also"] = {f"kernel_gcups_gaps_{other}_{args.gap_ext}": round(cells / (float(np.median(ks)) * 1e-3) / 1e9, 1)}
+            res_line["also"] = {f"kernel_gcups_gaps_{other}_{args.gap_ext}": round(cells / (float(np.median(ks)) * 1e-3) / 1e9, 1)}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(query, res, offs, lens, matrix, args.gap_open, args.gap_ext)
-        print(json.dumps(out))
+            res_host = d_res.cpu().numpy()
+            res_line["cpu_baseline"] = cpu_baseline(query, res_host, offs, matrix, args.gap_open, args.gap_ext, mode)
+        print(json.dumps(res_line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    sys.exit(status)
 
 
 if __name__ == "__main__":

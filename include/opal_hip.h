@@ -83,6 +83,12 @@ typedef struct OpalHipLaunch {
        (rows_per_lane + steps) * gap_ext; the caller guarantees they stay below 32767) */
     int skew;
     int* scratch;         /* [2 * number of sequences] carried across chunks (OV) */
+    /* waves per workgroup, 1..8 (0: default 4). The scheduler picks it from the kernel's register count
+       and the LDS size of the query profile so that every SIMD holds an even number (>= 2) of waves. */
+    int waves_per_block;
+    /* request at least this much LDS per workgroup (0: the query profile's own size): the scheduler pads the
+       request to keep an odd number of workgroups from sharing a CU */
+    int lds_bytes_min;
 } OpalHipLaunch;
 
 #define OPAL_HIP_MAX_ROWS 40
@@ -90,11 +96,20 @@ typedef struct OpalHipLaunch {
 int opal_hip_device_count(void);
 /* Select `device` for the calling thread. 0 on success. */
 int opal_hip_set_device(int device);
+int opal_hip_get_device(void);             /* the calling thread's current device, -1 on error */
 void* opal_hip_malloc(size_t bytes);
 void opal_hip_free(void* p);
+void* opal_hip_host_malloc(size_t bytes);  /* pinned host memory (staging of residues and results) */
+void opal_hip_host_free(void* p);
 int opal_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
 int opal_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
+int opal_hip_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+/* Device-to-device across GPUs (xGMI peer DMA): the gather step of the in-library multi-GPU search. */
+int opal_hip_memcpy_peer(void* dst, int dst_device, const void* src, int src_device, size_t bytes, void* stream);
 int opal_hip_memset(void* dst, int value, size_t bytes, void* stream);
+int opal_hip_memset32(void* dst, int value, size_t count, void* stream);   /* `count` 32-bit words */
+/* score[quads[4i]] = quads[4i+1], end_query[..] = quads[4i+2], end_target[..] = quads[4i+3]; `quads` on the device. */
+int opal_hip_scatter_results(const int* quads, int count, int* score, int* end_query, int* end_target, void* stream);
 int opal_hip_stream_sync(void* stream);
 void* opal_hip_stream_create(void);       /* non-blocking stream: ordered only through events */
 void opal_hip_stream_destroy(void* stream);
@@ -108,6 +123,9 @@ int opal_hip_launch(const OpalHipLaunch* args);
 /* Smallest rows_per_lane >= min_rows for which this kernel variant is instantiated (0: none).
    want_end bit0: the SW end-location pass; bit1: the multi-chunk (chunk_flags != 0) variants. */
 int opal_hip_rows_supported(int width, int mode, int want_end, int min_rows);
+/* VGPRs per lane of the kernel `args` selects (width, mode, want_end, detect_wrap, chunk_flags, skew,
+   rows_per_lane are read), 0 if unknown. */
+int opal_hip_kernel_vgprs(const OpalHipLaunch* args);
 /* Bytes of LDS the launch would need (query profile), for the scheduler's shape choice. */
 size_t opal_hip_lds_bytes(int width, int lanes_per_seq, int rows_per_lane, int alphabet_length);
 const char* opal_hip_last_error(void);
@@ -126,6 +144,12 @@ typedef struct OpalxDb OpalxDb; /* opaque: packed database resident in device me
 OpalxDb* opalx_db_create(unsigned char* const db[], int db_length, const int db_seq_lengths[]);
 /* Same, from one contiguous residue buffer: sequence j is residues[offsets[j] .. offsets[j+1]). */
 OpalxDb* opalx_db_create_flat(const unsigned char* residues, const int64_t* offsets, int db_length);
+/* Same with the residue buffer already in DEVICE memory of the current device (offsets stay on the host);
+   the buffer is only read during the call. */
+OpalxDb* opalx_db_create_flat_device(const unsigned char* d_residues, const int64_t* offsets, int db_length);
+/* opalSearchDatabase keeps its device buffers, pinned staging memory and streams in cached contexts between
+   calls; this frees them (optional: call it when no search is running, e.g. before unloading the library). */
+void opalx_release_cached(void);
 void opalx_db_destroy(OpalxDb* db);
 int opalx_db_num_sequences(const OpalxDb* db);
 int64_t opalx_db_num_residues(const OpalxDb* db);

@@ -33,6 +33,10 @@ def lib():
         i32p, u8p = C.POINTER(C.c_int), C.POINTER(C.c_ubyte)
         L.opalx_db_create_flat.restype = C.c_void_p
         L.opalx_db_create_flat.argtypes = [u8p, C.POINTER(C.c_int64), C.c_int]
+        L.opalx_db_create_flat_device.restype = C.c_void_p
+        L.opalx_db_create_flat_device.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int]
+        L.opalx_release_cached.restype = None
+        L.opalx_release_cached.argtypes = []
         L.opalx_db_destroy.restype = None
         L.opalx_db_destroy.argtypes = [C.c_void_p]
         L.opalx_db_num_sequences.restype = C.c_int

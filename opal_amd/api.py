@@ -90,13 +90,19 @@ def result_fields(results, *names):
 class PreparedDb:
     """A database packed once and kept in device memory (opalx_db_* in include/opal_hip.h)."""
 
-    def __init__(self, residues, offsets):
+    def __init__(self, residues, offsets, device_ptr=None):
+        """`residues`: uint8 host array (flat); or, with `device_ptr` (an int: address of the same flat buffer
+        already in device memory, e.g. a torch uint8 tensor's data_ptr()), nothing is uploaded."""
         L = _lib.lib()
-        self._res = _u8(residues)
         self._off = np.ascontiguousarray(offsets, dtype=np.int64)
         self.num_sequences = len(self._off) - 1
-        self._h = L.opalx_db_create_flat(self._res.ctypes.data_as(C.POINTER(C.c_ubyte)),
-                                         self._off.ctypes.data_as(C.POINTER(C.c_int64)), self.num_sequences)
+        if device_ptr is not None:
+            self._h = L.opalx_db_create_flat_device(C.c_void_p(device_ptr), self._off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                    self.num_sequences)
+        else:
+            self._res = _u8(residues)
+            self._h = L.opalx_db_create_flat(self._res.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                                             self._off.ctypes.data_as(C.POINTER(C.c_int64)), self.num_sequences)
         if not self._h:
             raise RuntimeError("opalx_db_create_flat failed: " + (L.opal_hip_last_error() or b"").decode())
         self.num_residues = int(L.opalx_db_num_residues(self._h))

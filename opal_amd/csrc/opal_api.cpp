@@ -11,21 +11,75 @@
 //
 // There is NO CPU fallback: without a usable gfx950 device every search returns
 // OPAL_ERR_NO_SIMD_SUPPORT and says why on stderr.
+//
+// What one opalSearchDatabase call costs on an MI355X is host work, not DP (the kernels need under two
+// milliseconds for 10^10 cells), so the boundary is built for that:
+//   * device buffers, pinned staging memory, streams and events live in cached CONTEXTS that calls
+//     borrow and give back (no hipMalloc/hipFree, stream or event creation in the steady state);
+//   * the N separate host allocations are gathered into pinned memory by a persistent thread pool,
+//     each chunk going to the device as soon as it is complete; the interleaving into tokens is a kernel;
+//   * results come back through pinned memory and are scattered into the N result structs by the pool;
+//   * with OPAL_HIP_DEVICES set, the call shards the database over several GPUs (sequences dealt in
+//     64-sequence groups balancing the residue count), one host thread per GPU.
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <functional>
+#include <map>
 #include <memory>
+#include <mutex>
+#include <new>
+#include <string>
 #include <thread>
 #include <vector>
 
+#include "host_pool.hpp"
 #include "opal.h"
 #include "opal_hip.h"
 
 namespace {
+
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static bool debug_on() {
+    static const int on = [] { const char* e = getenv("OPAL_HIP_DEBUG"); return (e && *e && *e != '0') ? 1 : 0; }();
+    return on != 0;
+}
+
+// ------------------------------------------------------------------------------------ buffers
+// Device / pinned-host buffers that only ever grow: a cached context keeps them across calls.
+template <typename T> struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;  // elements
+    bool ensure(size_t n, double slack = 1.0) {
+        if (n <= cap && p) return true;
+        opal_hip_free(p);
+        const size_t want = std::max<size_t>((size_t)((double)n * slack), 1);
+        p = (T*)opal_hip_malloc(want * sizeof(T));
+        cap = p ? want : 0;
+        return p != nullptr;
+    }
+    void release() { opal_hip_free(p); p = nullptr; cap = 0; }
+};
+template <typename T> struct PinBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t n, double slack = 1.0) {
+        if (n <= cap && p) return true;
+        opal_hip_host_free(p);
+        const size_t want = std::max<size_t>((size_t)((double)n * slack), 1);
+        p = (T*)opal_hip_host_malloc(want * sizeof(T));
+        cap = p ? want : 0;
+        return p != nullptr;
+    }
+    void release() { opal_hip_host_free(p); p = nullptr; cap = 0; }
+};
 
 // ------------------------------------------------------------------------------------ packed db
 // Sequences sorted by length (descending), paired up neighbour with neighbour. A pair is the unit a
@@ -38,27 +92,12 @@ struct HostPack {
     std::vector<int> pairLen;       // [2P]
     std::vector<int> pairSeq;       // [2P] caller index, -1 = absent
     std::vector<uint64_t> rawOff;   // [2P] where each sequence's residues start in the raw buffer
-    std::vector<int> emptySeqs;     // caller indices of zero-length sequences (handled on the host)
-    std::unique_ptr<unsigned char[]> gathered;  // raw residues in pair order (pointer-array inputs only)
-    const unsigned char* raw = nullptr;   // the buffer to upload: `gathered` or the caller's flat buffer
+    std::vector<int> emptySeqs;     // caller indices of zero-length sequences (answered on the host)
     uint64_t rawBytes = 0;
     uint64_t numTokens = 0;
     int64_t residues = 0;
     int numSeqs = 0;
 };
-
-static double now_ms() {
-    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-static bool debug_on() {
-    const char* e = getenv("OPAL_HIP_DEBUG");
-    return e && *e && *e != '0';
-}
-static unsigned host_threads() {
-    unsigned nt = std::thread::hardware_concurrency();
-    if (const char* e = getenv("OPAL_HOST_THREADS")) nt = (unsigned)atoi(e);
-    return std::max(1u, std::min(nt, 32u));
-}
 
 // Order and pairing (no residue is touched): stable sort by length, longest first.
 static void pack_order(int n, const int* lens, HostPack& out) {
@@ -100,64 +139,47 @@ static void pack_order(int n, const int* lens, HostPack& out) {
     out.numTokens = total;
 }
 
-// Residues given as separate host allocations: gather them (pair order) into one buffer, on host threads.
-template <typename GetSeq>
-static void gather_residues(GetSeq getSeq, HostPack& out) {
-    const size_t n2 = out.pairSeq.size();
-    out.rawOff.resize(n2);
-    uint64_t total = 0;
-    for (size_t i = 0; i < n2; i++) { out.rawOff[i] = total; total += (uint64_t)out.pairLen[i]; }
-    out.gathered.reset(new unsigned char[total + 16]);  // uninitialised on purpose: every byte below `total` is copied
-    auto copy = [&](size_t i0, size_t i1) {
-        for (size_t i = i0; i < i1; i++)
-            if (out.pairSeq[i] >= 0) memcpy(out.gathered.get() + out.rawOff[i], getSeq(out.pairSeq[i]), (size_t)out.pairLen[i]);
-    };
-    const unsigned nt = total > (1u << 20) ? host_threads() : 1u;
-    if (nt <= 1) copy(0, n2);
-    else {
-        std::vector<std::thread> pool;
-        size_t i0 = 0;
-        for (unsigned t = 0; t < nt; t++) {
-            const uint64_t goal = total * (t + 1) / nt;
-            size_t i1 = i0;
-            while (i1 < n2 && (t + 1 == nt || out.rawOff[i1] < goal)) i1++;
-            pool.emplace_back(copy, i0, i1);
-            i0 = i1;
-        }
-        for (auto& th : pool) th.join();
-    }
-    out.raw = out.gathered.get();
-    out.rawBytes = total;
-}
-
 }  // namespace
 
 struct OpalxDb {
+    int device = 0;
+    bool cached = false;  // a context of the opalSearchDatabase cache (returned to the free list, not destroyed)
     int numSeqs = 0;
     int numPairs = 0;
     int64_t residues = 0;
+    size_t numTokens = 0;
     // host copies the scheduler needs
     std::vector<int> pairLen;  // [2P], pairs sorted by length of A descending
     std::vector<int> pairSeq;
     std::vector<int> emptySeqs;
-    // device
-    uint16_t* dTokens = nullptr;
-    uint64_t* dPairOff = nullptr;
-    int* dPairLen = nullptr;
-    int* dPairSeq = nullptr;
-    int* dOvfCount = nullptr;  // [2] counters: width-16 overflow list length, width-32 wrap count
-    int* dOvfItems = nullptr;  // [2P]
-    size_t numTokens = 0;
-    void* dBoundary = nullptr; // 16 B per token: chunk-boundary rows of long queries (allocated on first use)
-    int* dScratch = nullptr;   // [2N] per-sequence values carried across query chunks
-    int* dResults = nullptr;   // [3N] device staging of host-array searches (opalx_search_host)
-    unsigned char* dQuery = nullptr;
-    int* dMatrix = nullptr;
-    size_t queryCap = 0, matrixCap = 0;
-    // side streams for launches that may overlap (created on first use; blocking streams: they order
-    // themselves against the null stream, which carries the copies, memsets and timing events)
+    // device: the packed database
+    DevBuf<uint16_t> tokens;
+    DevBuf<uint64_t> pairOff;
+    DevBuf<int> dPairLen, dPairSeq;
+    DevBuf<int> ovfCount;  // [2] counters: narrow-rung overflow list length, width-32 wrap count
+    DevBuf<int> ovfItems;  // [2P]
+    // device: per-search scratch
+    DevBuf<unsigned char> boundary;  // 16 B per token: chunk-boundary rows of long queries (allocated on first use)
+    DevBuf<int> scratch;             // [2N] per-sequence values carried across query chunks
+    DevBuf<int> results;             // [3N] device staging of host-array searches
+    DevBuf<int> quads;               // degenerate results on their way to the scatter kernel
+    DevBuf<unsigned char> query;
+    DevBuf<int> matrix;
+    // staging used while (re)filling the database
+    DevBuf<unsigned char> raw;
+    DevBuf<uint64_t> rawOff;
+    PinBuf<unsigned char> hRaw;
+    PinBuf<int> hResults;
+    // Streams: everything of one search runs on `main` (a non-blocking stream: no implicit ordering
+    // against the legacy null stream or against other contexts); long-sequence classes run on up to three
+    // side streams, forked from and joined back into `main` with events.
+    void* mainStream = nullptr;
     void* streams[3] = {nullptr, nullptr, nullptr};
-    void* events[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* events[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // 0 fork, 1-3 joins, 4-5 timing
+    void* main() {
+        if (!mainStream) mainStream = opal_hip_stream_create();
+        return mainStream;
+    }
     void* stream(int i) {
         if (!streams[i]) streams[i] = opal_hip_stream_create();
         return streams[i];
@@ -165,6 +187,11 @@ struct OpalxDb {
     void* event(int i) {
         if (!events[i]) events[i] = opal_hip_event_create();
         return events[i];
+    }
+    // Wait for everything this handle may have in flight (used on error paths before buffers are reused).
+    void quiesce() {
+        for (void* st : streams) if (st) opal_hip_stream_sync(st);
+        if (mainStream) opal_hip_stream_sync(mainStream);
     }
 };
 
@@ -189,42 +216,131 @@ static bool device_ok() {
     return checked > 0;
 }
 
-static OpalxDb* upload(HostPack& hp) {
-    OpalxDb* db = new OpalxDb;
-    db->numSeqs = hp.numSeqs;
-    db->numPairs = (int)hp.pairOff.size();
-    db->residues = hp.residues;
-    db->pairLen = hp.pairLen;
-    db->pairSeq = hp.pairSeq;
-    db->emptySeqs = hp.emptySeqs;
-    db->numTokens = hp.numTokens + 8;
-    const size_t P = hp.pairOff.size();
-    db->dTokens = (uint16_t*)opal_hip_malloc(db->numTokens * sizeof(uint16_t));
-    db->dPairOff = (uint64_t*)opal_hip_malloc(P * sizeof(uint64_t));
-    db->dPairLen = (int*)opal_hip_malloc(2 * P * sizeof(int));
-    db->dPairSeq = (int*)opal_hip_malloc(2 * P * sizeof(int));
-    db->dOvfCount = (int*)opal_hip_malloc(2 * sizeof(int));
-    db->dOvfItems = (int*)opal_hip_malloc(2 * P * sizeof(int));
-    unsigned char* dRaw = (unsigned char*)opal_hip_malloc(hp.rawBytes + 16);
-    uint64_t* dRawOff = (uint64_t*)opal_hip_malloc(2 * P * sizeof(uint64_t));
-    bool ok = db->dTokens && db->dPairOff && db->dPairLen && db->dPairSeq && db->dOvfCount && db->dOvfItems && dRaw && dRawOff;
-    if (ok && P) {
-        ok = !opal_hip_memcpy_h2d(dRaw, hp.raw, hp.rawBytes, nullptr) &&
-             !opal_hip_memcpy_h2d(dRawOff, hp.rawOff.data(), 2 * P * sizeof(uint64_t), nullptr) &&
-             !opal_hip_memcpy_h2d(db->dPairOff, hp.pairOff.data(), P * sizeof(uint64_t), nullptr) &&
-             !opal_hip_memcpy_h2d(db->dPairLen, hp.pairLen.data(), 2 * P * sizeof(int), nullptr) &&
-             !opal_hip_memcpy_h2d(db->dPairSeq, hp.pairSeq.data(), 2 * P * sizeof(int), nullptr) &&
-             !opal_hip_pack_tokens(dRaw, dRawOff, db->dPairOff, db->dPairLen, (int)P, db->dTokens, db->numTokens, nullptr) &&
-             !opal_hip_stream_sync(nullptr);
-    }
-    opal_hip_free(dRaw);
-    opal_hip_free(dRawOff);
-    if (!ok) { opalx_db_destroy(db); return nullptr; }
-    return db;
+static void db_release(OpalxDb* db) {
+    db->tokens.release(); db->pairOff.release(); db->dPairLen.release(); db->dPairSeq.release();
+    db->ovfCount.release(); db->ovfItems.release(); db->boundary.release(); db->scratch.release();
+    db->results.release(); db->quads.release(); db->query.release(); db->matrix.release();
+    db->raw.release(); db->rawOff.release(); db->hRaw.release(); db->hResults.release();
+    for (void*& st : db->streams) { opal_hip_stream_destroy(st); st = nullptr; }
+    opal_hip_stream_destroy(db->mainStream); db->mainStream = nullptr;
+    for (void*& ev : db->events) { opal_hip_event_destroy(ev); ev = nullptr; }
 }
 
+enum RawKind { RAW_POINTERS, RAW_HOST_FLAT, RAW_DEVICE_FLAT };
+
+/*
+ * (Re)fill `db` with the packed form of `hp`. Residues come from
+ *   RAW_POINTERS     getSeq(i): N separate host allocations -> gathered into pinned memory by the thread pool,
+ *                    every ~2 MB chunk uploaded as soon as it is complete;
+ *   RAW_HOST_FLAT    one contiguous host buffer (uploaded as it is, the device packer reads at hp.rawOff);
+ *   RAW_DEVICE_FLAT  the same already in device memory (nothing is copied).
+ * Buffers of a cached context are reused when large enough.
+ */
+static bool db_fill(OpalxDb* db, HostPack& hp, RawKind kind, const std::function<const unsigned char*(int)>& getSeq,
+                    const unsigned char* flat) {
+    const size_t P = hp.pairOff.size();
+    db->device = opal_hip_get_device();
+    db->numSeqs = hp.numSeqs;
+    db->numPairs = (int)P;
+    db->residues = hp.residues;
+    db->pairLen.swap(hp.pairLen);
+    db->pairSeq.swap(hp.pairSeq);
+    db->emptySeqs.swap(hp.emptySeqs);
+    db->numTokens = hp.numTokens + 8;
+    const double slack = db->cached ? 1.15 : 1.0;
+    void* st = db->main();
+    bool ok = st && db->tokens.ensure(db->numTokens, slack) && db->pairOff.ensure(P, slack) && db->dPairLen.ensure(2 * P, slack) &&
+              db->dPairSeq.ensure(2 * P, slack) && db->ovfCount.ensure(2) && db->ovfItems.ensure(2 * P, slack) &&
+              db->rawOff.ensure(2 * P, slack);
+    if (!ok) return false;
+    if (!P) return true;
+    const unsigned char* dRaw = nullptr;
+    if (kind == RAW_POINTERS) {
+        // rawOff = prefix sums of the lengths in pair order
+        hp.rawOff.resize(2 * P);
+        uint64_t total = 0;
+        for (size_t i = 0; i < 2 * P; i++) { hp.rawOff[i] = total; total += (uint64_t)db->pairLen[i]; }
+        hp.rawBytes = total;
+        if (!db->raw.ensure(total + 16, slack) || !db->hRaw.ensure(total + 16, slack)) return false;
+        // chunk boundaries: ~2 MB of residues each
+        const uint64_t chunkBytes = 2u << 20;
+        std::vector<size_t> cut{0};
+        for (size_t i = 0; i < 2 * P; i++)
+            if (hp.rawOff[i] - hp.rawOff[cut.back()] >= chunkBytes) cut.push_back(i);
+        cut.push_back(2 * P);
+        std::atomic<int> bad{0};
+        unsigned char* h = db->hRaw.p;
+        unsigned char* d = db->raw.p;
+        const std::vector<int>& seq = db->pairSeq;
+        const std::vector<int>& len = db->pairLen;
+        const int dev = db->device;
+        HostPool::get().parallel_for((int)cut.size() - 1, [&](int t) {
+            static thread_local int myDevice = -1;  // pool threads start on device 0: the copy below names a stream of `dev`
+            if (myDevice != dev) { opal_hip_set_device(dev); myDevice = dev; }
+            const size_t i0 = cut[(size_t)t], i1 = cut[(size_t)t + 1];
+            for (size_t i = i0; i < i1; i++)
+                if (seq[i] >= 0 && len[i] > 0) memcpy(h + hp.rawOff[i], getSeq(seq[i]), (size_t)len[i]);
+            const uint64_t b0 = hp.rawOff[i0], b1 = i1 < 2 * P ? hp.rawOff[i1] : total;
+            if (b1 > b0 && opal_hip_memcpy_h2d(d + b0, h + b0, b1 - b0, st)) bad.fetch_add(1);
+        });
+        if (bad.load()) return false;
+        dRaw = d;
+    } else if (kind == RAW_HOST_FLAT) {
+        if (!db->raw.ensure(hp.rawBytes + 16, slack)) return false;
+        if (hp.rawBytes && opal_hip_memcpy_h2d(db->raw.p, flat, hp.rawBytes, st)) return false;
+        dRaw = db->raw.p;
+    } else {
+        dRaw = flat;
+    }
+    ok = !opal_hip_memcpy_h2d(db->rawOff.p, hp.rawOff.data(), 2 * P * sizeof(uint64_t), st) &&
+         !opal_hip_memcpy_h2d(db->pairOff.p, hp.pairOff.data(), P * sizeof(uint64_t), st) &&
+         !opal_hip_memcpy_h2d(db->dPairLen.p, db->pairLen.data(), 2 * P * sizeof(int), st) &&
+         !opal_hip_memcpy_h2d(db->dPairSeq.p, db->pairSeq.data(), 2 * P * sizeof(int), st) &&
+         !opal_hip_pack_tokens(dRaw, db->rawOff.p, db->pairOff.p, db->dPairLen.p, (int)P, db->tokens.p, db->numTokens, st);
+    // hp's vectors are pageable host memory read by the async copies above: wait before they go away
+    if (opal_hip_stream_sync(st)) ok = false;
+    if (ok && !db->cached) { db->raw.release(); db->rawOff.release(); db->hRaw.release(); }
+    return ok;
+}
+
+// ------------------------------------------------------------------------------------ context cache
+// Contexts borrowed by opalSearchDatabase / opalSearchDatabaseCharSW: per device, a free list. A call takes one
+// (or creates it), fills it with its database, searches, and gives it back with all buffers kept. They are
+// never destroyed implicitly (opalx_release_cached() frees them on request): freeing device memory from a
+// static destructor races with the HIP runtime's own shutdown.
+struct ContextCache {
+    std::mutex m;
+    std::map<int, std::vector<OpalxDb*>> freeList;
+    OpalxDb* acquire(int device) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            auto& v = freeList[device];
+            if (!v.empty()) { OpalxDb* db = v.back(); v.pop_back(); return db; }
+        }
+        OpalxDb* db = new (std::nothrow) OpalxDb;
+        if (db) { db->cached = true; db->device = device; }
+        return db;
+    }
+    void give_back(OpalxDb* db) {
+        std::lock_guard<std::mutex> lk(m);
+        freeList[db->device].push_back(db);
+    }
+    static ContextCache& get() {
+        static ContextCache* c = new ContextCache;
+        return *c;
+    }
+};
+
+struct BorrowedContext {
+    OpalxDb* db;
+    explicit BorrowedContext(int device) : db(ContextCache::get().acquire(device)) {}
+    ~BorrowedContext() {
+        if (db) { db->quiesce(); ContextCache::get().give_back(db); }
+    }
+};
+
 // ------------------------------------------------------------------------------------ scheduling
-struct LaunchClass { int first, count, G, rows; };
+struct LaunchClass { int first, count, G, rows, wpb, ldsPad; };
 
 struct SearchCtx {
     OpalxDb* db;
@@ -241,6 +357,63 @@ static double step_clocks(int width, int rows) {
     return 4.3 * (11.0 * rows + 12.0);
 }
 
+// Registers per lane of a kernel variant, asked once per variant from the code object.
+static int kernel_vgprs(int width, int mode, int swEndPass, int multi, int skew, int rows) {
+    static std::mutex m;
+    static std::map<long long, int> cache;
+    const long long key = ((((long long)width * 8 + mode) * 4 + (swEndPass & 1) * 2 + (multi ? 1 : 0)) * 2 + (skew ? 1 : 0)) * 64 + rows;
+    std::lock_guard<std::mutex> lk(m);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    OpalHipLaunch a;
+    memset(&a, 0, sizeof a);
+    a.width = width; a.mode = mode; a.want_end = swEndPass & 1; a.chunk_flags = multi ? 1 : 0; a.skew = skew; a.rows_per_lane = rows;
+    const int v = opal_hip_kernel_vgprs(&a);
+    cache[key] = v;
+    return v;
+}
+
+/*
+ * Occupancy of one kernel shape (profiles/r01_ubench_rowblock.txt: one wave per SIMD issues at half
+ * rate, odd wave counts lose, two or four fill the pipe). Registers: 512 per lane per SIMD in granules
+ * of 8 (MI355X_MICROARCH.md, register files); LDS: 160 KiB per CU, the query profile is per workgroup;
+ * at most 32 waves per CU. Picks the waves per workgroup (and, when the register count alone would
+ * give an odd number of waves, an LDS request padded so that fewer workgroups fit) giving every SIMD
+ * an even number of waves. Returns waves per SIMD; `ldsPad` is the LDS bytes to request (0: the profile's own size).
+ */
+static int pick_occupancy(int vgprs, size_t ldsBytes, int* wpbOut, int* ldsPadOut) {
+    const int alloc = vgprs > 0 ? (vgprs + 7) / 8 * 8 : 128;
+    const int regWaves = std::max(1, std::min(8, 512 / alloc));
+    int bestW = 0, bestWpb = 4, bestPad = 0;
+    double bestScore = -1;
+    for (int wpb : {4, 8}) {
+        const int perSimdPerBlock = wpb / 4;
+        const int blocksByLds = (int)std::max<size_t>(1, (160 * 1024) / std::max<size_t>(ldsBytes, 1));
+        int blocks = std::min({blocksByLds, 32 / wpb, regWaves / perSimdPerBlock});
+        if (blocks < 1) {
+            if (perSimdPerBlock > regWaves) continue;  // a workgroup of this size does not fit the register file
+            blocks = 1;
+        }
+        int w = blocks * perSimdPerBlock;
+        int pad = 0;
+        if (w > 2 && (w & 1)) {  // odd: drop to the even count below by padding the LDS request
+            const int wantBlocks = (w - 1) / perSimdPerBlock;
+            if (wantBlocks >= 1 && wantBlocks * perSimdPerBlock == w - 1) {
+                pad = (160 * 1024) / (wantBlocks + 1) + 1024;  // wantBlocks fit, wantBlocks+1 do not
+                if ((size_t)pad < ldsBytes) pad = 0;
+                if ((size_t)pad * wantBlocks > 160 * 1024) pad = 0;
+                if (pad) w = w - 1;
+            }
+        }
+        const double score = (w == 1 ? 0.5 : (w & 1) ? 0.8 : 1.0) + 0.001 * w + (wpb == 4 ? 0.0005 : 0.0);
+        if (score > bestScore) { bestScore = score; bestW = w; bestWpb = wpb; bestPad = pad; }
+    }
+    *wpbOut = bestWpb;
+    *ldsPadOut = bestPad;
+    return bestW;
+}
+static double issue_factor(int wavesPerSimd) { return wavesPerSimd <= 1 ? 0.5 : (wavesPerSimd & 1) ? 0.8 : 1.0; }
+
 /*
  * Split the item range [first, first+count) (sorted by length, longest first) into classes of
  * equal wave geometry. Each sequence (pair) is spread over G lanes; a wave therefore needs
@@ -249,11 +422,11 @@ static double step_clocks(int width, int rows) {
  * the launch. `lenOf(i)` is the length of item i.
  */
 template <typename LenOf>
-static std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass, int Q, int A, LenOf lenOf, int first,
+static std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass, int skew, int Q, int A, LenOf lenOf, int first,
                                              int count) {
     std::vector<LaunchClass> out;
     if (count <= 0) return out;
-    struct Cand { int G, rows; double eff; };
+    struct Cand { int G, rows, wpb, ldsPad; double eff; };
     std::vector<Cand> cands;
     const char* forceG = getenv("OPAL_HIP_LANES_PER_SEQ");
     double lenSum = 0;
@@ -267,10 +440,13 @@ static std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass,
         if (need > OPAL_HIP_MAX_ROWS) continue;
         const int rows = opal_hip_rows_supported(width, mode, swEndPass, need);
         if (!rows) continue;
-        if (opal_hip_lds_bytes(width, G, rows, A) > 160 * 1024) continue;
+        const size_t lds = opal_hip_lds_bytes(width, G, rows, A);
+        if (lds > 160 * 1024) continue;
         if (G > 1 && (G / 2) * rows >= Q && !(forceG && *forceG)) continue;  // half the lanes would hold padding only
-        const double eff = ((double)Q / (G * rows)) * (rows / step_clocks(width, rows)) * (lavg / (lavg + G - 1));
-        cands.push_back({G, rows, eff});
+        int wpb = 4, ldsPad = 0;
+        const int waves = pick_occupancy(kernel_vgprs(width, mode, swEndPass, 0, skew, rows), lds, &wpb, &ldsPad);
+        const double eff = ((double)Q / (G * rows)) * (rows / step_clocks(width, rows)) * (lavg / (lavg + G - 1)) * issue_factor(waves);
+        cands.push_back({G, rows, wpb, ldsPad, eff});
     }
     if (cands.empty()) return out;
     size_t base = 0;
@@ -286,6 +462,7 @@ static std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass,
     size_t ci = cands.size() - 1;
     int start = first;
     auto fits = [&](size_t c, int len) { return (len + cands[c].G - 1) * step_clocks(width, cands[c].rows) <= budget; };
+    auto cls = [&](int s, int n, size_t c) { return LaunchClass{s, n, cands[c].G, cands[c].rows, cands[c].wpb, cands[c].ldsPad}; };
     int i = first;
     while (i < first + count) {
         const int len = lenOf(i);
@@ -294,21 +471,36 @@ static std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass,
         if (i == first) ci = want;
         if (want != ci) {
             // close the current class at a multiple of its slots-per-wave
-            out.push_back({start, i - start, cands[ci].G, cands[ci].rows});
+            out.push_back(cls(start, i - start, ci));
             start = i;
             ci = want;
         }
         if (ci == base) break;  // everything from here on uses the base geometry
         i += 64 / cands[ci].G;
     }
-    out.push_back({start, first + count - start, cands[ci].G, cands[ci].rows});
+    out.push_back(cls(start, first + count - start, ci));
     while (out.size() > 4) {  // at most three side streams: fold the two longest classes together
         out[1].count += out[0].count;
         out[1].first = out[0].first;
-        out[1].G = out[0].G; out[1].rows = out[0].rows;
+        out[1].G = out[0].G; out[1].rows = out[0].rows; out[1].wpb = out[0].wpb; out[1].ldsPad = out[0].ldsPad;
         out.erase(out.begin());
     }
     return out;
+}
+
+static void fill_launch(OpalHipLaunch& a, const SearchCtx& c, int width, int swEndPass, int detectWrap, const int* work,
+                        int* ovfCounter) {
+    memset(&a, 0, sizeof a);
+    OpalxDb* db = c.db;
+    a.width = width; a.mode = c.mode; a.want_end = swEndPass; a.detect_wrap = detectWrap;
+    a.query = db->query.p; a.query_length = c.Q; a.score_matrix = db->matrix.p; a.alphabet_length = c.A;
+    a.gap_open = c.Go; a.gap_ext = c.Ge;
+    a.tokens = db->tokens.p; a.pair_token_offset = db->pairOff.p; a.pair_len = db->dPairLen.p; a.pair_seq = db->dPairSeq.p;
+    a.work = work;
+    a.out_score = c.dScore; a.out_end_query = c.wantEnd ? c.dEndQ : nullptr; a.out_end_target = c.wantEnd ? c.dEndT : nullptr;
+    a.overflow_count = ovfCounter; a.overflow_items = db->ovfItems.p;
+    a.sat_limit = c.satLimit; a.neg_pad = c.negPad;
+    a.stream = db->main();
 }
 
 // Queries that no single wave geometry can hold (more than 64 lanes x 40 rows, or a query profile
@@ -334,9 +526,10 @@ static int launch_chunked(const SearchCtx& c, int width, int swEndPass, int dete
         return OPAL_ERR_NO_SIMD_SUPPORT;
     }
     OpalxDb* db = c.db;
-    if (!db->dBoundary) db->dBoundary = opal_hip_malloc(16 * (db->numTokens + 8));
-    if (!db->dScratch) db->dScratch = (int*)opal_hip_malloc(2 * sizeof(int) * (size_t)std::max(db->numSeqs, 1));
-    if (!db->dBoundary || !db->dScratch) return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (!db->boundary.ensure(16 * (db->numTokens + 8)) || !db->scratch.ensure(2 * (size_t)std::max(db->numSeqs, 1)))
+        return OPAL_ERR_NO_SIMD_SUPPORT;
+    int wpb = 4, ldsPad = 0;
+    pick_occupancy(kernel_vgprs(width, c.mode, swEndPass, 1, 0, bestS), opal_hip_lds_bytes(width, bestG, bestS, c.A), &wpb, &ldsPad);
     const int cap = bestG * bestS;
     const int nchunks = (c.Q + cap - 1) / cap;
     const int firstRows = c.Q - (nchunks - 1) * cap;  // SW/HW/OV: the partial chunk is the first one
@@ -345,22 +538,15 @@ static int launch_chunked(const SearchCtx& c, int width, int swEndPass, int dete
         if (c.mode == OPAL_MODE_NW) { row0 = ch * cap; rows = std::min(cap, c.Q - row0); }
         else { row0 = ch == 0 ? 0 : firstRows + (ch - 1) * cap; rows = ch == 0 ? firstRows : cap; }
         OpalHipLaunch a;
-        memset(&a, 0, sizeof a);
-        a.width = width; a.mode = c.mode; a.want_end = swEndPass; a.detect_wrap = detectWrap;
-        a.lanes_per_seq = bestG; a.rows_per_lane = bestS;
-        a.query = db->dQuery; a.query_length = c.Q; a.score_matrix = db->dMatrix; a.alphabet_length = c.A;
-        a.gap_open = c.Go; a.gap_ext = c.Ge;
-        a.tokens = db->dTokens; a.pair_token_offset = db->dPairOff; a.pair_len = db->dPairLen; a.pair_seq = db->dPairSeq;
-        a.work = work; a.first_item = firstItem; a.num_items = numItems;
-        a.out_score = c.dScore; a.out_end_query = c.wantEnd ? c.dEndQ : nullptr; a.out_end_target = c.wantEnd ? c.dEndT : nullptr;
-        a.overflow_count = ovfCounter; a.overflow_items = db->dOvfItems;
-        a.sat_limit = c.satLimit; a.neg_pad = c.negPad;
+        fill_launch(a, c, width, swEndPass, detectWrap, work, ovfCounter);
+        a.lanes_per_seq = bestG; a.rows_per_lane = bestS; a.waves_per_block = wpb;
+        a.first_item = firstItem; a.num_items = numItems;
         a.chunk_flags = (ch > 0 ? 1 : 0) | (ch < nchunks - 1 ? 2 : 0);
         a.chunk_row0 = row0; a.chunk_rows = rows;
-        a.boundary = db->dBoundary; a.scratch = db->dScratch;
+        a.boundary = db->boundary.p; a.scratch = db->scratch.p;
         if (debug_on())
-            fprintf(stderr, "[opal] chunk %d/%d rows [%d,+%d) width=%d mode=%d end=%d G=%d rows/lane=%d\n", ch + 1, nchunks, row0,
-                    rows, width, c.mode, swEndPass, bestG, bestS);
+            fprintf(stderr, "[opal] chunk %d/%d rows [%d,+%d) width=%d mode=%d end=%d G=%d rows/lane=%d waves/block=%d\n", ch + 1,
+                    nchunks, row0, rows, width, c.mode, swEndPass, bestG, bestS, wpb);
         if (opal_hip_launch(&a)) return OPAL_ERR_NO_SIMD_SUPPORT;
     }
     return 0;
@@ -370,60 +556,54 @@ template <typename LenOf>
 static int launch_range(const SearchCtx& c, int width, int swEndPass, int detectWrap, const int* work, int firstItem,
                         int numItems, LenOf lenOf, int* ovfCounter) {
     if (numItems <= 0) return 0;
-    std::vector<LaunchClass> classes;
-    if (work) {
-        // re-run lists are unordered: one class sized for the longest sequence of the database
-        auto l0 = [&](int) { return c.db->pairLen.empty() ? 1 : c.db->pairLen[0]; };
-        classes = plan_classes(width, c.mode, swEndPass, c.Q, c.A, l0, firstItem, numItems);
-    } else {
-        classes = plan_classes(width, c.mode, swEndPass, c.Q, c.A, lenOf, firstItem, numItems);
-    }
+    OpalxDb* db = c.db;
+    // skewed kernels (width 17, NW/HW/OV) add up to (rows + steps) * Ge to every value: allowed for a class when
+    // even its longest sequence stays inside the 16-bit range
+    auto skew_ok = [&](int item) {
+        const long long L0 = lenOf(item);
+        return std::min<long long>(c.Q, L0) * c.maxScore + (OPAL_HIP_MAX_ROWS + L0 + 64 + 4) * (long long)c.Ge < 32000;
+    };
+    const bool maySkew = width == 17 && c.mode != OPAL_MODE_SW && !work && !getenv("OPAL_HIP_NO_SKEW");
+    std::vector<LaunchClass> classes = plan_classes(width, c.mode, swEndPass, maySkew && skew_ok(firstItem + numItems - 1), c.Q, c.A,
+                                                    lenOf, firstItem, numItems);
     if (classes.empty() || getenv("OPAL_HIP_FORCE_CHUNKS"))
         return launch_chunked(c, width, swEndPass, detectWrap, work, firstItem, numItems, ovfCounter);
-    // The last class (the bulk of the database) runs on the null stream; the classes of long
+    // The last class (the bulk of the database) runs on the main stream; the classes of long
     // sequences run beside it on up to three side streams (one hardware queue each), forked from and
-    // joined back into the null stream with events, longest sequences enqueued first.
+    // joined back into the main stream with events, longest sequences enqueued first.
     const int nside = std::min<int>((int)classes.size() - 1, 3);
     void* fork = nullptr;
     if (nside > 0) {
-        fork = c.db->event(0);
-        if (!fork || opal_hip_event_record(fork, nullptr)) return OPAL_ERR_NO_SIMD_SUPPORT;
+        fork = db->event(0);
+        if (!fork || opal_hip_event_record(fork, db->main())) return OPAL_ERR_NO_SIMD_SUPPORT;
     }
-    for (size_t ki = 0; ki < classes.size(); ki++) {
+    int err = 0;
+    int recorded = 0;
+    for (size_t ki = 0; ki < classes.size() && !err; ki++) {
         const LaunchClass& k = classes[ki];
         OpalHipLaunch a;
-        memset(&a, 0, sizeof a);
-        a.width = width; a.mode = c.mode; a.want_end = swEndPass; a.detect_wrap = detectWrap;
-        a.lanes_per_seq = k.G; a.rows_per_lane = k.rows;
-        a.query = c.db->dQuery; a.query_length = c.Q; a.score_matrix = c.db->dMatrix; a.alphabet_length = c.A;
-        a.gap_open = c.Go; a.gap_ext = c.Ge;
-        a.tokens = c.db->dTokens; a.pair_token_offset = c.db->dPairOff; a.pair_len = c.db->dPairLen; a.pair_seq = c.db->dPairSeq;
-        a.work = work; a.first_item = k.first; a.num_items = k.count;
-        a.out_score = c.dScore; a.out_end_query = c.wantEnd ? c.dEndQ : nullptr; a.out_end_target = c.wantEnd ? c.dEndT : nullptr;
-        a.overflow_count = ovfCounter; a.overflow_items = c.db->dOvfItems;
-        a.sat_limit = c.satLimit; a.neg_pad = c.negPad;
-        if (width == 17 && c.mode != OPAL_MODE_SW && !work && !getenv("OPAL_HIP_NO_SKEW")) {
-            // skewed kernels add up to (rows + steps) * Ge to every value: allowed when even the longest
-            // sequence of the class stays inside the 16-bit range
-            const long long L0 = lenOf(k.first);
-            const long long top = std::min<long long>(c.Q, L0) * c.maxScore + (OPAL_HIP_MAX_ROWS + L0 + 64 + 4) * (long long)c.Ge;
-            a.skew = top < 32000;
-        }
+        fill_launch(a, c, width, swEndPass, detectWrap, work, ovfCounter);
+        a.lanes_per_seq = k.G; a.rows_per_lane = k.rows; a.waves_per_block = k.wpb; a.lds_bytes_min = k.ldsPad;
+        a.first_item = k.first; a.num_items = k.count;
+        const int skew = maySkew && skew_ok(k.first);
+        a.skew = skew;
         const bool side = (int)ki < nside;
-        a.stream = side ? c.db->stream((int)ki) : nullptr;
+        if (side) a.stream = db->stream((int)ki);
         a.priority = side ? 1 : 0;
         if (debug_on())
-            fprintf(stderr, "[opal] launch width=%d mode=%d end=%d items=[%d,+%d) G=%d rows=%d%s\n", width, c.mode, swEndPass,
-                    k.first, k.count, k.G, k.rows, side ? " (side stream)" : "");
-        if (side && opal_hip_stream_wait_event(a.stream, fork)) return OPAL_ERR_NO_SIMD_SUPPORT;
-        if (opal_hip_launch(&a)) return OPAL_ERR_NO_SIMD_SUPPORT;
+            fprintf(stderr, "[opal] launch width=%d mode=%d end=%d items=[%d,+%d) G=%d rows=%d waves/block=%d ldsPad=%d%s%s\n", width,
+                    c.mode, swEndPass, k.first, k.count, k.G, k.rows, k.wpb, k.ldsPad, skew ? " skew" : "", side ? " (side stream)" : "");
+        if (side && (!a.stream || opal_hip_stream_wait_event(a.stream, fork))) { err = 1; break; }
+        if (opal_hip_launch(&a)) { err = 1; break; }
         if (side) {
-            void* done = c.db->event(1 + (int)ki);
-            if (!done || opal_hip_event_record(done, a.stream)) return OPAL_ERR_NO_SIMD_SUPPORT;
+            void* done = db->event(1 + (int)ki);
+            if (!done || opal_hip_event_record(done, a.stream)) { err = 1; break; }
+            recorded = (int)ki + 1;
         }
     }
-    for (int i = 0; i < nside; i++)
-        if (opal_hip_stream_wait_event(nullptr, c.db->event(1 + i))) return OPAL_ERR_NO_SIMD_SUPPORT;
+    for (int i = 0; i < recorded; i++)
+        if (opal_hip_stream_wait_event(db->main(), db->event(1 + i))) err = 1;
+    if (err) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }  // nothing of this call stays in flight
     return 0;
 }
 
@@ -437,20 +617,10 @@ static bool args_fit_int32(int Go, int Ge, const int* M, int A) {
 }
 
 static int ensure_query_buffers(OpalxDb* db, const unsigned char* query, int Q, const int* M, int A) {
-    const size_t qb = (size_t)std::max(Q, 1), mb = (size_t)A * A * sizeof(int);
-    if (db->queryCap < qb) {
-        opal_hip_free(db->dQuery);
-        db->dQuery = (unsigned char*)opal_hip_malloc(qb);
-        db->queryCap = db->dQuery ? qb : 0;
-    }
-    if (db->matrixCap < mb) {
-        opal_hip_free(db->dMatrix);
-        db->dMatrix = (int*)opal_hip_malloc(mb);
-        db->matrixCap = db->dMatrix ? mb : 0;
-    }
-    if (!db->dQuery || !db->dMatrix) return 1;
-    if (Q && opal_hip_memcpy_h2d(db->dQuery, query, (size_t)Q, nullptr)) return 1;
-    if (opal_hip_memcpy_h2d(db->dMatrix, M, mb, nullptr)) return 1;
+    const size_t qb = (size_t)std::max(Q, 1), mb = (size_t)A * A;
+    if (!db->query.ensure(qb) || !db->matrix.ensure(mb)) return 1;
+    if (Q && opal_hip_memcpy_h2d(db->query.p, query, (size_t)Q, db->main())) return 1;
+    if (opal_hip_memcpy_h2d(db->matrix.p, M, mb * sizeof(int), db->main())) return 1;
     return 0;
 }
 
@@ -469,14 +639,19 @@ static void degenerate_result(int mode, int Q, int L, int Go, int Ge, int* score
     *endQ = Q - 1; *endT = L - 1;
 }
 
-static int write_one(int* dArr, int idx, int value) {
-    if (!dArr) return 0;
-    return opal_hip_memcpy_h2d(dArr + idx, &value, sizeof(int), nullptr) || opal_hip_stream_sync(nullptr);
+// {caller index, score, endQ, endT} quads -> one upload, one scatter kernel
+static int write_degenerate(OpalxDb* db, const std::vector<int>& quads, int* dScore, int* dEndQ, int* dEndT) {
+    const int count = (int)(quads.size() / 4);
+    if (!count) return 0;
+    if (!db->quads.ensure(quads.size(), 1.5)) return 1;
+    if (opal_hip_memcpy_h2d(db->quads.p, quads.data(), quads.size() * sizeof(int), db->main())) return 1;
+    if (opal_hip_scatter_results(db->quads.p, count, dScore, dEndQ, dEndT, db->main())) return 1;
+    return opal_hip_stream_sync(db->main());  // `quads` is pageable host memory of the caller's frame
 }
 
 /*
  * The scheduler. Plays the role of the reference's precision ladder (opal.cpp:496-535, :983-1021)
- * with the rungs gfx950 has: packed 16-bit first, 32-bit for whatever saturates or cannot be
+ * with the rungs gfx950 has: 16-bit first, 32-bit for whatever saturates or cannot be
  * proven safe. OPAL_OVERFLOW_SIMPLE and OPAL_OVERFLOW_BUCKETS give identical results in the
  * reference (only the re-run granularity differs); here both map to the same schedule.
  */
@@ -493,30 +668,29 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
     if (!device_ok()) return OPAL_ERR_NO_SIMD_SUPPORT;
     const int wantEnd = searchType != OPAL_SEARCH_SCORE;
     const int P = db->numPairs;
+    void* const st = db->main();
+    if (!st) return OPAL_ERR_NO_SIMD_SUPPORT;
     int rc = 0;
 
     // ---- degenerate shapes: answered from the matrix boundary
-    for (int idx : db->emptySeqs) {
-        int s, eq, et;
-        degenerate_result(mode, Q, 0, Go, Ge, &s, &eq, &et);
-        if (!wantEnd) { eq = et = -1; }
-        if (write_one(dScore, idx, s) || write_one(dEndQ, idx, eq) || write_one(dEndT, idx, et)) return OPAL_ERR_NO_SIMD_SUPPORT;
-    }
-    if (Q == 0) {
-        for (int i = 0; i < 2 * P; i++) {
-            if (db->pairSeq[i] < 0) continue;
+    {
+        std::vector<int> quads;
+        auto add = [&](int idx, int L) {
             int s, eq, et;
-            degenerate_result(mode, 0, db->pairLen[i], Go, Ge, &s, &eq, &et);
+            degenerate_result(mode, Q, L, Go, Ge, &s, &eq, &et);
             if (!wantEnd) { eq = et = -1; }
-            if (write_one(dScore, db->pairSeq[i], s) || write_one(dEndQ, db->pairSeq[i], eq) || write_one(dEndT, db->pairSeq[i], et))
-                return OPAL_ERR_NO_SIMD_SUPPORT;
-        }
-        return opal_hip_stream_sync(nullptr) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
+            quads.insert(quads.end(), {idx, s, eq, et});
+        };
+        for (int idx : db->emptySeqs) add(idx, 0);
+        if (Q == 0)
+            for (int i = 0; i < 2 * P; i++)
+                if (db->pairSeq[i] >= 0) add(db->pairSeq[i], db->pairLen[i]);
+        if (write_degenerate(db, quads, dScore, dEndQ, dEndT)) return OPAL_ERR_NO_SIMD_SUPPORT;
     }
-    if (P == 0) return opal_hip_stream_sync(nullptr) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
+    if (Q == 0 || P == 0) return opal_hip_stream_sync(st) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
 
     if (ensure_query_buffers(db, query, Q, M, A)) return OPAL_ERR_NO_SIMD_SUPPORT;
-    if (opal_hip_memset(db->dOvfCount, 0, 2 * sizeof(int), nullptr)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (opal_hip_memset(db->ovfCount.p, 0, 2 * sizeof(int), st)) return OPAL_ERR_NO_SIMD_SUPPORT;
 
     long long maxS = 0, minS = 0;
     for (int i = 0; i < A * A; i++) { maxS = std::max<long long>(maxS, M[i]); minS = std::min<long long>(minS, M[i]); }
@@ -541,14 +715,10 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
     SearchCtx c{db, Q, A, Go, Ge, mode, wantEnd, dScore, dEndQ, dEndT, satLimit, mode == OPAL_MODE_SW ? -satLimit : 0, maxS};
     const int nNarrow = narrow == 16 ? P : 2 * P;  // items of the narrow rung: pairs or sequences
     auto pairLenOf = [db](int p) { return db->pairLen[2 * (size_t)p]; };   // width-16 items are pairs
-    auto seqLenOf = [db](int it) { return db->pairLen[(size_t)it]; };      // width-32 items are pair*2+half
-    struct Events {  // timing events around every DP launch of this call, released on every return path
-        void* start = nullptr; void* stop = nullptr;
-        ~Events() { opal_hip_event_destroy(start); opal_hip_event_destroy(stop); }
-    } ev;
-    if (kernelMs) { ev.start = opal_hip_event_create(); ev.stop = opal_hip_event_create(); }
-    void* const evStart = ev.start; void* const evStop = ev.stop;
-    if (evStart) opal_hip_event_record(evStart, nullptr);
+    auto seqLenOf = [db](int it) { return db->pairLen[(size_t)it]; };      // width-17/32 items are pair*2+half
+    void* evStart = nullptr; void* evStop = nullptr;
+    if (kernelMs) { evStart = db->event(4); evStop = db->event(5); }
+    if (evStart) opal_hip_event_record(evStart, st);
 
     if (mode == OPAL_MODE_SW) {
         // rung 1: everything at 16 bits (if the inputs fit), saturated scores go to the re-run list.
@@ -556,26 +726,45 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
         // was first reached).
         int n32 = 0;
         const int* work32 = nullptr;
-        int first32 = 0;
+        std::vector<int> rerun;  // the re-run list, longest sequence first
         if (fits16) {
-            if (narrow == 16) rc = launch_range(c, 16, wantEnd, 0, nullptr, 0, nNarrow, pairLenOf, db->dOvfCount);
-            else rc = launch_range(c, 17, wantEnd, 0, nullptr, 0, nNarrow, seqLenOf, db->dOvfCount);
+            if (narrow == 16) rc = launch_range(c, 16, wantEnd, 0, nullptr, 0, nNarrow, pairLenOf, db->ovfCount.p);
+            else rc = launch_range(c, 17, wantEnd, 0, nullptr, 0, nNarrow, seqLenOf, db->ovfCount.p);
             if (rc) return rc;
             int cnt = 0;
-            if (opal_hip_memcpy_d2h(&cnt, db->dOvfCount, sizeof(int), nullptr) || opal_hip_stream_sync(nullptr))
+            if (opal_hip_memcpy_d2h(&cnt, db->ovfCount.p, sizeof(int), st) || opal_hip_stream_sync(st))
                 return OPAL_ERR_NO_SIMD_SUPPORT;
-            n32 = cnt; work32 = db->dOvfItems;
+            if (cnt > 0) {
+                // The kernels append in completion order: sort the list by length so that the width-32 launch
+                // classes get the geometry of the sequences they really hold (not the database's longest).
+                rerun.resize((size_t)cnt);
+                if (opal_hip_memcpy_d2h(rerun.data(), db->ovfItems.p, (size_t)cnt * sizeof(int), st) || opal_hip_stream_sync(st))
+                    return OPAL_ERR_NO_SIMD_SUPPORT;
+                std::sort(rerun.begin(), rerun.end(), [&](int a, int b) {
+                    const int la = db->pairLen[(size_t)a], lb = db->pairLen[(size_t)b];
+                    return la != lb ? la > lb : a < b;
+                });
+                if (opal_hip_memcpy_h2d(db->ovfItems.p, rerun.data(), (size_t)cnt * sizeof(int), st) || opal_hip_stream_sync(st))
+                    return OPAL_ERR_NO_SIMD_SUPPORT;
+            }
+            n32 = cnt; work32 = db->ovfItems.p;
         } else {
-            n32 = 2 * P; first32 = 0; work32 = nullptr;  // items pair*2+half enumerate every sequence
+            n32 = 2 * P; work32 = nullptr;  // items pair*2+half enumerate every sequence
         }
         // rung 2: width 32, with the reference's wrap test when a wrap is arithmetically possible
         if (n32 > 0) {
             const long long maxLen = db->pairLen[0];
             const int detect = (double)std::min<long long>(Q, maxLen) * (double)maxS > (double)INT_MAX;
-            if ((rc = launch_range(c, 32, wantEnd, detect, work32, first32, n32, seqLenOf, db->dOvfCount + 1))) return rc;
+            if (work32) {
+                auto rerunLenOf = [&](int i) { return db->pairLen[(size_t)rerun[(size_t)i]]; };
+                rc = launch_range(c, 32, wantEnd, detect, work32, 0, n32, rerunLenOf, db->ovfCount.p + 1);
+            } else {
+                rc = launch_range(c, 32, wantEnd, detect, nullptr, 0, n32, seqLenOf, db->ovfCount.p + 1);
+            }
+            if (rc) return rc;
             if (detect) {
                 int wraps = 0;
-                if (opal_hip_memcpy_d2h(&wraps, db->dOvfCount + 1, sizeof(int), nullptr) || opal_hip_stream_sync(nullptr))
+                if (opal_hip_memcpy_d2h(&wraps, db->ovfCount.p + 1, sizeof(int), st) || opal_hip_stream_sync(st))
                     return OPAL_ERR_NO_SIMD_SUPPORT;
                 if (wraps) rc = OPAL_ERR_OVERFLOW;
             }
@@ -609,54 +798,169 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
         }
         if (nBad > 0) rc = OPAL_ERR_OVERFLOW;
         if (2 * p32 > nBad &&
-            launch_range(c, 32, 0, 0, nullptr, nBad, 2 * p32 - nBad, seqLenOf, db->dOvfCount + 1))
+            launch_range(c, 32, 0, 0, nullptr, nBad, 2 * p32 - nBad, seqLenOf, db->ovfCount.p + 1))
             return OPAL_ERR_NO_SIMD_SUPPORT;
         if (P > p32) {
-            const int e = narrow == 16 ? launch_range(c, 16, 0, 0, nullptr, p32, P - p32, pairLenOf, db->dOvfCount)
-                                       : launch_range(c, 17, 0, 0, nullptr, 2 * p32, 2 * (P - p32), seqLenOf, db->dOvfCount);
+            const int e = narrow == 16 ? launch_range(c, 16, 0, 0, nullptr, p32, P - p32, pairLenOf, db->ovfCount.p)
+                                       : launch_range(c, 17, 0, 0, nullptr, 2 * p32, 2 * (P - p32), seqLenOf, db->ovfCount.p);
             if (e) return OPAL_ERR_NO_SIMD_SUPPORT;
         }
     }
-    if (evStop) opal_hip_event_record(evStop, nullptr);
-    if (opal_hip_stream_sync(nullptr)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (evStop) opal_hip_event_record(evStop, st);
+    if (opal_hip_stream_sync(st)) return OPAL_ERR_NO_SIMD_SUPPORT;
     if (kernelMs && evStart && evStop) *kernelMs = opal_hip_event_elapsed_ms(evStart, evStop);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------ devices of a call
+// OPAL_HIP_DEVICES = "all" | "0,1,2,..." makes opalSearchDatabase shard every call over those GPUs. A device
+// may be listed more than once (two contexts on one GPU): that is how the sharding is tested on a one-GPU box.
+static std::vector<int> call_devices() {
+    std::vector<int> out;
+    const char* env = getenv("OPAL_HIP_DEVICES");
+    if (!env || !*env) return out;
+    const int n = opal_hip_device_count();
+    if (!strcmp(env, "all")) {
+        for (int i = 0; i < n; i++) out.push_back(i);
+        return out;
+    }
+    const char* p = env;
+    while (*p) {
+        char* end = nullptr;
+        const long v = strtol(p, &end, 10);
+        if (end == p) break;
+        if (v >= 0 && v < n) out.push_back((int)v);
+        p = *end ? end + 1 : end;
+    }
+    return out;
+}
+
+/*
+ * Deal sequences to `parts` shards: indices sorted by length (descending), cut into groups of
+ * 64 consecutive ones (sequences of one wave stay together), every group to the shard with the fewest residues
+ * so far. Returns shard[k] = list of positions into `lens`.
+ */
+static std::vector<std::vector<int>> deal_groups(const int* lens, int n, int parts) {
+    std::vector<int> order((size_t)n);
+    for (int i = 0; i < n; i++) order[(size_t)i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lens[a] > lens[b]; });
+    std::vector<std::vector<int>> shard((size_t)parts);
+    std::vector<long long> load((size_t)parts, 0);
+    for (int g = 0; g < n; g += 64) {
+        const int e = std::min(n, g + 64);
+        long long sum = 0;
+        for (int i = g; i < e; i++) sum += lens[order[(size_t)i]];
+        size_t best = 0;
+        for (size_t k = 1; k < shard.size(); k++)
+            if (load[k] < load[best]) best = k;
+        load[best] += sum;
+        shard[best].insert(shard[best].end(), order.begin() + g, order.begin() + e);
+    }
+    return shard;
+}
+
+/*
+ * One shard of an opalSearchDatabase call on the calling thread's current device: pack, upload, search,
+ * download. `ids` (may be null = identity) maps shard position -> caller index; results land in
+ * score/endQ/endT at SHARD positions (INT_MIN = not written by the search).
+ */
+static int run_shard(int device, const unsigned char* query, int Q, unsigned char* const* db, const int* dbLens, const int* ids,
+                     int n, int Go, int Ge, const int* M, int A, int searchType, int mode, int* score, int* endQ, int* endT,
+                     double* tms) {
+    BorrowedContext ctx(device);
+    OpalxDb* pdb = ctx.db;
+    if (!pdb) return OPAL_ERR_NO_SIMD_SUPPORT;
+    const double t0 = now_ms();
+    HostPack hp;
+    if (ids) {
+        std::vector<int> lens((size_t)n);
+        for (int i = 0; i < n; i++) lens[(size_t)i] = dbLens[ids[i]];
+        pack_order(n, lens.data(), hp);
+    } else {
+        pack_order(n, dbLens, hp);
+    }
+    const double t1 = now_ms();
+    auto getSeq = [&](int i) { return (const unsigned char*)db[ids ? ids[i] : i]; };
+    if (!db_fill(pdb, hp, RAW_POINTERS, getSeq, nullptr)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    const double t2 = now_ms();
+    const size_t nn = (size_t)std::max(n, 1);
+    const int wantEnd = searchType != OPAL_SEARCH_SCORE;
+    if (!pdb->results.ensure(3 * nn, 1.15) || !pdb->hResults.ensure(3 * nn, 1.15)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    int* dS = pdb->results.p; int* dQ = dS + nn; int* dT = dS + 2 * nn;
+    void* st = pdb->main();
+    // INT_MIN marks "not written by the search" (a sequence the search had to give up on)
+    if (opal_hip_memset32(dS, INT_MIN, nn, st) || (wantEnd && opal_hip_memset32(dQ, -1, 2 * nn, st))) return OPAL_ERR_NO_SIMD_SUPPORT;
+    int rc = search_core(pdb, query, Q, Go, Ge, M, A, searchType, mode, dS, wantEnd ? dQ : nullptr, wantEnd ? dT : nullptr, nullptr);
+    const double t3 = now_ms();
+    if (rc == OPAL_ERR_NO_SIMD_SUPPORT || rc == OPAL_ERR_INVALID_MODE) return rc;
+    int* h = pdb->hResults.p;
+    if (opal_hip_memcpy_d2h(h, dS, (wantEnd ? 3 : 1) * nn * sizeof(int), st) || opal_hip_stream_sync(st)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    memcpy(score, h, (size_t)n * sizeof(int));
+    if (wantEnd) { memcpy(endQ, h + nn, (size_t)n * sizeof(int)); memcpy(endT, h + 2 * nn, (size_t)n * sizeof(int)); }
+    if (tms) { tms[0] += t1 - t0; tms[1] += t2 - t1; tms[2] += t3 - t2; tms[3] += now_ms() - t3; }
     return rc;
 }
 
 }  // namespace
 
 // ------------------------------------------------------------------------------------ opalx_* API
+static OpalxDb* create_from(HostPack& hp, RawKind kind, const std::function<const unsigned char*(int)>& getSeq,
+                            const unsigned char* flat) {
+    OpalxDb* db = new (std::nothrow) OpalxDb;
+    if (!db) return nullptr;
+    if (!db_fill(db, hp, kind, getSeq, flat)) { opalx_db_destroy(db); return nullptr; }
+    return db;
+}
+
 extern "C" OpalxDb* opalx_db_create(unsigned char* const db[], int db_length, const int db_seq_lengths[]) {
     if (!device_ok()) return nullptr;
     HostPack hp;
     pack_order(db_length, db_seq_lengths, hp);
-    gather_residues([&](int i) { return (const unsigned char*)db[i]; }, hp);
-    return upload(hp);
+    return create_from(hp, RAW_POINTERS, [&](int i) { return (const unsigned char*)db[i]; }, nullptr);
+}
+
+static void flat_offsets(const int64_t* offsets, int db_length, HostPack& hp) {
+    std::vector<int> lens((size_t)db_length);
+    for (int i = 0; i < db_length; i++) lens[(size_t)i] = (int)(offsets[i + 1] - offsets[i]);
+    pack_order(db_length, lens.data(), hp);
+    // already contiguous: the device packer reads each sequence at its offset
+    hp.rawOff.resize(hp.pairSeq.size());
+    for (size_t i = 0; i < hp.pairSeq.size(); i++) hp.rawOff[i] = hp.pairSeq[i] >= 0 ? (uint64_t)offsets[hp.pairSeq[i]] : 0;
+    hp.rawBytes = (uint64_t)offsets[db_length];
 }
 
 extern "C" OpalxDb* opalx_db_create_flat(const unsigned char* residues, const int64_t* offsets, int db_length) {
     if (!device_ok()) return nullptr;
-    std::vector<int> lens((size_t)db_length);
-    for (int i = 0; i < db_length; i++) lens[i] = (int)(offsets[i + 1] - offsets[i]);
     HostPack hp;
-    pack_order(db_length, lens.data(), hp);
-    // already contiguous: upload as it is, the device packer reads each sequence at its offset
-    hp.rawOff.resize(hp.pairSeq.size());
-    for (size_t i = 0; i < hp.pairSeq.size(); i++) hp.rawOff[i] = hp.pairSeq[i] >= 0 ? (uint64_t)offsets[hp.pairSeq[i]] : 0;
-    hp.raw = residues;
-    hp.rawBytes = (uint64_t)offsets[db_length];
-    return upload(hp);
+    flat_offsets(offsets, db_length, hp);
+    return create_from(hp, RAW_HOST_FLAT, nullptr, residues);
+}
+
+extern "C" OpalxDb* opalx_db_create_flat_device(const unsigned char* d_residues, const int64_t* offsets, int db_length) {
+    if (!device_ok()) return nullptr;
+    HostPack hp;
+    flat_offsets(offsets, db_length, hp);
+    return create_from(hp, RAW_DEVICE_FLAT, nullptr, d_residues);
 }
 
 extern "C" void opalx_db_destroy(OpalxDb* db) {
     if (!db) return;
-    opal_hip_free(db->dTokens); opal_hip_free(db->dPairOff); opal_hip_free(db->dPairLen); opal_hip_free(db->dPairSeq);
-    opal_hip_free(db->dOvfCount); opal_hip_free(db->dOvfItems);
-    opal_hip_free(db->dQuery); opal_hip_free(db->dMatrix);
-    opal_hip_free(db->dBoundary); opal_hip_free(db->dScratch); opal_hip_free(db->dResults);
-    for (void* st : db->streams) opal_hip_stream_destroy(st);
-    for (void* ev : db->events) opal_hip_event_destroy(ev);
+    db->quiesce();
+    db_release(db);
     delete db;
+}
+
+extern "C" void opalx_release_cached(void) {
+    ContextCache& c = ContextCache::get();
+    std::lock_guard<std::mutex> lk(c.m);
+    const int cur = opal_hip_get_device();
+    for (auto& kv : c.freeList) {
+        if (kv.second.empty()) continue;
+        opal_hip_set_device(kv.first);
+        for (OpalxDb* db : kv.second) { db->quiesce(); db_release(db); delete db; }
+        kv.second.clear();
+    }
+    if (cur >= 0) opal_hip_set_device(cur);
 }
 
 extern "C" int opalx_db_num_sequences(const OpalxDb* db) { return db ? db->numSeqs : 0; }
@@ -680,24 +984,24 @@ extern "C" int opalx_search_host(OpalxDb* db, const unsigned char* query, int qu
     if (!db) return OPAL_ERR_NO_SIMD_SUPPORT;
     const int n = db->numSeqs;
     const int wantEnd = search_type != OPAL_SEARCH_SCORE;
-    const size_t bytes = (size_t)std::max(n, 1) * sizeof(int);
-    if (!db->dResults) db->dResults = (int*)opal_hip_malloc(3 * bytes);  // kept for the life of the handle
-    int* d = db->dResults;
-    if (!d) return OPAL_ERR_NO_SIMD_SUPPORT;
-    int* dS = d; int* dQ = d + std::max(n, 1); int* dT = d + 2 * (size_t)std::max(n, 1);
+    const size_t nn = (size_t)std::max(n, 1);
+    if (!db->results.ensure(3 * nn)) return OPAL_ERR_NO_SIMD_SUPPORT;  // kept for the life of the handle
+    int* dS = db->results.p; int* dQ = dS + nn; int* dT = dS + 2 * nn;
+    void* st = db->main();
+    if (!st) return OPAL_ERR_NO_SIMD_SUPPORT;
     // pre-load the caller's values so that sequences the search does not write keep them
     int rc = 0;
-    if (opal_hip_memcpy_h2d(dS, score, (size_t)n * sizeof(int), nullptr)) rc = OPAL_ERR_NO_SIMD_SUPPORT;
-    if (!rc && end_query && opal_hip_memcpy_h2d(dQ, end_query, (size_t)n * sizeof(int), nullptr)) rc = OPAL_ERR_NO_SIMD_SUPPORT;
-    if (!rc && end_target && opal_hip_memcpy_h2d(dT, end_target, (size_t)n * sizeof(int), nullptr)) rc = OPAL_ERR_NO_SIMD_SUPPORT;
+    if (opal_hip_memcpy_h2d(dS, score, (size_t)n * sizeof(int), st)) rc = OPAL_ERR_NO_SIMD_SUPPORT;
+    if (!rc && end_query && opal_hip_memcpy_h2d(dQ, end_query, (size_t)n * sizeof(int), st)) rc = OPAL_ERR_NO_SIMD_SUPPORT;
+    if (!rc && end_target && opal_hip_memcpy_h2d(dT, end_target, (size_t)n * sizeof(int), st)) rc = OPAL_ERR_NO_SIMD_SUPPORT;
     if (!rc)
         rc = search_core(db, query, query_length, gap_open, gap_ext, score_matrix, alphabet_length, search_type, mode, dS,
                          wantEnd ? dQ : nullptr, wantEnd ? dT : nullptr, nullptr);
     if (rc != OPAL_ERR_NO_SIMD_SUPPORT && rc != OPAL_ERR_INVALID_MODE) {
-        int e = opal_hip_memcpy_d2h(score, dS, (size_t)n * sizeof(int), nullptr);
-        if (wantEnd && end_query) e |= opal_hip_memcpy_d2h(end_query, dQ, (size_t)n * sizeof(int), nullptr);
-        if (wantEnd && end_target) e |= opal_hip_memcpy_d2h(end_target, dT, (size_t)n * sizeof(int), nullptr);
-        e |= opal_hip_stream_sync(nullptr);
+        int e = opal_hip_memcpy_d2h(score, dS, (size_t)n * sizeof(int), st);
+        if (wantEnd && end_query) e |= opal_hip_memcpy_d2h(end_query, dQ, (size_t)n * sizeof(int), st);
+        if (wantEnd && end_target) e |= opal_hip_memcpy_d2h(end_target, dT, (size_t)n * sizeof(int), st);
+        e |= opal_hip_stream_sync(st);
         if (e) rc = OPAL_ERR_NO_SIMD_SUPPORT;
     }
     return rc;
@@ -719,69 +1023,148 @@ extern "C" void opalSearchResultSetScore(OpalSearchResult* result, int score) {
     result->score = score;
 }
 
-extern "C" int opalSearchDatabase(unsigned char query[], int queryLength, unsigned char* db[], int dbLength,
-                                  int dbSeqLengths[], int gapOpen, int gapExt, int* scoreMatrix, int alphabetLength,
-                                  OpalSearchResult* results[], const int searchType, int mode, int overflowMethod) {
-    if (mode != OPAL_MODE_NW && mode != OPAL_MODE_HW && mode != OPAL_MODE_OV && mode != OPAL_MODE_SW)
-        return OPAL_ERR_INVALID_MODE;
-    // Results that already hold what is asked for are kept (opal.h:118-122, opal.cpp:1446-1451);
-    // implemented with the documented, whole-database indexing (the reference indexes `skip`
-    // bucket-locally, opal.cpp:510,998).
-    std::vector<int> todo;
-    todo.reserve((size_t)dbLength);
-    for (int i = 0; i < dbLength; i++) {
-        const bool have = results[i]->scoreSet &&
-                          (searchType == OPAL_SEARCH_SCORE ||
-                           (results[i]->endLocationQuery >= 0 && results[i]->endLocationTarget >= 0));
-        if (!have) todo.push_back(i);
-    }
-    int rc = 0;
-    if (!todo.empty()) {
-        if (!device_ok()) return OPAL_ERR_NO_SIMD_SUPPORT;
-        const int n = (int)todo.size();
-        std::vector<int> lens((size_t)n);
-        for (int i = 0; i < n; i++) lens[i] = dbSeqLengths[todo[i]];
-        const double t0 = now_ms();
-        HostPack hp;
-        pack_order(n, lens.data(), hp);
-        gather_residues([&](int i) { return (const unsigned char*)db[todo[i]]; }, hp);
-        const double t1 = now_ms();
-        OpalxDb* pdb = upload(hp);
-        if (!pdb) return OPAL_ERR_NO_SIMD_SUPPORT;
-        const double t2 = now_ms();
-        const int st = searchType == OPAL_SEARCH_SCORE ? OPAL_SEARCH_SCORE : OPAL_SEARCH_SCORE_END;
-        // INT_MIN marks "not written by the search" (a sequence the search had to give up on)
-        std::vector<int> score((size_t)n, INT_MIN), endQ((size_t)n, -1), endT((size_t)n, -1);
-        rc = opalx_search_host(pdb, query, queryLength, gapOpen, gapExt, scoreMatrix, alphabetLength, st, mode,
-                               overflowMethod, score.data(), endQ.data(), endT.data());
-        const double t3 = now_ms();
-        opalx_db_destroy(pdb);
-        if (rc == OPAL_ERR_NO_SIMD_SUPPORT || rc == OPAL_ERR_INVALID_MODE) return rc;
-        for (int i = 0; i < n; i++) {
-            if (score[i] == INT_MIN) continue;
-            OpalSearchResult* r = results[todo[i]];
-            opalSearchResultSetScore(r, score[i]);
-            r->endLocationQuery = endQ[i];
-            r->endLocationTarget = endT[i];
+namespace {
+
+// Which results still need computing (opal.h:118-122, opal.cpp:1446-1451), with the documented,
+// whole-database indexing (the reference indexes `skip` bucket-locally, opal.cpp:510,998).
+// Returns true if EVERY result needs computing (then `todo` stays empty = identity).
+static bool collect_todo(OpalSearchResult* results[], int n, int searchType, std::vector<int>& todo) {
+    HostPool& pool = HostPool::get();
+    const int tasks = n >= (1 << 16) ? std::min(pool.width(), 16) : 1;
+    std::vector<std::vector<int>> have((size_t)tasks);  // positions that are already computed, per range
+    auto scan = [&](int t) {
+        const int i0 = (int)((long long)n * t / tasks), i1 = (int)((long long)n * (t + 1) / tasks);
+        for (int i = i0; i < i1; i++) {
+            const OpalSearchResult* r = results[i];
+            if (r->scoreSet && (searchType == OPAL_SEARCH_SCORE || (r->endLocationQuery >= 0 && r->endLocationTarget >= 0)))
+                have[(size_t)t].push_back(i);
         }
+    };
+    pool.parallel_for(tasks, scan);
+    size_t nh = 0;
+    for (auto& v : have) nh += v.size();
+    if (nh == 0) return true;
+    todo.reserve((size_t)n - nh);
+    int next = 0;
+    for (auto& v : have)
+        for (int i : v) { while (next < i) todo.push_back(next++); next = i + 1; }
+    while (next < n) todo.push_back(next++);
+    return false;
+}
+
+static int search_into_results(unsigned char query[], int Q, unsigned char* db[], int dbLength, int dbSeqLengths[], int Go, int Ge,
+                               int* M, int A, OpalSearchResult* results[], int searchType, int mode, bool clearAlignment) {
+    const double tA = now_ms();
+    std::vector<int> todo;
+    const bool all = collect_todo(results, dbLength, searchType, todo);
+    const int n = all ? dbLength : (int)todo.size();
+    const int* ids = all ? nullptr : todo.data();
+    int rc = 0;
+    double tms[4] = {0, 0, 0, 0};
+    const double tB = now_ms();
+    double tC = tB;
+    if (n > 0) {
+        if (!device_ok()) return OPAL_ERR_NO_SIMD_SUPPORT;
+        const int st = searchType == OPAL_SEARCH_SCORE ? OPAL_SEARCH_SCORE : OPAL_SEARCH_SCORE_END;
+        const int wantEnd = st != OPAL_SEARCH_SCORE;
+        std::unique_ptr<int[]> buf(new (std::nothrow) int[3 * (size_t)n]);
+        if (!buf) return OPAL_ERR_NO_SIMD_SUPPORT;
+        int* score = buf.get(); int* endQ = score + n; int* endT = score + 2 * (size_t)n;
+        std::vector<int> devices = call_devices();
+        if (devices.size() <= 1 || n < 2 * 64) {
+            if (devices.size() == 1 && opal_hip_set_device(devices[0])) return OPAL_ERR_NO_SIMD_SUPPORT;
+            rc = run_shard(opal_hip_get_device(), query, Q, db, dbSeqLengths, ids, n, Go, Ge, M, A, st, mode, score, endQ, endT, tms);
+        } else {
+            // several GPUs: deal 64-sequence groups balancing the residue count, one host thread per GPU, each
+            // running the single-GPU pipeline on its shard; the host is the gather root (results live in host structs)
+            std::vector<int> lens((size_t)n);
+            for (int i = 0; i < n; i++) lens[(size_t)i] = dbSeqLengths[ids ? ids[i] : i];
+            std::vector<std::vector<int>> shard = deal_groups(lens.data(), n, (int)devices.size());
+            std::vector<int> rcs(devices.size(), 0);
+            std::vector<std::vector<int>> out(devices.size());
+            std::vector<std::thread> threads;
+            const int callerDevice = opal_hip_get_device();
+            for (size_t k = 0; k < devices.size(); k++) {
+                threads.emplace_back([&, k] {
+                    std::vector<int>& pos = shard[k];
+                    const int m = (int)pos.size();
+                    if (!m) return;
+                    // device_ok() first: its once-per-thread OPAL_HIP_DEVICE selection must not override the shard's GPU
+                    if (!device_ok() || opal_hip_set_device(devices[k])) { rcs[k] = OPAL_ERR_NO_SIMD_SUPPORT; return; }
+                    std::vector<int> sid((size_t)m);  // shard position -> caller index
+                    for (int i = 0; i < m; i++) sid[(size_t)i] = ids ? ids[pos[(size_t)i]] : pos[(size_t)i];
+                    out[k].assign(3 * (size_t)m, 0);
+                    int* s = out[k].data();
+                    rcs[k] = run_shard(devices[k], query, Q, db, dbSeqLengths, sid.data(), m, Go, Ge, M, A, st, mode, s, s + m,
+                                       s + 2 * (size_t)m, nullptr);
+                });
+            }
+            for (auto& th : threads) th.join();
+            if (callerDevice >= 0) opal_hip_set_device(callerDevice);
+            for (size_t k = 0; k < devices.size(); k++) {
+                if (rcs[k] == OPAL_ERR_NO_SIMD_SUPPORT || rcs[k] == OPAL_ERR_INVALID_MODE) return rcs[k];
+                if (rcs[k]) rc = rcs[k];
+                const int m = (int)shard[k].size();
+                for (int i = 0; i < m; i++) {
+                    const int p = shard[k][(size_t)i];
+                    score[p] = out[k][(size_t)i];
+                    endQ[p] = wantEnd ? out[k][(size_t)m + i] : -1;
+                    endT[p] = wantEnd ? out[k][2 * (size_t)m + i] : -1;
+                }
+            }
+        }
+        tC = now_ms();
+        if (rc == OPAL_ERR_NO_SIMD_SUPPORT || rc == OPAL_ERR_INVALID_MODE) return rc;
+        // scatter into the caller's result structs (and, for non-alignment searches, the post-fill of
+        // opal.cpp:1508-1515 in the same pass when the call succeeded)
+        const bool post = clearAlignment && rc == 0;
+        HostPool& pool = HostPool::get();
+        const int tasks = n >= (1 << 14) ? std::min(pool.width(), 32) : 1;
+        pool.parallel_for(tasks, [&](int t) {
+            const int i0 = (int)((long long)n * t / tasks), i1 = (int)((long long)n * (t + 1) / tasks);
+            for (int i = i0; i < i1; i++) {
+                OpalSearchResult* r = results[ids ? ids[i] : i];
+                if (score[i] != INT_MIN) {
+                    r->scoreSet = 1;
+                    r->score = score[i];
+                    r->endLocationQuery = wantEnd ? endQ[i] : -1;
+                    r->endLocationTarget = wantEnd ? endT[i] : -1;
+                }
+                if (post && all) { r->alignment = NULL; r->alignmentLength = -1; r->startLocationQuery = -1; r->startLocationTarget = -1; }
+            }
+        });
         if (debug_on())
-            fprintf(stderr, "[opal] opalSearchDatabase: pack %.2f ms, upload %.2f ms, search+download %.2f ms, free+scatter %.2f ms\n",
-                    t1 - t0, t2 - t1, t3 - t2, now_ms() - t3);
-    } else if (!args_fit_int32(gapOpen, gapExt, scoreMatrix, alphabetLength)) {
+            fprintf(stderr, "[opal] opalSearchDatabase: todo %.2f ms | order %.2f, gather+upload+pack %.2f, search %.2f, download %.2f | "
+                    "scatter %.2f ms\n", tB - tA, tms[0], tms[1], tms[2], tms[3], now_ms() - tC);
+    } else if (!args_fit_int32(Go, Ge, M, A)) {
         rc = OPAL_ERR_OVERFLOW;
     }
     if (rc) return rc;  // alignment fields untouched on error (opal.cpp:1473)
+    if (clearAlignment && !(all && n > 0)) {  // opal.cpp:1508-1515 (already done in the scatter pass when everything was computed)
+        for (int i = 0; i < dbLength; i++) {
+            results[i]->alignment = NULL;
+            results[i]->alignmentLength = -1;
+            results[i]->startLocationQuery = -1;
+            results[i]->startLocationTarget = -1;
+        }
+    }
+    return 0;
+}
 
-    if (searchType == OPAL_SEARCH_ALIGNMENT) {
+}  // namespace
+
+extern "C" int opalSearchDatabase(unsigned char query[], int queryLength, unsigned char* db[], int dbLength,
+                                  int dbSeqLengths[], int gapOpen, int gapExt, int* scoreMatrix, int alphabetLength,
+                                  OpalSearchResult* results[], const int searchType, int mode, int overflowMethod) {
+    (void)overflowMethod;  // OPAL_OVERFLOW_SIMPLE and _BUCKETS give identical results (see search_core)
+    if (mode != OPAL_MODE_NW && mode != OPAL_MODE_HW && mode != OPAL_MODE_OV && mode != OPAL_MODE_SW)
+        return OPAL_ERR_INVALID_MODE;
+    const int rc = search_into_results(query, queryLength, db, dbLength, dbSeqLengths, gapOpen, gapExt, scoreMatrix,
+                                       alphabetLength, results, searchType, mode, searchType != OPAL_SEARCH_ALIGNMENT);
+    if (rc) return rc;
+    if (searchType == OPAL_SEARCH_ALIGNMENT)
         return opalx_find_alignments(query, queryLength, db, dbLength, dbSeqLengths, gapOpen, gapExt, scoreMatrix,
-                                    alphabetLength, results, mode);
-    }
-    for (int i = 0; i < dbLength; i++) {  // opal.cpp:1508-1515
-        results[i]->alignment = NULL;
-        results[i]->alignmentLength = -1;
-        results[i]->startLocationQuery = -1;
-        results[i]->startLocationTarget = -1;
-    }
+                                     alphabetLength, results, mode);
     return 0;
 }
 
@@ -798,20 +1181,17 @@ extern "C" int opalSearchDatabaseCharSW(unsigned char query[], int queryLength, 
         return OPAL_ERR_OVERFLOW;
     }
     if (!device_ok()) return OPAL_ERR_NO_SIMD_SUPPORT;
-    OpalxDb* pdb = opalx_db_create(db, dbLength, dbSeqLengths);
-    if (!pdb) return OPAL_ERR_NO_SIMD_SUPPORT;
-    std::vector<int> score((size_t)dbLength, INT_MIN);
-    int rc = opalx_search_host(pdb, query, queryLength, gapOpen, gapExt, scoreMatrix, alphabetLength, OPAL_SEARCH_SCORE,
-                               OPAL_MODE_SW, OPAL_OVERFLOW_SIMPLE, score.data(), nullptr, nullptr);
-    opalx_db_destroy(pdb);
+    std::vector<int> score((size_t)std::max(dbLength, 1), INT_MIN);
+    int rc = run_shard(opal_hip_get_device(), query, queryLength, db, dbSeqLengths, nullptr, dbLength, gapOpen, gapExt, scoreMatrix,
+                       alphabetLength, OPAL_SEARCH_SCORE, OPAL_MODE_SW, score.data(), nullptr, nullptr, nullptr);
     if (rc == OPAL_ERR_NO_SIMD_SUPPORT) return rc;
     rc = 0;
     for (int i = 0; i < dbLength; i++) {
         // the 8-bit pass represents 0..127: a sequence overflows iff its exact score is >= 128
-        if (score[i] == INT_MIN || score[i] >= 128) {
+        if (score[(size_t)i] == INT_MIN || score[(size_t)i] >= 128) {
             results[i]->score = -1; results[i]->scoreSet = 0; rc = OPAL_ERR_OVERFLOW;
         } else {
-            opalSearchResultSetScore(results[i], score[i]);
+            opalSearchResultSetScore(results[i], score[(size_t)i]);
             results[i]->endLocationQuery = -1; results[i]->endLocationTarget = -1;
         }
     }

@@ -39,6 +39,36 @@ extern "C" void* opal_hip_malloc(size_t bytes) {
 
 extern "C" void opal_hip_free(void* p) { if (p) (void)hipFree(p); }
 
+extern "C" void* opal_hip_host_malloc(size_t bytes) {
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) { fail("hipHostMalloc", e); return nullptr; }
+    return p;
+}
+
+extern "C" void opal_hip_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+extern "C" int opal_hip_get_device(void) {
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) return -1;
+    return d;
+}
+
+extern "C" int opal_hip_memcpy_peer(void* dst, int dst_device, const void* src, int src_device, size_t bytes, void* stream) {
+    hipError_t e = hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : fail("hipMemcpyPeerAsync", e);
+}
+
+extern "C" int opal_hip_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : fail("hipMemcpyAsync(D2D)", e);
+}
+
+extern "C" int opal_hip_memset32(void* dst, int value, size_t count, void* stream) {
+    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)dst, value, count, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : fail("hipMemsetD32Async", e);
+}
+
 extern "C" int opal_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
     hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
     return e == hipSuccess ? 0 : fail("hipMemcpyAsync(H2D)", e);
@@ -59,6 +89,8 @@ extern "C" int opal_hip_stream_sync(void* stream) {
     return e == hipSuccess ? 0 : fail("hipStreamSynchronize", e);
 }
 
+// Non-blocking streams: nothing is ordered against the legacy null stream; the scheduler orders its
+// launches with fork/join events only.
 extern "C" void* opal_hip_stream_create(void) {
     hipStream_t st;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
@@ -120,6 +152,26 @@ extern "C" int opal_hip_pack_tokens(const unsigned char* raw, const uint64_t* ra
     return e == hipSuccess ? 0 : fail("pack kernel launch", e);
 }
 
+// Degenerate shapes (empty targets, empty query) are answered on the host: their values reach the
+// caller-order result arrays through one small scatter instead of one copy per sequence.
+__global__ void opal_scatter_results_kernel(const int* __restrict__ quad, int count, int* __restrict__ score,
+                                            int* __restrict__ endQ, int* __restrict__ endT) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= count) return;
+    const int idx = quad[4 * i];
+    score[idx] = quad[4 * i + 1];
+    if (endQ) endQ[idx] = quad[4 * i + 2];
+    if (endT) endT[idx] = quad[4 * i + 3];
+}
+
+extern "C" int opal_hip_scatter_results(const int* quads, int count, int* score, int* end_query, int* end_target, void* stream) {
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(opal_scatter_results_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, quads, count,
+                       score, end_query, end_target);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("scatter kernel launch", e);
+}
+
 static size_t lds_bytes(int width, int G, int rows, int A) {
     const int es = width == 16 ? 2 : 4;  // width 17 keeps 4-byte profile entries (value in the low half)
     return (size_t)(A + 1) * (size_t)opal_profile_stride(es, G, rows) + 16;
@@ -161,6 +213,16 @@ extern "C" int opal_hip_rows_supported(int width, int mode, int want_end, int mi
     return 0;
 }
 
+// Registers per lane of the kernel that `a` would launch (from the code object, hipFuncGetAttributes):
+// the scheduler derives waves per SIMD from it (512 registers per lane per SIMD, granule 8).
+extern "C" int opal_hip_kernel_vgprs(const OpalHipLaunch* a) {
+    KernelFn fn = pick_kernel(a->width, a->mode, launch_flags(a), a->rows_per_lane);
+    if (!fn) return 0;
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, (const void*)fn) != hipSuccess) return 0;
+    return attr.numRegs;
+}
+
 extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
     const int G = a->lanes_per_seq;
     int log2G = 0;
@@ -197,10 +259,11 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
     p.negPad = a->neg_pad;
     const int slots = 64 / G;
     const int jobs = (a->num_items + slots - 1) / slots;
-    int wpb = WAVES_PER_BLOCK;
-    if (const char* e = getenv("OPAL_HIP_WAVES_PER_BLOCK")) { wpb = atoi(e); if (wpb < 1 || wpb > MAX_WAVES_PER_BLOCK) wpb = WAVES_PER_BLOCK; }
+    int wpb = (a->waves_per_block >= 1 && a->waves_per_block <= MAX_WAVES_PER_BLOCK) ? a->waves_per_block : WAVES_PER_BLOCK;
+    if (const char* e = getenv("OPAL_HIP_WAVES_PER_BLOCK")) { const int w = atoi(e); if (w >= 1 && w <= MAX_WAVES_PER_BLOCK) wpb = w; }
     const int blocks = (jobs + wpb - 1) / wpb;
-    const size_t lds = lds_bytes(a->width, G, a->rows_per_lane, a->alphabet_length);
+    size_t lds = lds_bytes(a->width, G, a->rows_per_lane, a->alphabet_length);
+    if (a->lds_bytes_min > 0 && (size_t)a->lds_bytes_min > lds && a->lds_bytes_min <= 160 * 1024) lds = (size_t)a->lds_bytes_min;
     if (lds > 160 * 1024) {
         snprintf(g_err, sizeof g_err, "query profile needs %zu bytes of LDS (>160 KiB)", lds);
         fprintf(stderr, "[opal-hip] %s\n", g_err);

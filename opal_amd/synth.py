@@ -89,6 +89,99 @@ def database(num_seqs, seed=42, first=0):
     return out, offsets, lens
 
 
+def database_subset(ids, seed=42, lens=None):
+    """The sequences with GLOBAL indices `ids` (any order, any subset) of database `seed`, as
+    (residues, offsets, lens). Used by the multi-GPU sharding (opal_amd/shard.py): a rank owns a
+    length-balanced, non-contiguous set of sequences and generates exactly those."""
+    ids = np.asarray(ids, dtype=np.int64)
+    n = len(ids)
+    if lens is None:
+        lens = np.array([lengths(seed, int(i), 1)[0] for i in ids], dtype=np.int32) if n < 64 else _lengths_of(seed, ids)
+    lens = np.asarray(lens, dtype=np.int32)
+    offsets = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    cdf, codes = _residue_table()
+    out = np.empty(int(offsets[-1]), dtype=np.uint8)
+    rseed = np.uint64(seed ^ 0x5851F42D4C957F2D)
+    batch = 512
+    for a in range(0, n, batch):
+        b = min(a + batch, n)
+        m = int(offsets[b] - offsets[a])
+        loc = np.repeat(np.arange(a, b, dtype=np.int64), lens[a:b])
+        pos = np.arange(m, dtype=np.int64) - (offsets[a:b] - offsets[a])[loc - a]
+        c = (ids[loc] * 5000 + pos).astype(np.uint64)
+        with np.errstate(over="ignore"):
+            z = rseed + (c + np.uint64(1)) * _GOLDEN
+            z = (z ^ (z >> np.uint64(30))) * _M1
+            z = (z ^ (z >> np.uint64(27))) * _M2
+            z = z ^ (z >> np.uint64(31))
+        u = ((z >> np.uint64(11)).astype(np.float64) + 0.5) / 9007199254740992.0
+        out[offsets[a]:offsets[b]] = codes[np.minimum(np.searchsorted(cdf, u, side="right"), len(codes) - 1)]
+    return out, offsets, lens
+
+
+def _lengths_of(seed, ids):
+    """Lengths of the sequences `ids` (computed over the covering contiguous range, in blocks)."""
+    ids = np.asarray(ids, dtype=np.int64)
+    out = np.empty(len(ids), dtype=np.int32)
+    lo, hi = int(ids.min()), int(ids.max()) + 1
+    block = 1 << 20
+    for a in range(lo, hi, block):
+        b = min(a + block, hi)
+        sel = np.nonzero((ids >= a) & (ids < b))[0]
+        if len(sel):
+            out[sel] = lengths(seed, a, b - a)[ids[sel] - a]
+    return out
+
+
+def residues_device(ids, lens, seed, device):
+    """Same residues as database_subset(ids)[0], generated ON THE GPU with torch integer arithmetic
+    (bench.py: a 5-million-sequence shard is 1.7 GB of residues; numpy needs minutes for that).
+    Lengths come from the host (float64 log/cos are not guaranteed bit-identical on the device); the
+    residue stream is pure 64-bit integer arithmetic plus one exact float64 division, so the result is
+    bit-identical to the numpy generator (tests/test_gpu_fullsize.py checks a sample).
+    Returns (uint8 tensor[sum lens] on `device`, int64 numpy offsets)."""
+    import torch
+    ids_t = torch.as_tensor(np.asarray(ids, dtype=np.int64), device=device)
+    lens_np = np.asarray(lens, dtype=np.int64)
+    offsets = np.zeros(len(lens_np) + 1, dtype=np.int64)
+    np.cumsum(lens_np, out=offsets[1:])
+    total = int(offsets[-1])
+    out = torch.empty(total, dtype=torch.uint8, device=device)
+    cdf, codes = _residue_table()
+    cdf_t = torch.as_tensor(cdf, device=device)
+    codes_t = torch.as_tensor(codes, device=device)
+    lens_t = torch.as_tensor(lens_np, device=device)
+    offs_t = torch.as_tensor(offsets, device=device)
+
+    def s64(v):  # two's-complement int64 view of a uint64 constant
+        v = int(v) & 0xFFFFFFFFFFFFFFFF
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    def lsr(x, k):  # logical shift right on int64
+        return (x >> k) & ((1 << (64 - k)) - 1)
+
+    G, M1, M2 = s64(_GOLDEN), s64(_M1), s64(_M2)
+    rseed = s64(seed ^ 0x5851F42D4C957F2D)
+    batch = 1 << 16  # sequences per step (temporaries: a few hundred MB at most)
+    for a in range(0, len(lens_np), batch):
+        b = min(a + batch, len(lens_np))
+        m = int(offsets[b] - offsets[a])
+        if m == 0:
+            continue
+        loc = torch.repeat_interleave(torch.arange(a, b, device=device), lens_t[a:b])
+        pos = torch.arange(m, device=device, dtype=torch.int64) - (offs_t[loc] - int(offsets[a]))
+        c = ids_t[loc] * 5000 + pos
+        z = rseed + (c + 1) * G
+        z = (z ^ lsr(z, 30)) * M1
+        z = (z ^ lsr(z, 27)) * M2
+        z = z ^ lsr(z, 31)
+        u = (lsr(z, 11).to(torch.float64) + 0.5) / 9007199254740992.0
+        idx = torch.clamp(torch.searchsorted(cdf_t, u, right=True), max=len(codes) - 1)
+        out[int(offsets[a]):int(offsets[b])] = codes_t[idx]
+    return out, offsets
+
+
 def query(length, seed=7):
     """uint8[length] synthetic query drawn from the same background distribution."""
     return _residues(seed, 0, length)

@@ -1,6 +1,7 @@
-"""world_size-2 test of the multi-rank path on CPU (gloo): each rank owns a shard of the same synthetic
-database, computes its shard's scores (with the CPU oracle standing in for the device search, which needs
-a GPU), and rank 0 receives every score with one gather, in database order."""
+"""world_size-2 tests of the multi-rank plumbing on CPU (gloo): the residue-balanced deal, the padded
+single gather and the permutation back to database order. The device search needs a GPU, so here the CPU
+oracle stands in for it (the same ranks running the real device search are covered by
+tests/test_gpu_fullsize.py::test_two_rank_bench_on_one_gpu)."""
 import os
 import socket
 
@@ -52,6 +53,66 @@ def test_two_rank_shard_and_gather(tmp_path, oracle):
     db = [res[offs[i]:offs[i + 1]] for i in range(world * N_PER_RANK)]
     rc, want, _, _ = oracle.search(synth.query(QLEN, seed=7), db, 11, 1, blosum50()[1], 0, oracle_lib.MODE_SW)
     np.testing.assert_array_equal(got, want)
+
+
+def _worker_balanced(rank, world, port, out_path, total):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    all_lens = synth.lengths(42, 0, total)
+    owned_lists = shard.deal(all_lens, world)
+    owned = owned_lists[rank]
+    npad = max(len(o) for o in owned_lists)
+    res, offs, lens = synth.database_subset(owned, 42, lens=all_lens[owned])
+    db = [res[offs[i]:offs[i + 1]] for i in range(len(owned))]
+    rc, s, eq, et = oracle_lib.Oracle().search(synth.query(QLEN, seed=7), db, 11, 1, blosum50()[1], 0, oracle_lib.MODE_SW)
+    assert rc == 0
+    block = torch.zeros(npad, dtype=torch.int32)
+    block[: len(owned)] = torch.from_numpy(s.copy())
+    gathered = shard.gather_results(block, world, rank)
+    dist.barrier()
+    if rank == 0:
+        np.save(out_path, shard.scatter_to_global(gathered, owned_lists, total).numpy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_balanced_deal_and_gather(tmp_path, oracle):
+    """The bench path's sharding: non-contiguous, residue-balanced shards, padded gather, permutation back."""
+    world, total = 2, 200
+    out = str(tmp_path / "scores_balanced.npy")
+    mp.spawn(_worker_balanced, args=(world, _free_port(), out, total), nprocs=world, join=True)
+    got = np.load(out)
+    res, offs, lens = synth.database(total, seed=42)
+    db = [res[offs[i]:offs[i + 1]] for i in range(total)]
+    rc, want, _, _ = oracle.search(synth.query(QLEN, seed=7), db, 11, 1, blosum50()[1], 0, oracle_lib.MODE_SW)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_deal_balances_residues_and_partitions():
+    lens = synth.lengths(42, 0, 50000)
+    for world in (1, 2, 4, 8):
+        owned = shard.deal(lens, world)
+        allidx = np.sort(np.concatenate(owned))
+        assert (allidx == np.arange(len(lens))).all()           # a partition
+        loads = np.array([lens[o].astype(np.int64).sum() for o in owned])
+        assert loads.max() - loads.min() <= 64 * 5000             # within one group of the longest sequences
+        assert loads.max() / loads.mean() < 1.01
+        for o in owned:                                           # every shard longest-first
+            assert (np.diff(lens[o].astype(np.int64)) <= 0).all()
+    # deterministic
+    a, b = shard.deal(lens, 4), shard.deal(lens, 4)
+    assert all((x == y).all() for x, y in zip(a, b))
+
+
+def test_database_subset_matches_contiguous_generation():
+    r, o, l = synth.database(400, 42, first=1000)
+    ids = np.random.RandomState(0).permutation(400)[:120] + 1000
+    r2, o2, l2 = synth.database_subset(ids, 42)
+    for k, g in enumerate(ids):
+        i = g - 1000
+        assert l2[k] == l[i] and (r2[o2[k]:o2[k + 1]] == r[o[i]:o[i + 1]]).all()
+    rt, ot = synth.residues_device(ids, l2, 42, "cpu")
+    assert (rt.numpy() == r2).all() and (ot == o2).all()
 
 
 def test_shard_bounds_cover_everything():

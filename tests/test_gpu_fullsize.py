@@ -1,5 +1,7 @@
 """BASELINE.json-sized runs on the GPU, checked through size-independent properties and a sampled
 oracle comparison (the oracle cannot finish 1e10 cells in seconds)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -67,3 +69,193 @@ def test_c2_order_independence_and_gaps(c2):
     planted = seqs[:50] + [c2["q"].copy()]
     rc, s, eq, et = PreparedDb.from_sequences(planted).search(c2["q"], 11, 1, c2["m"], 1, 3)
     assert s[-1] == int(c2["m"][c2["q"], c2["q"]].sum()) and (eq[-1], et[-1]) == (299, 299)
+
+
+def _sample(lens, n_random, seed=1, n_edge=40):
+    order = np.argsort(lens, kind="stable")
+    rng = np.random.RandomState(seed)
+    return np.unique(np.concatenate([order[:n_edge], order[-n_edge:], rng.choice(len(lens), n_random, replace=False)]))
+
+
+def test_c2_score_only_is_the_kernel_the_bench_times(c2, oracle):
+    """BASELINE.json configs[1] exactly as stated: SW SCORE-ONLY on 100 000 sequences (the instantiation bench.py
+    times, opal_dp_kernel<17,SW,0,S>), both gap settings of SURVEY.md 8d. Every score must equal the score of the
+    score+end instantiation, and a sample must equal the oracle."""
+    pdb, q, m = c2["pdb"], c2["q"], c2["m"]
+    pick = _sample(c2["lens"], 300)
+    db = [c2["res"][c2["offs"][i]:c2["offs"][i + 1]] for i in pick]
+    for go in (11, 3):
+        rc0, s0, eq0, et0 = pdb.search(q, go, 1, m, 0, oracle_lib.MODE_SW)
+        rc1, s1, eq1, et1 = pdb.search(q, go, 1, m, 1, oracle_lib.MODE_SW)
+        assert rc0 == rc1 == 0
+        np.testing.assert_array_equal(s0, s1)
+        assert (eq0 == -1).all() and (et0 == -1).all()  # score-only leaves end locations at -1 (opal.cpp:423-426)
+        orc, so, _, _ = oracle.search(q, db, go, 1, m, 0, oracle_lib.MODE_SW)
+        assert orc == 0
+        np.testing.assert_array_equal(s0[pick], so)
+        assert (s0 > 0).all()
+
+
+def test_device_generator_matches_numpy():
+    import torch
+    from opal_amd import synth
+    ids = np.random.RandomState(2).choice(5000000, 3000, replace=False)
+    lens = synth._lengths_of(42, ids)
+    res, offs, _ = synth.database_subset(ids, 42, lens=lens)
+    d, o = synth.residues_device(ids, lens, 42, torch.device("cuda", 0))
+    assert (o == offs).all() and (d.cpu().numpy() == res).all()
+
+
+@pytest.fixture(scope="module")
+def c4shard():
+    """One rank's share of BASELINE.json configs[3]: 5 000 000 synthetic sequences dealt to 8 GPUs (625 000 here)."""
+    import torch
+    from opal_amd import shard, synth
+    from opal_amd.api import PreparedDb
+    from opal_amd.fasta import read_fasta
+    from opal_amd.score_matrix import blosum50
+    import cases
+    all_lens = synth.lengths(42, 0, 5000000)
+    owned = shard.deal(all_lens, 8)[3]
+    lens = all_lens[owned]
+    d_res, offs = synth.residues_device(owned, lens, 42, torch.device("cuda", 0))
+    torch.cuda.synchronize()
+    q = read_fasta(os.path.join(cases.DATA, "query_P18080.fasta"), blosum50()[0])[0]
+    pdb = PreparedDb(None, offs, device_ptr=d_res.data_ptr())
+    return dict(owned=owned, lens=lens, offs=offs, q=q, m=blosum50()[1], pdb=pdb, keep=d_res)
+
+
+def test_c4_shard_all_modes(c4shard, oracle):
+    """P18080 (513 aa) x a 625 000-sequence shard, all four modes with end locations + SW score-only:
+    size-independent properties on everything, bit-exact oracle comparison on a sample."""
+    from opal_amd import synth
+    pdb, q, m, lens, owned = c4shard["pdb"], c4shard["q"], c4shard["m"], c4shard["lens"], c4shard["owned"]
+    Q = len(q)
+    assert Q == 513 and 600000 < len(owned) < 650000
+    out = {}
+    for mode in ("SW", "OV", "HW", "NW"):
+        rc, s, eq, et = pdb.search(q, 3, 1, m, 1, oracle_lib.MODES[mode])
+        assert rc == 0, mode
+        out[mode] = (s, eq, et)
+    rc, s0, _, _ = pdb.search(q, 3, 1, m, 0, oracle_lib.MODE_SW)
+    assert rc == 0
+    np.testing.assert_array_equal(s0, out["SW"][0])
+    assert (out["SW"][0] >= out["OV"][0]).all() and (out["OV"][0] >= out["HW"][0]).all() and (out["HW"][0] >= out["NW"][0]).all()
+    assert (out["NW"][1] == Q - 1).all() and (out["NW"][2] == lens - 1).all() and (out["HW"][1] == Q - 1).all()
+    for mode in out:
+        s, eq, et = out[mode]
+        live = s != 0 if mode == "SW" else np.ones(len(s), bool)
+        assert (eq[live] >= 0).all() and (eq[live] < Q).all() and (et[live] >= 0).all() and (et[live] < lens[live]).all()
+    pick = _sample(lens, 200, seed=4, n_edge=30)
+    res, offs, _ = synth.database_subset(owned[pick], 42, lens=lens[pick])
+    db = [res[offs[i]:offs[i + 1]] for i in range(len(pick))]
+    for mode in out:
+        rc, s, eq, et = oracle.search(q, db, 3, 1, m, 1, oracle_lib.MODES[mode])
+        np.testing.assert_array_equal(out[mode][0][pick], s, err_msg=mode)
+        np.testing.assert_array_equal(out[mode][1][pick], eq, err_msg=mode)
+        np.testing.assert_array_equal(out[mode][2][pick], et, err_msg=mode)
+
+
+def test_c5_long_query_buckets(oracle):
+    """BASELINE.json configs[4]: a 2000-aa query (16-bit rung, then the 32-bit re-run) on 100 000 sequences,
+    OPAL_OVERFLOW_BUCKETS. BLOSUM50 cannot push a 2000-aa alignment past 16 bits, so the forced
+    overflow comes from planted self-matches under a x3-scaled matrix, as the survey prescribes."""
+    from opal_amd import synth
+    from opal_amd.api import PreparedDb
+    from opal_amd.score_matrix import blosum50
+    n = 100000
+    res, offs, lens = synth.database(n, seed=42)
+    q = synth.query(2000, seed=7)
+    m = blosum50()[1]
+    pdb = PreparedDb(res, offs)
+    pick = _sample(lens, 60, seed=5, n_edge=10)
+    db = [res[offs[i]:offs[i + 1]] for i in pick]
+    out = {}
+    for mode in ("SW", "OV", "HW", "NW"):
+        rc, s, eq, et = pdb.search(q, 3, 1, m, 1, oracle_lib.MODES[mode], overflow_method=1)
+        assert rc == 0, mode
+        out[mode] = s
+        orc, so, oq, ot = oracle.search(q, db, 3, 1, m, 1, oracle_lib.MODES[mode])
+        np.testing.assert_array_equal(s[pick], so, err_msg=mode)
+        np.testing.assert_array_equal(eq[pick], oq, err_msg=mode)
+        np.testing.assert_array_equal(et[pick], ot, err_msg=mode)
+    assert (out["SW"] >= out["OV"]).all() and (out["OV"] >= out["HW"]).all() and (out["HW"] >= out["NW"]).all()
+    rc, s0, _, _ = pdb.search(q, 3, 1, m, 0, oracle_lib.MODE_SW, overflow_method=1)
+    np.testing.assert_array_equal(s0, out["SW"])
+    # forced 16 -> 32 bit: x3 matrix, the query itself (and two mutilated copies) planted among 3000 sequences
+    m3 = (m * 3).astype(np.int32)
+    seqs = [res[offs[i]:offs[i + 1]] for i in range(3000)]
+    planted = {17: q.copy(), 1501: q[:1700].copy(), 2999: np.concatenate([q[300:], q[:50]])}
+    for k, v in planted.items():
+        seqs[k] = v
+    rc, s, eq, et = PreparedDb.from_sequences(seqs).search(q, 11, 1, m3, 1, oracle_lib.MODE_SW, overflow_method=1)
+    assert rc == 0
+    self_score = int(m3[q, q].sum())
+    assert self_score > 32767 and s[17] == self_score and (eq[17], et[17]) == (1999, 1999)
+    chk = sorted(planted) + [0, 1, 2, 1000, 2000]
+    orc, so, oq, ot = oracle.search(q, [seqs[i] for i in chk], 11, 1, m3, 1, oracle_lib.MODE_SW)
+    np.testing.assert_array_equal(s[chk], so)
+    np.testing.assert_array_equal(eq[chk], oq)
+    np.testing.assert_array_equal(et[chk], ot)
+    assert (s[sorted(planted)] > 32767).all()
+
+
+def _run_bench(extra, env_extra=None):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+def test_two_rank_bench_on_one_gpu():
+    """The N>1 path of bench.py with the REAL device search: `--gpus 2` starts two ranks by itself (both on GPU 0 here,
+    results gathered through gloo); the gathered, re-ordered scores must equal the one-rank run's (same global database)."""
+    common = ["--total-seqs", "30000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e"]
+    one = _run_bench(["--gpus", "1"] + common)
+    two = _run_bench(["--gpus", "2"] + common, {"BENCH_SHARE_GPU": "1", "BENCH_BACKEND": "gloo"})
+    assert one["verified"] and two["verified"]
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert one["verify"]["score_crc32"] == two["verify"]["score_crc32"]
+    assert one["roofline"]["bound"] == "valu-issue" and 0 < one["roofline"]["frac"] < 1
+
+
+def test_api_context_reuse_and_multi_device(oracle):
+    """opalSearchDatabase keeps its device buffers between calls (cached contexts) and can shard one call over
+    several GPUs (OPAL_HIP_DEVICES; "0,0" = two contexts on this box's one GPU): growing and shrinking databases,
+    interleaved modes, and the sharded call must all give the single-call answers."""
+    import opal_amd
+    from opal_amd import synth
+    from opal_amd.score_matrix import blosum50
+    m = blosum50()[1]
+    q = synth.query(180, seed=7)
+    want = {}
+    for n, first in ((500, 0), (6000, 1000), (64, 9000), (3000, 20000)):
+        res, offs, lens = synth.database(n, seed=42, first=first)
+        db = [res[offs[i]:offs[i + 1]] for i in range(n)]
+        for mode in ("SW", "NW"):
+            rc, results = opal_amd.search_database(q, db, 3, 1, m, opal_amd.OPAL_SEARCH_SCORE_END, opal_amd.MODES[mode])
+            assert rc == 0
+            got = opal_amd.result_fields(results, "score", "endLocationQuery", "endLocationTarget")
+            pick = np.arange(0, n, max(1, n // 100))
+            orc, so, oq, ot = oracle.search(q, [db[i] for i in pick], 3, 1, m, 1, opal_amd.MODES[mode])
+            np.testing.assert_array_equal(got[0][pick], so)
+            np.testing.assert_array_equal(got[1][pick], oq)
+            np.testing.assert_array_equal(got[2][pick], ot)
+            want[(n, mode)] = got
+    os.environ["OPAL_HIP_DEVICES"] = "0,0"
+    try:
+        res, offs, lens = synth.database(6000, seed=42, first=1000)
+        db = [res[offs[i]:offs[i + 1]] for i in range(6000)]
+        for mode in ("SW", "NW"):
+            rc, results = opal_amd.search_database(q, db, 3, 1, m, opal_amd.OPAL_SEARCH_SCORE_END, opal_amd.MODES[mode])
+            assert rc == 0
+            got = opal_amd.result_fields(results, "score", "endLocationQuery", "endLocationTarget")
+            for a, b in zip(got, want[(6000, mode)]):
+                np.testing.assert_array_equal(a, b)
+    finally:
+        del os.environ["OPAL_HIP_DEVICES"]
