@@ -135,6 +135,26 @@ void opal_hip_event_destroy(void* ev);
 int opal_hip_event_record(void* ev, void* stream);
 float opal_hip_event_elapsed_ms(void* start, void* stop); /* synchronises on `stop` */
 
+/* Start locations on the device (rev_kernel.hip): for every listed sequence, the score-limited reverse pass of
+   reference src/opal.cpp:1475-1507 from its end cell. All pointers are device pointers. */
+typedef struct OpalHipRevLaunch {
+    int mode;                     /* OPAL_MODE_* of the search that produced score / end */
+    const unsigned char* query; int query_length;
+    const int* score_matrix; int alphabet_length;
+    int gap_open, gap_ext;
+    const uint16_t* tokens; const uint64_t* pair_token_offset;
+    const int* seq_item;          /* [N] caller index -> pair*2 + half in the packed database */
+    const int* items; int num_items;   /* caller indices to process (NULL: 0..num_items-1) */
+    const int* score; const int* end_query; const int* end_target;   /* [N], caller order */
+    int* start_query; int* start_target;                             /* [N], caller order */
+    int* flags;                   /* [2], zeroed by the caller: [0] length of `redo`, [1] sequences with no start found */
+    int* redo;                    /* [N] sequences whose start the host must recompute (see rev_kernel.hip) */
+    void* stream;
+} OpalHipRevLaunch;
+/* rows per lane the reverse kernel would use for this query length (0: longer than 64 x 40 rows, unsupported) */
+int opal_hip_rev_rows_supported(int query_length);
+int opal_hip_rev_launch(const OpalHipRevLaunch* args);
+
 /* ------------------------------------------------------------------ part 2 */
 
 typedef struct OpalxDb OpalxDb; /* opaque: packed database resident in device memory */
@@ -177,10 +197,32 @@ int opalx_search_host(OpalxDb* db, const unsigned char* query, int query_length,
  * start location and alignment operations, exactly as OPAL_SEARCH_ALIGNMENT does after the search
  * (reference src/opal.cpp:1475-1507, findAlignment :1236-1431). `alignment` is malloc()ed.
  */
+#define OPALX_ERR_NO_MEMORY 4   /* additive error code: the host traceback could not allocate its matrix */
 struct OpalSearchResult;
 int opalx_find_alignments(unsigned char query[], int query_length, unsigned char* db[], int db_length,
                           int db_seq_lengths[], int gap_open, int gap_ext, int* score_matrix, int alphabet_length,
                           struct OpalSearchResult* results[], int mode);
+
+/* The same with start cells already known for some sequences (start_query[i] / start_target[i] >= 0, e.g. from
+   opalx_search_starts): only the box between start and end is traced for those. NULL arrays or negative
+   entries mean "find it" (the full score-limited reverse pass on the host). */
+int opalx_find_alignments_from(unsigned char query[], int query_length, unsigned char* db[], int db_length,
+                               int db_seq_lengths[], int gap_open, int gap_ext, int* score_matrix, int alphabet_length,
+                               struct OpalSearchResult* results[], int mode, const int* start_query, const int* start_target);
+
+/*
+ * Start locations of alignments, computed on the device (rev_kernel.hip; reference src/opal.cpp:1475-1507):
+ * d_score / d_end_query / d_end_target are the device arrays a search with OPAL_SEARCH_SCORE_END on the same
+ * database, query, gaps, matrix and mode has filled; d_start_query / d_start_target (db_length ints each)
+ * receive the start cells in caller order (-1: no alignment). `redo` (host, capacity db_length, may be NULL) receives
+ * the indices whose start is not reliable and must be found by the host pass (opalx_find_alignments_from with a
+ * negative start) -- empty in practice; *redo_count their number. Returns 0, OPAL_ERR_NO_SIMD_SUPPORT when the
+ * query is longer than the kernel supports (2560 rows).
+ */
+int opalx_search_starts(OpalxDb* db, const unsigned char* query, int query_length, int gap_open, int gap_ext,
+                        const int* score_matrix, int alphabet_length, int mode,
+                        const int* d_score, const int* d_end_query, const int* d_end_target,
+                        int* d_start_query, int* d_start_target, int* redo, int* redo_count);
 
 #ifdef __cplusplus
 }

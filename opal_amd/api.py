@@ -139,6 +139,20 @@ class PreparedDb:
                                             C.byref(ms))
         return rc, ms.value
 
+    def search_starts_device(self, query, gap_open, gap_ext, score_matrix, mode, d_score, d_end_q, d_end_t, d_start_q, d_start_t):
+        """opalx_search_starts: start cells on the device from the score / end-cell arrays a SCORE_END search of the
+        same query left in device memory (raw pointers). Returns (rc, redo) -- `redo` = indices the host must redo."""
+        q = _u8(query)
+        m = np.ascontiguousarray(score_matrix, dtype=np.int32)
+        redo = np.zeros(max(self.num_sequences, 1), np.int32)
+        cnt = C.c_int(0)
+        rc = _lib.lib().opalx_search_starts(self._h, q.ctypes.data_as(C.POINTER(C.c_ubyte)), len(q), int(gap_open), int(gap_ext),
+                                            m.ctypes.data_as(C.POINTER(C.c_int)), int(m.shape[0]), int(mode),
+                                            C.c_void_p(d_score), C.c_void_p(d_end_q), C.c_void_p(d_end_t),
+                                            C.c_void_p(d_start_q), C.c_void_p(d_start_t),
+                                            redo.ctypes.data_as(C.POINTER(C.c_int)), C.byref(cnt))
+        return rc, redo[: cnt.value].copy()
+
     def search(self, query, gap_open, gap_ext, score_matrix, search_type=OPAL_SEARCH_SCORE, mode=OPAL_MODE_SW,
                overflow_method=OPAL_OVERFLOW_BUCKETS):
         """Host-array convenience: returns (rc, score, endQ, endT) int32 arrays."""

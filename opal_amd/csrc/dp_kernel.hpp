@@ -427,7 +427,12 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
             reg diag = diagIn;
             reg f = inF;
             reg h = 0;
-            reg cm = 0;  // SW second pass: this column's maximum over my rows
+            // SW with end location: this column's maximum over my rows, kept per block of 8 rows so that the row scan
+            // below only has to look inside the block that holds it
+            constexpr int NB = (S + 7) / 8;
+            reg cmb[NB];
+#pragma unroll
+            for (int b = 0; b < NB; b++) cmb[b] = 0;
             if constexpr (WIDTH == 17) {
                 // Plain 16-bit path: profile reads run one block of 4 rows ahead, the diagonal add of row
                 // j+1 is issued before row j's block so that H[j][c-1]'s register is free for H[j][c].
@@ -445,7 +450,7 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
                         if (j < S) {
                             reg dn = 0;
                             if (j + 1 < S) dn = V::adds(Hp[j], P[i + 1]);  // diagonal of the next row: last use of H[j][c-1]
-                            if (MODE == MODE_SW) V::row_sw(d, En[j], f, SWEND ? cm : mx, h, Qv, Rv);
+                            if (MODE == MODE_SW) V::row_sw(d, En[j], f, SWEND ? cmb[j / 8] : mx, h, Qv, Rv);
                             else if (SKEW) V::row_skew(d, En[j], f, h, GQv);
                             else V::row_global(d, En[j], f, h, Qv, Rv);
                             Hp[j] = h;
@@ -489,7 +494,7 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
                         reg hq;
                         if (MODE == MODE_SW) {
                             // E, F are kept >= 0 by unsigned saturation, so H >= 0 needs no extra max
-                            if (SWEND) cm = V::maxs(cm, h); else mx = V::maxs(mx, h);
+                            if (SWEND) cmb[j / 8] = V::maxs(cmb[j / 8], h); else mx = V::maxs(mx, h);
                             hq = V::subu(h, Qv);
                             En[j] = V::maxs(V::subu(e, Rv), hq);
                             f = V::maxs(V::subu(f, Rv), hq);
@@ -511,7 +516,12 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
             if (MODE == MODE_SW && SWEND) {
                 // End location in the same pass. cm = this column's maximum over my rows. Only a STRICT
                 // improvement of my running maximum can be the first cell holding the final score
-                // (smallest column first, opal.h:44-45); the row scan below runs for those columns only.
+                // (smallest column first, opal.h:44-45); the row scan below runs for those columns only, and only
+                // inside the 8-row blocks whose maximum is the column's (some lane of a wave improves in almost
+                // every column, so the scan's cost is per step, not per improvement).
+                reg cm = cmb[0];
+#pragma unroll
+                for (int b = 1; b < NB; b++) cm = V::maxs(cm, cmb[b]);
                 const reg nm = V::maxs(mx, cm);
                 bool improved = false;
 #pragma unroll
@@ -523,8 +533,13 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
                         if (cv > V::half(mx, hh)) {
                             int r = 0;
 #pragma unroll
-                            for (int j = S - 1; j >= 0; j--)
-                                if (V::same(Hp[j], cm, hh)) r = j;  // smallest row of the column holding it
+                            for (int b = NB - 1; b >= 0; b--) {  // descending: the smallest block (then row) holding it wins
+                                if (V::same(cmb[b], cm, hh)) {
+#pragma unroll
+                                    for (int j = (8 * b + 8 < S ? 8 * b + 8 : S) - 1; j >= 8 * b; j--)
+                                        if (V::same(Hp[j], cm, hh)) r = j;
+                                }
+                            }
                             endRow[hh] = r0 + r;
                             endCol[hh] = c;
                         }

@@ -165,6 +165,11 @@ struct OpalxDb {
     DevBuf<int> quads;               // degenerate results on their way to the scatter kernel
     DevBuf<unsigned char> query;
     DevBuf<int> matrix;
+    // start-location pass (rev_kernel.hip): caller index -> pair*2+half, flags and the host-redo list
+    DevBuf<int> seqItem;
+    bool seqItemValid = false;
+    DevBuf<int> revFlags;
+    DevBuf<int> redo;
     // staging used while (re)filling the database
     DevBuf<unsigned char> raw;
     DevBuf<uint64_t> rawOff;
@@ -220,6 +225,7 @@ static void db_release(OpalxDb* db) {
     db->tokens.release(); db->pairOff.release(); db->dPairLen.release(); db->dPairSeq.release();
     db->ovfCount.release(); db->ovfItems.release(); db->boundary.release(); db->scratch.release();
     db->results.release(); db->quads.release(); db->query.release(); db->matrix.release();
+    db->seqItem.release(); db->revFlags.release(); db->redo.release();
     db->raw.release(); db->rawOff.release(); db->hRaw.release(); db->hResults.release();
     for (void*& st : db->streams) { opal_hip_stream_destroy(st); st = nullptr; }
     opal_hip_stream_destroy(db->mainStream); db->mainStream = nullptr;
@@ -247,6 +253,7 @@ static bool db_fill(OpalxDb* db, HostPack& hp, RawKind kind, const std::function
     db->pairSeq.swap(hp.pairSeq);
     db->emptySeqs.swap(hp.emptySeqs);
     db->numTokens = hp.numTokens + 8;
+    db->seqItemValid = false;
     const double slack = db->cached ? 1.15 : 1.0;
     void* st = db->main();
     bool ok = st && db->tokens.ensure(db->numTokens, slack) && db->pairOff.ensure(P, slack) && db->dPairLen.ensure(2 * P, slack) &&
@@ -694,7 +701,8 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
 
     long long maxS = 0, minS = 0;
     for (int i = 0; i < A * A; i++) { maxS = std::max<long long>(maxS, M[i]); minS = std::min<long long>(minS, M[i]); }
-    const bool fits16 = Go <= 32767 && Ge <= 32767 && maxS <= 32767 && minS >= -32768;
+    bool fits16 = Go <= 32767 && Ge <= 32767 && maxS <= 32767 && minS >= -32768;
+    if (const char* e = getenv("OPAL_HIP_FORCE_WIDTH")) { if (atoi(e) == 32) fits16 = false; }  // test / profiling hook
 
     // Narrow rung: 17 = plain 16-bit, one sequence per lane (full-rate VALU, 4-byte LDS profile entries);
     // 16 = packed pairs (half-rate VALU, 2-byte entries: used when the wider profile does not fit LDS).
@@ -812,6 +820,50 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
     return rc;
 }
 
+// Start cells on the device for every sequence of `db` (see include/opal_hip.h, opalx_search_starts).
+static int search_starts(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, const int* M, int A, int mode,
+                         const int* dScore, const int* dEndQ, const int* dEndT, int* dStartQ, int* dStartT, int* redoHost,
+                         int* redoCount) {
+    if (redoCount) *redoCount = 0;
+    const int n = db->numSeqs;
+    if (n <= 0) return 0;
+    if (Q < 1 || !opal_hip_rev_rows_supported(Q) || (size_t)(A + 1) * A * sizeof(int) > 64 * 1024) return OPAL_ERR_NO_SIMD_SUPPORT;
+    void* st = db->main();
+    if (!st) return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (!db->seqItemValid) {
+        std::vector<int> inv((size_t)n, 0);
+        for (size_t i = 0; i < db->pairSeq.size(); i++)
+            if (db->pairSeq[i] >= 0) inv[(size_t)db->pairSeq[i]] = (int)i;
+        if (!db->seqItem.ensure((size_t)n, db->cached ? 1.15 : 1.0)) return OPAL_ERR_NO_SIMD_SUPPORT;
+        if (opal_hip_memcpy_h2d(db->seqItem.p, inv.data(), (size_t)n * sizeof(int), st) || opal_hip_stream_sync(st))
+            return OPAL_ERR_NO_SIMD_SUPPORT;
+        db->seqItemValid = true;
+    }
+    if (!db->revFlags.ensure(2) || !db->redo.ensure((size_t)n, db->cached ? 1.15 : 1.0)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (ensure_query_buffers(db, query, Q, M, A)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (opal_hip_memset(db->revFlags.p, 0, 2 * sizeof(int), st)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    OpalHipRevLaunch a;
+    memset(&a, 0, sizeof a);
+    a.mode = mode; a.query = db->query.p; a.query_length = Q; a.score_matrix = db->matrix.p; a.alphabet_length = A;
+    a.gap_open = Go; a.gap_ext = Ge;
+    a.tokens = db->tokens.p; a.pair_token_offset = db->pairOff.p; a.seq_item = db->seqItem.p;
+    a.items = nullptr; a.num_items = n;
+    a.score = dScore; a.end_query = dEndQ; a.end_target = dEndT;
+    a.start_query = dStartQ; a.start_target = dStartT; a.flags = db->revFlags.p; a.redo = db->redo.p;
+    a.stream = st;
+    if (opal_hip_rev_launch(&a)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    int flags[2] = {0, 0};
+    if (opal_hip_memcpy_d2h(flags, db->revFlags.p, sizeof flags, st) || opal_hip_stream_sync(st)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    // empty sequences have no token stream and no end cell: nothing to start from (the kernel saw endT = -1)
+    if (flags[0] > 0 && redoHost) {
+        if (opal_hip_memcpy_d2h(redoHost, db->redo.p, (size_t)flags[0] * sizeof(int), st) || opal_hip_stream_sync(st))
+            return OPAL_ERR_NO_SIMD_SUPPORT;
+    }
+    if (redoCount) *redoCount = flags[0];
+    if (debug_on()) fprintf(stderr, "[opal] start locations on the device: %d sequences, %d to redo on the host, %d not found\n", n, flags[0], flags[1]);
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------ devices of a call
 // OPAL_HIP_DEVICES = "all" | "0,1,2,..." makes opalSearchDatabase shard every call over those GPUs. A device
 // may be listed more than once (two contexts on one GPU): that is how the sharding is tested on a one-GPU box.
@@ -866,7 +918,7 @@ static std::vector<std::vector<int>> deal_groups(const int* lens, int n, int par
  */
 static int run_shard(int device, const unsigned char* query, int Q, unsigned char* const* db, const int* dbLens, const int* ids,
                      int n, int Go, int Ge, const int* M, int A, int searchType, int mode, int* score, int* endQ, int* endT,
-                     double* tms) {
+                     double* tms, int* startQ = nullptr, int* startT = nullptr) {
     BorrowedContext ctx(device);
     OpalxDb* pdb = ctx.db;
     if (!pdb) return OPAL_ERR_NO_SIMD_SUPPORT;
@@ -885,7 +937,7 @@ static int run_shard(int device, const unsigned char* query, int Q, unsigned cha
     const double t2 = now_ms();
     const size_t nn = (size_t)std::max(n, 1);
     const int wantEnd = searchType != OPAL_SEARCH_SCORE;
-    if (!pdb->results.ensure(3 * nn, 1.15) || !pdb->hResults.ensure(3 * nn, 1.15)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (!pdb->results.ensure(5 * nn, 1.15) || !pdb->hResults.ensure(5 * nn, 1.15)) return OPAL_ERR_NO_SIMD_SUPPORT;
     int* dS = pdb->results.p; int* dQ = dS + nn; int* dT = dS + 2 * nn;
     void* st = pdb->main();
     // INT_MIN marks "not written by the search" (a sequence the search had to give up on)
@@ -894,9 +946,28 @@ static int run_shard(int device, const unsigned char* query, int Q, unsigned cha
     const double t3 = now_ms();
     if (rc == OPAL_ERR_NO_SIMD_SUPPORT || rc == OPAL_ERR_INVALID_MODE) return rc;
     int* h = pdb->hResults.p;
-    if (opal_hip_memcpy_d2h(h, dS, (wantEnd ? 3 : 1) * nn * sizeof(int), st) || opal_hip_stream_sync(st)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    // start cells for the alignment search, on the device while the end cells are still there (n4). Any failure
+    // just leaves them unknown (INT_MIN): the host traceback then finds them with its own full pass.
+    bool haveStarts = false;
+    std::vector<int> redo;
+    int nredo = 0;
+    if (startQ && startT && rc == 0 && wantEnd && n > 0 && !getenv("OPAL_HIP_HOST_STARTS")) {
+        redo.resize((size_t)n);
+        haveStarts = search_starts(pdb, query, Q, Go, Ge, M, A, mode, dS, dQ, dT, dS + 3 * nn, dS + 4 * nn, redo.data(), &nredo) == 0;
+    }
+    if (opal_hip_memcpy_d2h(h, dS, (haveStarts ? 5 : wantEnd ? 3 : 1) * nn * sizeof(int), st) || opal_hip_stream_sync(st))
+        return OPAL_ERR_NO_SIMD_SUPPORT;
     memcpy(score, h, (size_t)n * sizeof(int));
     if (wantEnd) { memcpy(endQ, h + nn, (size_t)n * sizeof(int)); memcpy(endT, h + 2 * nn, (size_t)n * sizeof(int)); }
+    if (startQ && startT) {
+        if (haveStarts) {
+            memcpy(startQ, h + 3 * nn, (size_t)n * sizeof(int)); memcpy(startT, h + 4 * nn, (size_t)n * sizeof(int));
+            for (int i = 0; i < nredo; i++) { startQ[redo[(size_t)i]] = INT_MIN; startT[redo[(size_t)i]] = INT_MIN; }
+            for (int i = 0; i < n; i++) if (score[i] == INT_MIN) { startQ[i] = INT_MIN; startT[i] = INT_MIN; }
+        } else {
+            for (int i = 0; i < n; i++) { startQ[i] = INT_MIN; startT[i] = INT_MIN; }
+        }
+    }
     if (tms) { tms[0] += t1 - t0; tms[1] += t2 - t1; tms[2] += t3 - t2; tms[3] += now_ms() - t3; }
     return rc;
 }
@@ -1007,6 +1078,17 @@ extern "C" int opalx_search_host(OpalxDb* db, const unsigned char* query, int qu
     return rc;
 }
 
+extern "C" int opalx_search_starts(OpalxDb* db, const unsigned char* query, int query_length, int gap_open, int gap_ext,
+                                   const int* score_matrix, int alphabet_length, int mode, const int* d_score,
+                                   const int* d_end_query, const int* d_end_target, int* d_start_query, int* d_start_target,
+                                   int* redo, int* redo_count) {
+    if (!db || !d_score || !d_end_query || !d_end_target || !d_start_query || !d_start_target) return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (mode != OPAL_MODE_NW && mode != OPAL_MODE_HW && mode != OPAL_MODE_OV && mode != OPAL_MODE_SW) return OPAL_ERR_INVALID_MODE;
+    if (!device_ok()) return OPAL_ERR_NO_SIMD_SUPPORT;
+    return search_starts(db, query, query_length, gap_open, gap_ext, score_matrix, alphabet_length, mode, d_score, d_end_query,
+                         d_end_target, d_start_query, d_start_target, redo, redo_count);
+}
+
 // ------------------------------------------------------------------------------------ opal.h API
 extern "C" void opalInitSearchResult(OpalSearchResult* result) {
     result->scoreSet = 0;
@@ -1052,8 +1134,11 @@ static bool collect_todo(OpalSearchResult* results[], int n, int searchType, std
     return false;
 }
 
+// `starts`: NULL, or 2*dbLength ints receiving the start cells found on the device for the sequences this call
+// computed ({startQ[dbLength], startT[dbLength]}, INT_MIN = unknown).
 static int search_into_results(unsigned char query[], int Q, unsigned char* db[], int dbLength, int dbSeqLengths[], int Go, int Ge,
-                               int* M, int A, OpalSearchResult* results[], int searchType, int mode, bool clearAlignment) {
+                               int* M, int A, OpalSearchResult* results[], int searchType, int mode, bool clearAlignment,
+                               int* starts) {
     const double tA = now_ms();
     std::vector<int> todo;
     const bool all = collect_todo(results, dbLength, searchType, todo);
@@ -1067,13 +1152,15 @@ static int search_into_results(unsigned char query[], int Q, unsigned char* db[]
         if (!device_ok()) return OPAL_ERR_NO_SIMD_SUPPORT;
         const int st = searchType == OPAL_SEARCH_SCORE ? OPAL_SEARCH_SCORE : OPAL_SEARCH_SCORE_END;
         const int wantEnd = st != OPAL_SEARCH_SCORE;
-        std::unique_ptr<int[]> buf(new (std::nothrow) int[3 * (size_t)n]);
+        std::unique_ptr<int[]> buf(new (std::nothrow) int[5 * (size_t)n]);
         if (!buf) return OPAL_ERR_NO_SIMD_SUPPORT;
         int* score = buf.get(); int* endQ = score + n; int* endT = score + 2 * (size_t)n;
+        int* startQ = starts ? score + 3 * (size_t)n : nullptr; int* startT = starts ? score + 4 * (size_t)n : nullptr;
         std::vector<int> devices = call_devices();
         if (devices.size() <= 1 || n < 2 * 64) {
             if (devices.size() == 1 && opal_hip_set_device(devices[0])) return OPAL_ERR_NO_SIMD_SUPPORT;
-            rc = run_shard(opal_hip_get_device(), query, Q, db, dbSeqLengths, ids, n, Go, Ge, M, A, st, mode, score, endQ, endT, tms);
+            rc = run_shard(opal_hip_get_device(), query, Q, db, dbSeqLengths, ids, n, Go, Ge, M, A, st, mode, score, endQ, endT, tms,
+                           startQ, startT);
         } else {
             // several GPUs: deal 64-sequence groups balancing the residue count, one host thread per GPU, each
             // running the single-GPU pipeline on its shard; the host is the gather root (results live in host structs)
@@ -1093,10 +1180,11 @@ static int search_into_results(unsigned char query[], int Q, unsigned char* db[]
                     if (!device_ok() || opal_hip_set_device(devices[k])) { rcs[k] = OPAL_ERR_NO_SIMD_SUPPORT; return; }
                     std::vector<int> sid((size_t)m);  // shard position -> caller index
                     for (int i = 0; i < m; i++) sid[(size_t)i] = ids ? ids[pos[(size_t)i]] : pos[(size_t)i];
-                    out[k].assign(3 * (size_t)m, 0);
+                    out[k].assign(5 * (size_t)m, INT_MIN);
                     int* s = out[k].data();
                     rcs[k] = run_shard(devices[k], query, Q, db, dbSeqLengths, sid.data(), m, Go, Ge, M, A, st, mode, s, s + m,
-                                       s + 2 * (size_t)m, nullptr);
+                                       s + 2 * (size_t)m, nullptr, starts ? s + 3 * (size_t)m : nullptr,
+                                       starts ? s + 4 * (size_t)m : nullptr);
                 });
             }
             for (auto& th : threads) th.join();
@@ -1110,6 +1198,7 @@ static int search_into_results(unsigned char query[], int Q, unsigned char* db[]
                     score[p] = out[k][(size_t)i];
                     endQ[p] = wantEnd ? out[k][(size_t)m + i] : -1;
                     endT[p] = wantEnd ? out[k][2 * (size_t)m + i] : -1;
+                    if (starts) { startQ[p] = out[k][3 * (size_t)m + i]; startT[p] = out[k][4 * (size_t)m + i]; }
                 }
             }
         }
@@ -1131,6 +1220,7 @@ static int search_into_results(unsigned char query[], int Q, unsigned char* db[]
                     r->endLocationTarget = wantEnd ? endT[i] : -1;
                 }
                 if (post && all) { r->alignment = NULL; r->alignmentLength = -1; r->startLocationQuery = -1; r->startLocationTarget = -1; }
+                if (starts) { starts[ids ? ids[i] : i] = startQ[i]; starts[(size_t)dbLength + (ids ? ids[i] : i)] = startT[i]; }
             }
         });
         if (debug_on())
@@ -1159,12 +1249,18 @@ extern "C" int opalSearchDatabase(unsigned char query[], int queryLength, unsign
     (void)overflowMethod;  // OPAL_OVERFLOW_SIMPLE and _BUCKETS give identical results (see search_core)
     if (mode != OPAL_MODE_NW && mode != OPAL_MODE_HW && mode != OPAL_MODE_OV && mode != OPAL_MODE_SW)
         return OPAL_ERR_INVALID_MODE;
+    // Alignment search: score + end cells on the device, start cells on the device (rev_kernel.hip), then the host
+    // traces the operations inside each (start..end) box. Sequences whose score/end the caller supplied (not
+    // recomputed here, opal.h:118-122) have no device start: the host pass finds theirs.
+    std::vector<int> starts;
+    if (searchType == OPAL_SEARCH_ALIGNMENT) starts.assign(2 * (size_t)std::max(dbLength, 1), INT_MIN);
     const int rc = search_into_results(query, queryLength, db, dbLength, dbSeqLengths, gapOpen, gapExt, scoreMatrix,
-                                       alphabetLength, results, searchType, mode, searchType != OPAL_SEARCH_ALIGNMENT);
+                                       alphabetLength, results, searchType, mode, searchType != OPAL_SEARCH_ALIGNMENT,
+                                       searchType == OPAL_SEARCH_ALIGNMENT ? starts.data() : nullptr);
     if (rc) return rc;
     if (searchType == OPAL_SEARCH_ALIGNMENT)
-        return opalx_find_alignments(query, queryLength, db, dbLength, dbSeqLengths, gapOpen, gapExt, scoreMatrix,
-                                     alphabetLength, results, mode);
+        return opalx_find_alignments_from(query, queryLength, db, dbLength, dbSeqLengths, gapOpen, gapExt, scoreMatrix,
+                                          alphabetLength, results, mode, starts.data(), starts.data() + dbLength);
     return 0;
 }
 

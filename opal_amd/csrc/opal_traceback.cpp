@@ -15,15 +15,26 @@
 //   H prefers E, then F, then the diagonal (opal.cpp:1378-1386); a gap state prefers to close
 //   (opal.cpp:1389, 1394); the first column reaching the score wins (:1275), then the first row
 //   (:1355).
+//
+// With start cells already known (the device's reverse pass, rev_kernel.hip) only the box between start and end
+// is traced: the DP is causal from the corner, so the box of the reversed prefixes holds exactly the cells the
+// full pass would have computed there, and the traceback from the box's far corner is the same walk.
+// Memory: one byte per cell of whatever is traced; concurrent tracebacks share a byte budget
+// (OPAL_TRACEBACK_BYTES, default 8 GiB) and an allocation failure is reported as OPALX_ERR_NO_MEMORY
+// instead of escaping through the C ABI.
 #include <algorithm>
+#include <atomic>
 #include <climits>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <thread>
+#include <mutex>
+#include <new>
 #include <vector>
 
+#include "host_pool.hpp"
 #include "opal.h"
 #include "opal_hip.h"
 
@@ -57,8 +68,6 @@ static void find_alignment(const unsigned char* q, int Q, const unsigned char* t
         dirs.resize((size_t)(c + 1) * Q);
         uint8_t* d = dirs.data() + (size_t)c * Q;
         int uF = NEG, uH = -Go - c * Ge, ulH = c == 0 ? 0 : uH + Ge;
-        const int* Mrow = nullptr;
-        (void)Mrow;
         for (int r = 0; r < Q; r++) {
             const int eo = Hp[r] - Go, ee = Ep[r] - Ge;
             const int E = std::max(eo, ee);
@@ -115,8 +124,38 @@ static void find_alignment(const unsigned char* q, int Q, const unsigned char* t
     std::reverse(ops.begin(), ops.end());
 }
 
+// Bytes of traceback flags in flight across threads: a thread waits until its matrix fits the budget
+// (a matrix larger than the whole budget runs alone).
+class ByteBudget {
+public:
+    explicit ByteBudget(uint64_t total) : total_(total) {}
+    void acquire(uint64_t n) {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return used_ == 0 || used_ + n <= total_; });
+        used_ += n;
+    }
+    void release(uint64_t n) {
+        { std::lock_guard<std::mutex> lk(m_); used_ -= n; }
+        cv_.notify_all();
+    }
+private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    uint64_t total_, used_ = 0;
+};
+
+static void emit(OpalSearchResult* res, const Aligned& a, int aq, int at) {
+    res->startLocationQuery = aq - a.endQ - 1;
+    res->startLocationTarget = at - a.endT - 1;
+    res->alignmentLength = (int)a.ops.size();
+    res->alignment = (unsigned char*)malloc(a.ops.size() ? a.ops.size() : 1);  // caller free()s (opal.h)
+    for (size_t i = 0; i < a.ops.size(); i++) res->alignment[i] = a.ops[a.ops.size() - 1 - i];  // back to forward order
+}
+
+// knownStartQ/T: start cell if already known (>= 0), else INT_MIN -> the full score-limited reverse pass finds it.
 static void align_one(const unsigned char* rQuery, int queryLength, const unsigned char* target, int Go, int Ge,
-                      const int* M, int A, OpalSearchResult* res, int mode, std::vector<unsigned char>& rTarget) {
+                      const int* M, int A, OpalSearchResult* res, int mode, std::vector<unsigned char>& rTarget,
+                      int knownStartQ, int knownStartT, ByteBudget& budget) {
     if (mode == OPAL_MODE_SW && res->score == 0) {  // no alignment at all (opal.cpp:1479-1483)
         res->alignment = NULL; res->alignmentLength = 0;
         res->startLocationQuery = res->startLocationTarget = -1;
@@ -133,35 +172,60 @@ static void align_one(const unsigned char* rQuery, int queryLength, const unsign
     rTarget.resize((size_t)at);
     for (int i = 0; i < at; i++) rTarget[i] = target[at - 1 - i];
     Aligned a;
+    if (knownStartQ >= 0 && knownStartT >= 0 && knownStartQ < aq && knownStartT < at) {
+        // box between start and end: the first bq x bt cells of the reversed prefixes, traced from its far corner
+        const int bq = aq - knownStartQ, bt = at - knownStartT;
+        const uint64_t bytes = (uint64_t)bq * (uint64_t)bt;
+        budget.acquire(bytes);
+        struct Rel { ByteBudget& b; uint64_t n; ~Rel() { b.release(n); } } rel{budget, bytes};
+        find_alignment(alignQuery, bq, rTarget.data(), bt, Go, Ge, M, A, INT_MAX, OPAL_MODE_NW, a);
+        if (a.score == res->score) { emit(res, a, aq, at); return; }
+        // the given start does not carry the score: fall through to the full pass (never seen; kept for safety)
+        if (getenv("OPAL_HIP_DEBUG")) fprintf(stderr, "[opal] traceback: start (%d,%d) gives %d, expected %d; full pass\n", knownStartQ, knownStartT, a.score, res->score);
+    }
+    const uint64_t bytes = (uint64_t)aq * (uint64_t)at;  // upper bound (the pass stops at the start column)
+    budget.acquire(bytes);
+    struct Rel { ByteBudget& b; uint64_t n; ~Rel() { b.release(n); } } rel{budget, bytes};
     find_alignment(alignQuery, aq, rTarget.data(), at, Go, Ge, M, A, res->score, mode, a);
-    res->startLocationQuery = aq - a.endQ - 1;
-    res->startLocationTarget = at - a.endT - 1;
-    res->alignmentLength = (int)a.ops.size();
-    res->alignment = (unsigned char*)malloc(a.ops.size() ? a.ops.size() : 1);  // caller free()s (opal.h)
-    for (size_t i = 0; i < a.ops.size(); i++) res->alignment[i] = a.ops[a.ops.size() - 1 - i];  // back to forward order
+    emit(res, a, aq, at);
 }
 
 }  // namespace
 
-extern "C" int opalx_find_alignments(unsigned char query[], int queryLength, unsigned char* db[], int dbLength,
-                                     int dbSeqLengths[], int gapOpen, int gapExt, int* scoreMatrix, int alphabetLength,
-                                     OpalSearchResult* results[], int mode) {
+extern "C" int opalx_find_alignments_from(unsigned char query[], int queryLength, unsigned char* db[], int dbLength,
+                                          int dbSeqLengths[], int gapOpen, int gapExt, int* scoreMatrix, int alphabetLength,
+                                          OpalSearchResult* results[], int mode, const int* startQuery, const int* startTarget) {
     (void)dbSeqLengths;
     std::vector<unsigned char> rQuery((size_t)std::max(queryLength, 1));
     for (int i = 0; i < queryLength; i++) rQuery[i] = query[queryLength - 1 - i];
-    unsigned nt = std::thread::hardware_concurrency();
-    const char* env = getenv("OPAL_HOST_THREADS");
-    if (env && *env) nt = (unsigned)atoi(env);
-    nt = std::max(1u, std::min(nt, 32u));
-    nt = std::min<unsigned>(nt, (unsigned)std::max(dbLength, 1));
-    auto work = [&](unsigned tid) {
+    uint64_t total = 8ull << 30;
+    if (const char* e = getenv("OPAL_TRACEBACK_BYTES")) { const long long v = atoll(e); if (v > 0) total = (uint64_t)v; }
+    ByteBudget budget(total);
+    std::atomic<int> failed{0};
+    HostPool& pool = HostPool::get();
+    const int tasks = std::max(1, std::min(dbLength, pool.width() * 4));
+    pool.parallel_for(tasks, [&](int t) {
         std::vector<unsigned char> rTarget;
-        for (int i = (int)tid; i < dbLength; i += (int)nt)
-            align_one(rQuery.data(), queryLength, db[i], gapOpen, gapExt, scoreMatrix, alphabetLength, results[i], mode, rTarget);
-    };
-    if (nt == 1) { work(0); return 0; }
-    std::vector<std::thread> pool;
-    for (unsigned t = 0; t < nt; t++) pool.emplace_back(work, t);
-    for (auto& th : pool) th.join();
+        for (int i = t; i < dbLength; i += tasks) {
+            if (failed.load(std::memory_order_relaxed)) return;
+            try {
+                align_one(rQuery.data(), queryLength, db[i], gapOpen, gapExt, scoreMatrix, alphabetLength, results[i], mode, rTarget,
+                          startQuery ? startQuery[i] : INT_MIN, startTarget ? startTarget[i] : INT_MIN, budget);
+            } catch (const std::bad_alloc&) {
+                failed.store(1);
+            }
+        }
+    });
+    if (failed.load()) {
+        fprintf(stderr, "[opal] traceback: out of host memory (a %d-row alignment matrix did not fit)\n", queryLength);
+        return OPALX_ERR_NO_MEMORY;
+    }
     return 0;
+}
+
+extern "C" int opalx_find_alignments(unsigned char query[], int queryLength, unsigned char* db[], int dbLength,
+                                     int dbSeqLengths[], int gapOpen, int gapExt, int* scoreMatrix, int alphabetLength,
+                                     OpalSearchResult* results[], int mode) {
+    return opalx_find_alignments_from(query, queryLength, db, dbLength, dbSeqLengths, gapOpen, gapExt, scoreMatrix, alphabetLength,
+                                      results, mode, nullptr, nullptr);
 }

@@ -171,8 +171,101 @@ def test_alignment_search(name, ours, oracle, golden):
                                           np.frombuffer(ops[i], np.uint8)) == 0
 
 
+def _device_starts(q, db, go, ge, m, mode):
+    """score+end search, then the reverse pass, both on the device -> host arrays + redo list."""
+    import torch
+    from opal_amd.api import PreparedDb
+    pdb = PreparedDb.from_sequences(db)
+    n = len(db)
+    dev = torch.device("cuda", 0)
+    t = [torch.full((n,), -7, dtype=torch.int32, device=dev) for _ in range(5)]
+    rc, _ = pdb.search_device(q, go, ge, m, 1, mode, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr())
+    assert rc == 0
+    rc, redo = pdb.search_starts_device(q, go, ge, m, mode, *[x.data_ptr() for x in t])
+    assert rc == 0
+    return [x.cpu().numpy() for x in t], redo
+
+
+@pytest.mark.parametrize("name", ALIGN_CASES)
+def test_device_start_locations_vs_golden(name, golden):
+    """n4: start cells computed ON THE GPU (rev_kernel.hip) equal the reference's recorded startQ/startT."""
+    case = cases.CASES[name]
+    q, db, m = cases.materialise(case)
+    for mode in case["modes"]:
+        (s, eq, et, sq, st), redo = _device_starts(q, db, case["gap_open"], case["gap_ext"], m, MODES[mode])
+        want = golden[name]["align"][mode]
+        np.testing.assert_array_equal(s, want["score"])
+        live = np.ones(len(db), bool)
+        live[redo] = False                    # sequences handed back to the host pass (OV coincidences; none expected here)
+        assert len(redo) <= max(1, len(db) // 10)
+        for i in np.nonzero(live)[0]:
+            if mode == "SW" and s[i] == 0:
+                assert (sq[i], st[i]) == (-1, -1)
+                continue
+            assert (sq[i], st[i]) == (want["startQ"][i], want["startT"][i]), f"{name} {mode} #{i}: start"
+
+
+@pytest.mark.parametrize("mode", ["SW", "NW", "HW", "OV"])
+def test_device_start_locations_differential(mode, ours, monkeypatch):
+    """n4 on a larger set: the alignment search with device start cells + box traceback gives the same start cells and
+    operation strings as the same search with the host's full reverse pass (OPAL_HIP_HOST_STARTS=1)."""
+    from opal_amd import synth
+    from opal_amd.score_matrix import blosum50
+    res, offs, lens = synth.database(700, seed=42, first=40000)
+    db = [res[offs[i]:offs[i + 1]] for i in range(700)]
+    q = synth.query(333, seed=9)
+    m = blosum50()[1]
+    rc, s, eq, et, sset, (arr, _) = ours.search(q, db, 3, 1, m, 2, MODES[mode])
+    assert rc == 0
+    sq, st, ops = ours.alignments(arr)
+    monkeypatch.setenv("OPAL_HIP_HOST_STARTS", "1")
+    rc2, s2, eq2, et2, sset2, (arr2, _) = ours.search(q, db, 3, 1, m, 2, MODES[mode])
+    assert rc2 == 0
+    sq2, st2, ops2 = ours.alignments(arr2)
+    np.testing.assert_array_equal(s, s2)
+    np.testing.assert_array_equal(sq, sq2)
+    np.testing.assert_array_equal(st, st2)
+    assert ops == ops2
+    # and straight from the kernel: few or no sequences handed back to the host
+    (ds, deq, det, dsq, dst), redo = _device_starts(q, db, 3, 1, m, MODES[mode])
+    keep = np.ones(len(db), bool); keep[redo] = False
+    np.testing.assert_array_equal(dsq[keep], sq[keep])
+    np.testing.assert_array_equal(dst[keep], st[keep])
+    assert len(redo) <= 35, f"{len(redo)} of 700 sequences needed the host pass"
+
+
 REF_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
 DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data")
+
+
+CLI = os.path.join(os.path.dirname(LIB), "opal_hip_aligner")
+
+
+def _cli_lines(binary, args):
+    import subprocess
+    out = subprocess.run([binary] + args, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-2000:]
+    skip = ("Cpu time of searching", "Wall time of searching", "GCUPS")
+    return [ln for ln in out.stdout.splitlines() if not ln.startswith(skip)]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_DIR, "ref_opal_aligner")), reason="reference CLI not built")
+@pytest.mark.parametrize("mode", ["SW", "NW", "HW", "OV"])
+@pytest.mark.parametrize("level", [0, 1, 2])
+def test_own_cli_output_equals_reference_cli(mode, level):
+    """n3: our own command-line front end (opal_cli.cpp, GPU library) prints the same lines as the reference's
+    opal_aligner (its own objects, CPU) on the bundled test data: scores, start/end cells, alignment blocks."""
+    assert os.path.exists(CLI), "opal_hip_aligner not built"
+    for query, db in (("query_O74807.fasta", "uniprot_sprot15.fasta"), ("query_P18080.fasta", "uniprot_sprot196.fasta")):
+        if level == 2 and db.endswith("196.fasta") and mode != "SW":
+            continue  # keep the CPU reference's alignment runs short
+        args = ["-a", mode, "-x", str(level), os.path.join(DATA, query), os.path.join(DATA, db)]
+        ours_lines = _cli_lines(CLI, args)
+        ref_lines = _cli_lines(os.path.join(REF_DIR, "ref_opal_aligner"), args)
+        if mode == "SW" and level == 1:
+            # SW score 0 with end location: the reference prints an undefined end cell (SURVEY.md 8c-2); none in this data
+            pass
+        assert ours_lines == ref_lines
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF_DIR, "dropin_test")), reason="drop-in binaries not built")

@@ -65,7 +65,7 @@ def test_fails_loudly_without_a_gpu(capfd):
     assert rc == 3  # invalid mode is reported before anything else
 
 
-def _traceback(lib, q, db, go, ge, m, mode, score, eq, et):
+def _traceback(lib, q, db, go, ge, m, mode, score, eq, et, starts=None):
     n = len(db)
     arr = (OpalSearchResult * n)()
     ptrs = (C.POINTER(OpalSearchResult) * n)()
@@ -76,9 +76,13 @@ def _traceback(lib, q, db, go, ge, m, mode, score, eq, et):
         ptrs[i] = C.pointer(arr[i])
     keep, dptrs, lens = oracle_lib._db_pointers(db)
     qq = np.ascontiguousarray(q, np.uint8); mm = np.ascontiguousarray(m, np.int32)
-    rc = lib.opalx_find_alignments(qq.ctypes.data_as(C.POINTER(C.c_ubyte)), len(qq), dptrs, n,
-                                   lens.ctypes.data_as(C.POINTER(C.c_int)), int(go), int(ge),
-                                   mm.ctypes.data_as(C.POINTER(C.c_int)), mm.shape[0], ptrs, int(mode))
+    args = (qq.ctypes.data_as(C.POINTER(C.c_ubyte)), len(qq), dptrs, n, lens.ctypes.data_as(C.POINTER(C.c_int)), int(go), int(ge),
+            mm.ctypes.data_as(C.POINTER(C.c_int)), mm.shape[0], ptrs, int(mode))
+    if starts is None:
+        rc = lib.opalx_find_alignments(*args)
+    else:  # start cells already known (as the device's reverse pass delivers them): only the start..end box is traced
+        sq = np.ascontiguousarray(starts[0], np.int32); st = np.ascontiguousarray(starts[1], np.int32)
+        rc = lib.opalx_find_alignments_from(*args, sq.ctypes.data_as(C.POINTER(C.c_int)), st.ctypes.data_as(C.POINTER(C.c_int)))
     assert rc == 0
     return arr
 
@@ -108,6 +112,78 @@ def test_traceback_matches_reference_alignments(name, oracle, golden):
             assert (sq[i], st[i]) == (want["startQ"][i], want["startT"][i]), f"{name} {mode} #{i} start"
             assert oracle.check_alignment(q, db[i], case["gap_open"], case["gap_ext"], m, s[i], sq[i], st[i],
                                           eq[i], et[i], np.frombuffer(ops[i], np.uint8)) == 0
+
+
+@pytest.mark.parametrize("name", ALIGN_CASES)
+def test_box_traceback_from_known_starts(name, oracle, golden):
+    """With the start cells given (the goldens' own), tracing only the start..end box yields the same operation
+    strings as the reference; unknown entries (INT_MIN) fall back to the full pass."""
+    lib = C.CDLL(LIB)
+    abi = oracle_lib.OpalABI(LIB)
+    case = cases.CASES[name]
+    q, db, m = cases.materialise(case)
+    for mode in case["modes"]:
+        rc, s, eq, et = oracle.search(q, db, case["gap_open"], case["gap_ext"], m, 1, MODES[mode])
+        want = golden[name]["align"][mode]
+        sq0 = np.array(want["startQ"], np.int32); st0 = np.array(want["startT"], np.int32)
+        sq0[::3] = np.iinfo(np.int32).min  # every third one "unknown"
+        arr = _traceback(lib, q, db, case["gap_open"], case["gap_ext"], m, MODES[mode], s, eq, et, starts=(sq0, st0))
+        sq, st, ops = abi.alignments(arr)
+        for i in range(len(db)):
+            if mode == "SW" and s[i] == 0:
+                assert (sq[i], st[i], ops[i]) == (-1, -1, b"")
+                continue
+            assert "".join(str(b) for b in ops[i]) == want["ops"][i], f"{name} {mode} #{i} operations"
+            assert (sq[i], st[i]) == (want["startQ"][i], want["startT"][i]), f"{name} {mode} #{i} start"
+
+
+def _gappy_pairs(seed, n, alphabet=4):
+    """Targets that equal the query with long insertions / deletions: optimal alignments with long gaps, i.e.
+    paths far from the diagonal (the reference traces inside a band, opal.cpp:1057-1179; ours does not)."""
+    rng = np.random.RandomState(seed)
+    q = rng.randint(0, alphabet, 260).astype(np.uint8)
+    db = []
+    for i in range(n):
+        cut = sorted(rng.choice(np.arange(20, 240), 2, replace=False))
+        ins = rng.randint(0, alphabet, rng.randint(30, 400)).astype(np.uint8)
+        kind = i % 3
+        if kind == 0:    # long insertion in the target
+            t = np.concatenate([q[:cut[0]], ins, q[cut[0]:]])
+        elif kind == 1:  # long deletion (target lacks a stretch of the query)
+            t = np.concatenate([q[:cut[0]], q[cut[1]:]])
+        else:            # both, plus flanks
+            t = np.concatenate([ins[:50], q[:cut[0]], ins, q[cut[1]:], ins[:30]])
+        db.append(t.astype(np.uint8))
+    return q, db
+
+
+@pytest.mark.skipif(not oracle_lib.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("mode", cases.ALL_MODES)
+@pytest.mark.parametrize("gaps", [(3, 1), (2, 1), (6, 1)])
+def test_traceback_long_gaps_vs_live_reference(mode, gaps, oracle):
+    """Long, gappy alignments (cheap gaps, insertions of up to 400 columns): start cells and operation strings of
+    the unbanded host traceback equal the reference's banded one (band vs no band, HW/OV stop test).
+    (Gap settings with gapOpen == gapExt or gapExt == 0 are left out: the reference's own alignment pass crashes on
+    this data with them -- its band algebra, opal.cpp:1057-1179 -- so there is nothing to compare with.)"""
+    lib = C.CDLL(LIB)
+    abi = oracle_lib.OpalABI(LIB)
+    ref = oracle_lib.RefLib()
+    q, db = _gappy_pairs(77, 18)
+    m = cases.simple_matrix(4, 4, -3)
+    go, ge = gaps
+    rc, s, eq, et, sset, (rarr, _) = ref.search(q, db, go, ge, m, 2, MODES[mode], 0)
+    assert rc == 0
+    rsq, rst, rops = ref.alignments(rarr)
+    arr = _traceback(lib, q, db, go, ge, m, MODES[mode], s, eq, et)
+    sq, st, ops = abi.alignments(arr)
+    np.testing.assert_array_equal(sq, rsq)
+    np.testing.assert_array_equal(st, rst)
+    assert ops == rops
+    assert max(len(o) for o in ops) > 300
+    # and with the starts given: same strings from the box alone
+    arr = _traceback(lib, q, db, go, ge, m, MODES[mode], s, eq, et, starts=(rsq, rst))
+    sq2, st2, ops2 = abi.alignments(arr)
+    assert ops2 == rops and (sq2 == rsq).all() and (st2 == rst).all()
 
 
 @pytest.mark.skipif(not oracle_lib.have_ref(), reason="oracle/_ref not built (needs /root/reference)")

@@ -4,6 +4,8 @@ Pins the oracle: every golden vector recorded from the reference's SSE4.1/AVX2 l
 (tests/golden/make_golden.py), the known answers of SURVEY.md 8(c), and -- when the build
 container's oracle/_ref/libopal_ref.so is present -- a live differential run.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -115,3 +117,36 @@ def test_int32_wrap_rule_vs_live_reference(oracle):
         assert rc == rrc == want_rc
         if not rc:
             assert s[0] == rs[0]
+
+
+def test_oracle_sanitized(tmp_path):
+    """The restatement is UBSan-clean: the -fsanitize=undefined build (oracle/Makefile,
+    liboracle_san.so, aborting on the first report) runs a spread of golden cases, incl. the 32-bit escalation pins
+    and the degenerate shapes, in a fresh process."""
+    import subprocess
+    import sys
+    subprocess.check_call(["make", "-s", "-C", oracle_lib.ORACLE_DIR, "liboracle_san.so"])
+    script = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, cases, oracle_lib
+orc = oracle_lib.Oracle(%r)
+for name in ("readme_example", "td_test1_test1", "pin_100_same_match3", "pin_2000_same_match30_int32", "random4_q200_db300_o0",
+             "synth_q37_db700_o3", "c1_O74807_sprot15_sw_score"):
+    case = cases.CASES[name]
+    q, db, m = cases.materialise(case)
+    for mode in case["modes"]:
+        rc, s, eq, et = orc.search(q, db, case["gap_open"], case["gap_ext"], m, case["search_type"], oracle_lib.MODES[mode])
+    if case.get("char_sw"):
+        orc.char_sw(q, db, case["gap_open"], case["gap_ext"], m)
+# degenerate shapes and extreme arguments
+m = cases.simple_matrix(4, 2**30 - 2, -1)
+for mode in range(4):
+    orc.search([], [[1, 2, 3], []], 3, 1, cases.simple_matrix(4, 2, -1), 1, mode)
+    orc.search([1, 1, 1], [[1, 1, 1], []], 2**30, 2**30, m, 1, mode)
+print("sanitized ok")
+""" % (os.path.dirname(oracle_lib.ORACLE_DIR), os.path.join(os.path.dirname(oracle_lib.ORACLE_DIR), "tests"),
+       os.path.join(oracle_lib.ORACLE_DIR, "liboracle_san.so"))
+    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "sanitized ok" in out.stdout, out.stdout[-1000:] + out.stderr[-3000:]
+    assert "runtime error" not in out.stderr
