@@ -83,7 +83,7 @@ typedef struct OpalHipLaunch {
        (rows_per_lane + steps) * gap_ext; the caller guarantees they stay below 32767) */
     int skew;
     int* scratch;         /* [2 * number of sequences] carried across chunks (OV) */
-    /* waves per workgroup, 1..8 (0: default 4). The scheduler picks it from the kernel's register count
+    /* waves per workgroup, 1..opal_hip_max_waves_per_block(width) (0: default 4). The scheduler picks it from the kernel's register count
        and the LDS size of the query profile so that every SIMD holds an even number (>= 2) of waves. */
     int waves_per_block;
     /* request at least this much LDS per workgroup (0: the query profile's own size): the scheduler pads the
@@ -121,8 +121,11 @@ int opal_hip_pack_tokens(const unsigned char* raw, const uint64_t* raw_off, cons
 /* Enqueue one DP kernel. 0 on success, non-zero if the shape is not launchable. */
 int opal_hip_launch(const OpalHipLaunch* args);
 /* Smallest rows_per_lane >= min_rows for which this kernel variant is instantiated (0: none).
-   want_end bit0: the SW end-location pass; bit1: the multi-chunk (chunk_flags != 0) variants. */
+   want_end bit0: the SW end-location pass; bit1: the multi-chunk (chunk_flags != 0) variants; bit2: the
+   diagonal-skewed variants (width 17, NW/HW/OV). */
 int opal_hip_rows_supported(int width, int mode, int want_end, int min_rows);
+/* Largest waves_per_block the kernels of this width are compiled for (8; 16 for width 18). */
+int opal_hip_max_waves_per_block(int width);
 /* VGPRs per lane of the kernel `args` selects (width, mode, want_end, detect_wrap, chunk_flags, skew,
    rows_per_lane are read), 0 if unknown. */
 int opal_hip_kernel_vgprs(const OpalHipLaunch* args);

@@ -30,6 +30,9 @@
 #include <limits.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 #define MODE_NW 0
 #define MODE_HW 1
 #define MODE_OV 2
@@ -42,6 +45,10 @@
 
 #define WAVES_PER_BLOCK 4      // default waves per block (the launch may use fewer or more, up to MAX)
 #define MAX_WAVES_PER_BLOCK 8
+// Width 18 serves long queries whose profile fills most of the LDS: one workgroup per CU, so the workgroup itself
+// must bring 4 waves per SIMD (16 waves; its kernels stay below the 128 registers that allows).
+#define MAX_WAVES_PER_BLOCK_W18 16
+__host__ __device__ constexpr int opal_max_waves_per_block(int width) { return width == 18 ? MAX_WAVES_PER_BLOCK_W18 : MAX_WAVES_PER_BLOCK; }
 
 struct KParams {
     const unsigned char* query;
@@ -142,7 +149,8 @@ template <> struct Vec<17> {
     // One row of one column as ONE asm block (hipcc pads every asm statement with a wait state and cannot
     // coalesce registers through it, so the block is as large as the data flow allows). d = H(diag) + P.
     // SW: E and F stay >= 0 through the unsigned clamp, so H >= 0 without a max against 0.
-    static __device__ __forceinline__ void row_sw(reg d, reg& e, reg& f, reg& acc, reg& h, reg Qv, reg Rv) {
+    // The gap penalties are wave-uniform: they enter as SGPR operands (no VGPR copies to keep or re-make per step).
+    static __device__ __forceinline__ void row_sw(reg d, reg& e, reg& f, reg& acc, reg& h, unsigned Qs, unsigned Rs) {
         reg hq;
         asm("v_max_i16_e32 %0, %5, %1\n\t"
             "v_max_i16_e32 %0, %0, %2\n\t"
@@ -153,39 +161,85 @@ template <> struct Vec<17> {
             "v_max_i16_e32 %1, %1, %4\n\t"
             "v_max_i16_e32 %2, %2, %4"
             : "=&v"(h), "+v"(e), "+v"(f), "+v"(acc), "=&v"(hq)
-            : "v"(d), "v"(Qv), "v"(Rv));
+            : "v"(d), "s"(Qs), "s"(Rs));
     }
     // NW/HW/OV in the skewed representation X' = X + (j + s)*Ge (j: register index, s: step): a gap
     // extension costs nothing any more, E' = max(E', g), F' = max(F', g) with g = H' - (Go - Ge); the profile
     // carries the +2*Ge the diagonal needs. 6 instructions per cell with the add, instead of 8.
-    static __device__ __forceinline__ void row_skew(reg d, reg& e, reg& f, reg& h, reg GQv) {
+    static __device__ __forceinline__ void row_skew(reg d, reg& e, reg& f, reg& h, unsigned GQs) {
         reg g;
         asm("v_max_i16_e32 %0, %4, %1\n\t"
             "v_max_i16_e32 %0, %0, %2\n\t"
-            "v_sub_u16_e32 %3, %0, %5\n\t"
+            "v_subrev_u16_e32 %3, %5, %0\n\t"
             "v_max_i16_e32 %1, %1, %3\n\t"
             "v_max_i16_e32 %2, %2, %3"
             : "=&v"(h), "+v"(e), "+v"(f), "=&v"(g)
-            : "v"(d), "v"(GQv));
+            : "v"(d), "s"(GQs));
     }
+    // End-location row scan, N <= 4 rows per statement: r = (H[j0+i] == cm) ? j0+i : r, highest row first so that the
+    // smallest matching row wins. v_cmp_eq_u16 + v_cndmask = 2 instructions per row; the compares of a block come first
+    // so that two instructions separate a compare from the select that reads its SGPR mask (gfx950 hazard).
+    template <int N, int J0>
+    static __device__ __forceinline__ void scan_rows(const reg* H, reg cm, int& r) {
+        unsigned long long m0, m1, m2, m3;
+        if constexpr (N == 4) {
+            asm("v_cmp_eq_u16_e64 %[m3], %[h3], %[cm]\n\tv_cmp_eq_u16_e64 %[m2], %[h2], %[cm]\n\t"
+                "v_cmp_eq_u16_e64 %[m1], %[h1], %[cm]\n\tv_cmp_eq_u16_e64 %[m0], %[h0], %[cm]\n\t"
+                "v_cndmask_b32_e64 %[r], %[r], %[j3], %[m3]\n\tv_cndmask_b32_e64 %[r], %[r], %[j2], %[m2]\n\t"
+                "v_cndmask_b32_e64 %[r], %[r], %[j1], %[m1]\n\tv_cndmask_b32_e64 %[r], %[r], %[j0], %[m0]"
+                : [r] "+v"(r), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3)
+                : [h0] "v"(H[0]), [h1] "v"(H[1]), [h2] "v"(H[2]), [h3] "v"(H[3]), [cm] "v"(cm), [j0] "n"(J0), [j1] "n"(J0 + 1),
+                  [j2] "n"(J0 + 2), [j3] "n"(J0 + 3));
+        } else if constexpr (N == 3) {
+            asm("v_cmp_eq_u16_e64 %[m2], %[h2], %[cm]\n\tv_cmp_eq_u16_e64 %[m1], %[h1], %[cm]\n\t"
+                "v_cmp_eq_u16_e64 %[m0], %[h0], %[cm]\n\t"
+                "v_cndmask_b32_e64 %[r], %[r], %[j2], %[m2]\n\tv_cndmask_b32_e64 %[r], %[r], %[j1], %[m1]\n\t"
+                "v_cndmask_b32_e64 %[r], %[r], %[j0], %[m0]"
+                : [r] "+v"(r), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2)
+                : [h0] "v"(H[0]), [h1] "v"(H[1]), [h2] "v"(H[2]), [cm] "v"(cm), [j0] "n"(J0), [j1] "n"(J0 + 1), [j2] "n"(J0 + 2));
+        } else if constexpr (N == 2) {
+            asm("v_cmp_eq_u16_e64 %[m1], %[h1], %[cm]\n\tv_cmp_eq_u16_e64 %[m0], %[h0], %[cm]\n\ts_nop 0\n\t"
+                "v_cndmask_b32_e64 %[r], %[r], %[j1], %[m1]\n\tv_cndmask_b32_e64 %[r], %[r], %[j0], %[m0]"
+                : [r] "+v"(r), [m0] "=&s"(m0), [m1] "=&s"(m1)
+                : [h0] "v"(H[0]), [h1] "v"(H[1]), [cm] "v"(cm), [j0] "n"(J0), [j1] "n"(J0 + 1));
+        } else {
+            asm("v_cmp_eq_u16_e64 %[m0], %[h0], %[cm]\n\ts_nop 1\n\tv_cndmask_b32_e64 %[r], %[r], %[j0], %[m0]"
+                : [r] "+v"(r), [m0] "=&s"(m0)
+                : [h0] "v"(H[0]), [cm] "v"(cm), [j0] "n"(J0));
+        }
+    }
+    // Blocks of up to 4 rows as one asm statement each (generated: scripts/gen_row_blocks.py)
+#include "row_blocks.inc"
     // NW/HW/OV: signed, wrapping (the host proves a-priori that nothing leaves the 16-bit range)
-    static __device__ __forceinline__ void row_global(reg d, reg& e, reg& f, reg& h, reg Qv, reg Rv) {
+    static __device__ __forceinline__ void row_global(reg d, reg& e, reg& f, reg& h, unsigned Qs, unsigned Rs) {
         reg hq;
         asm("v_max_i16_e32 %0, %4, %1\n\t"
             "v_max_i16_e32 %0, %0, %2\n\t"
-            "v_sub_u16_e32 %1, %1, %6\n\t"
-            "v_sub_u16_e32 %3, %0, %5\n\t"
-            "v_sub_u16_e32 %2, %2, %6\n\t"
+            "v_subrev_u16_e32 %1, %6, %1\n\t"
+            "v_subrev_u16_e32 %3, %5, %0\n\t"
+            "v_subrev_u16_e32 %2, %6, %2\n\t"
             "v_max_i16_e32 %1, %1, %3\n\t"
             "v_max_i16_e32 %2, %2, %3"
             : "=&v"(h), "+v"(e), "+v"(f), "=&v"(hq)
-            : "v"(d), "v"(Qv), "v"(Rv));
+            : "v"(d), "s"(Qs), "s"(Rs));
     }
 };
 
-// wave_shr:1 -- lane i receives lane i-1's value (lane 0 keeps `old`).
-__device__ __forceinline__ unsigned shr1(unsigned v, unsigned old) {
-    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x138, 0xf, 0xf, false);
+// Width "18": the same arithmetic as width 17 with 2-byte profile entries (one ds_read_b128 feeds 8 rows; the odd
+// rows' values are the high halves, moved down by one full-rate v_lshrrev_b32 each): half the LDS, so queries of
+// ~1600-2560 residues, whose 4-byte profile exceeds 160 KiB, still run one sequence per lane on full-rate
+// instructions (+0.5 instructions per cell) instead of falling back to the packed pairs of width 16.
+template <> struct Vec<18> : Vec<17> {
+    typedef short elem;
+};
+
+// wave_shr:1 -- lane i receives lane i-1's value; lane 0 receives 0 (bound_ctrl: no `old` register to prepare).
+__device__ __forceinline__ unsigned shr1(unsigned v) {
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x138, 0xf, 0xf, true);
+}
+// wave_shl:1 -- lane i receives lane i+1's value; lane 63 receives 0.
+__device__ __forceinline__ unsigned shl1(unsigned v) {
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xf, 0xf, true);
 }
 
 __device__ __forceinline__ int wave_max_i32(int v) {
@@ -212,6 +266,26 @@ template <typename T, int S, int LO, int HI> struct SelectRow {
     }
 };
 
+// Compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{})
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// One aligned 16-byte LDS read at an absolute LDS byte address (profile offsets carry the LDS base, so no address
+// arithmetic is left per read: ds_read_b128 v, vaddr offset:imm).
+typedef int opal_v4i __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const opal_v4i opal_lds_v4i;
+typedef __attribute__((address_space(3))) unsigned char opal_lds_u8;
+__device__ __forceinline__ int4 lds_ld16(unsigned addr) {
+    const opal_v4i v = *(opal_lds_v4i*)(uintptr_t)addr;
+    return make_int4(v.x, v.y, v.z, v.w);
+}
+
 // LDS geometry shared by kernel and host-side sizing
 // Every LDS read is one naturally aligned 16-byte ds_read_b128 (a misaligned one is replayed at ~64
 // cycles): a lane's segment of a letter's profile is padded to a multiple of 16 bytes, and the letter
@@ -227,7 +301,7 @@ __host__ __device__ inline int opal_profile_stride(int es, int G, int S) {
 
 // ------------------------------------------------------------------ the DP kernel
 template <int WIDTH, int MODE, int FLAGS, int S>
-__global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const KParams p) {
+__global__ void __launch_bounds__(opal_max_waves_per_block(WIDTH) * 64) opal_dp_kernel(const KParams p) {
     using V = Vec<WIDTH>;
     using reg = typename V::reg;
     using elem = typename V::elem;
@@ -239,6 +313,7 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
     constexpr bool SWEND = (FLAGS & FLAG_SWEND) != 0;
     constexpr bool WRAP = (FLAGS & FLAG_WRAP) != 0;
     constexpr bool MULTI = (FLAGS & FLAG_MULTI) != 0;
+    constexpr bool PLAIN = WIDTH == 17 || WIDTH == 18;  // one sequence per lane, plain 16-bit instructions
     constexpr bool SKEW = (FLAGS & FLAG_SKEW) != 0 && WIDTH == 17 && MODE != MODE_SW && !MULTI;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -252,15 +327,42 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
     // Q-1 in the last register of the last lane, where it is read without a register select.
     // With FLAG_MULTI the launch covers CR query rows starting at q0; only the first chunk (SW/HW/OV) or the
     // last one (NW) is partial, so the padding rule is unchanged.
-    const int satLimit = (WIDTH == 17) ? p.satLimit : V::SATMAX;  // scores >= this are re-run at 32 bits
-    const int negPad = (WIDTH == 17) ? p.negPad : V::NEG;         // profile value of pad residues / pad rows
+    const int satLimit = PLAIN ? p.satLimit : V::SATMAX;  // scores >= this are re-run at 32 bits
+    const int negPad = PLAIN ? p.negPad : V::NEG;         // profile value of pad residues / pad rows
     const int q0 = MULTI ? p.q0 : 0;
     const int CR = MULTI ? p.chunkRows : Q;
     const bool hasPrev = MULTI && (p.chunkFlags & 1), hasNext = MULTI && (p.chunkFlags & 2);
     const int padTop = (MODE == MODE_NW || hasPrev) ? 0 : (G * S - CR);
 
-    // ---- stage the query profile in LDS: QP[letter][k][j] = M[query[k*S+j-padTop]][letter]; letter A = padding
-    {
+    // ---- stage the query profile in LDS: QP[letter][k][j] = M[query[k*S+j-padTop]][letter]; letter A = padding.
+    // A thread owns (lane k, row j) positions and walks the letters: one query byte per position, then matrix reads
+    // that do not depend on each other (8 in flight), instead of a dependent query->matrix load pair and two integer
+    // divisions per ENTRY (a block spent ~30 us here; every block of a launch pays it before its first column).
+    if constexpr (PLAIN) {
+        const int perLetter = G * SPAD;
+        for (int rem = threadIdx.x; rem < perLetter; rem += blockDim.x) {
+            const int k = rem / SPAD;
+            const int j = rem - k * SPAD;
+            const int lr = k * S + j - padTop;  // row within this chunk
+            const bool real = lr >= 0 && j < S && lr < CR;
+            const int* mrow = p.matrix + (real ? (int)p.query[q0 + lr] * A : 0);
+            // virtual rows above the query are transparent (0); pad rows (NW: below the query) and the pad letter: negPad
+            const int fill = (lr < 0 ? 0 : negPad) + (SKEW ? 2 * p.Ge : 0);
+            unsigned char* dst = lds + k * LANE_BYTES + j * ES;
+            if (real) {
+                const int sk = SKEW ? 2 * p.Ge : 0;  // skewed diagonal: H'(j,s) = H'(j-1,s-1) + P + 2*Ge
+                for (int letter = 0; letter < A; letter += 2) {  // two independent loads in flight per position
+                    const int l1 = min(letter + 1, A - 1);
+                    const int v0 = mrow[letter], v1 = mrow[l1];
+                    *reinterpret_cast<elem*>(dst + letter * stride) = (elem)(v0 + sk);
+                    *reinterpret_cast<elem*>(dst + l1 * stride) = (elem)(v1 + sk);
+                }
+                *reinterpret_cast<elem*>(dst + A * stride) = (elem)(negPad + sk);
+            } else {
+                for (int letter = 0; letter <= A; letter++) *reinterpret_cast<elem*>(dst + letter * stride) = (elem)fill;
+            }
+        }
+    } else {  // the packed and 32-bit kernels keep the entry-wise loop (their register budget is tighter)
         const int perLetter = G * SPAD;
         const int total = (A + 1) * perLetter;
         for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
@@ -272,7 +374,6 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
             int v = negPad;     // pad residue, and (NW) rows below the query
             if (lr < 0) v = 0;  // virtual rows above the query: transparent
             else if (letter < A && j < S && lr < CR) v = p.matrix[(int)p.query[q0 + lr] * A + letter];
-            if (SKEW) v += 2 * p.Ge;  // skewed diagonal: H'(j,s) = H'(j-1,s-1) + P + 2*Ge
             *reinterpret_cast<elem*>(lds + letter * stride + k * LANE_BYTES + j * ES) = (elem)v;
         }
     }
@@ -317,7 +418,8 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
     // ---- per-lane DP state
     const int Go = p.Go, Ge = p.Ge;
     const reg Qv = V::splat(Go), Rv = V::splat(Ge);
-    const reg GQv = V::splat(Go - Ge);           // SKEW: g = H' - (Go - Ge)
+    // the same as wave-uniform 16-bit patterns for the asm row blocks (SGPR operands)
+    const unsigned Qs = (unsigned)Go & 0xffffu, Rs = (unsigned)Ge & 0xffffu, GQs = (unsigned)(Go - Ge) & 0xffffu;
     const reg SR1v = V::splat((S - 1) * Ge);     // SKEW: frame change between the last register of a lane and register 0 of the next
     const int r0 = q0 + k * S - padTop;  // query row held in register 0 (negative: virtual rows)
     reg Hp[S], En[S];               // H[r][c-1] and E[r][c] for my rows
@@ -344,7 +446,8 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
     reg diagIn = SKEW ? V::splat(-2 * Ge) : 0;  // H[r0-1][c-1]; H[-1][-1] = 0 in every mode (frame (-1)+(-1) when skewed)
     if (hasPrev && (MODE == MODE_NW || MODE == MODE_HW))  // H[q0-1][-1] for the first lane of a lower chunk
         diagIn = V::splat(V::clampv(-(long long)Go - (long long)(q0 - 1) * Ge));
-    const unsigned padOff = (unsigned)(A * stride);
+    const unsigned ldsBase = (unsigned)(uintptr_t)(opal_lds_u8*)lds;
+    const unsigned padOff = ldsBase + (unsigned)(A * stride);  // profile offsets are absolute LDS addresses
     unsigned offv[NH];
 #pragma unroll
     for (int h = 0; h < NH; h++) offv[h] = padOff + (unsigned)(k * LANE_BYTES);  // pad columns until real ones arrive
@@ -369,9 +472,16 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
     jlo = jlo < 0 ? 0 : (jlo > S ? S : jlo);
     jhi = jhi < 0 ? 0 : (jhi > S ? S : jhi);
 
-    // token prefetch (one step ahead)
+    // Residue tokens -> LDS profile offsets, G columns at a time: at the start of every batch of G steps lane k of a
+    // slot decodes the token of column s+k (letter * stride, or the padding letter beyond the sequence); the queue
+    // then moves one lane towards lane 0 per step (one wave_shl DPP move), so lane 0 of a slot always holds the
+    // offset of the column it starts. (Lane G-1 receives the next slot's lane 0: that value would reach my lane 0
+    // only after G steps, when the queue has been refilled.) The tokens of the next batch are loaded a batch ahead.
+    unsigned tokq[NH];
+#pragma unroll
+    for (int h = 0; h < NH; h++) tokq[h] = padOff;
     unsigned tokNext = 0;
-    if (0 < slotLen) tokNext = p.tokens[tokBase];
+    if (k < slotLen) tokNext = p.tokens[tokBase + (uint64_t)k];
     // chunk boundary prefetch (one step ahead): {H, F-input} of the row above my chunk at the next column
     auto bndIdx = [&](int c) -> uint64_t { return NH == 2 ? tokBase + (uint64_t)c : 2 * (tokBase + (uint64_t)c) + (uint64_t)half0; };
     uint2 bndNext = make_uint2(0u, 0u);
@@ -380,8 +490,18 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
     int topHv = V::clampv(-(long long)Go);  // NW: H[-1][0]
     reg sRv = 0;                             // SKEW: s*Ge as a 16-bit value
     for (int s = 0; s < nsteps; s++) {
-        const unsigned tok = tokNext;
-        if (s + 1 < slotLen) tokNext = p.tokens[tokBase + (uint64_t)(s + 1)];
+        if ((s & (G - 1)) == 0) {  // wave-uniform: refill the queue with columns s .. s+G-1
+            const unsigned tok = tokNext;
+            const int col = s + k;
+            if (col + G < slotLen) tokNext = p.tokens[tokBase + (uint64_t)(col + G)];
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+                unsigned mine;
+                if (NH == 2) mine = (h == 0) ? (tok & 0xffu) : ((tok >> 8) & 0xffu);
+                else mine = half0 ? ((tok >> 8) & 0xffu) : (tok & 0xffu);
+                tokq[h] = (col < len[h]) ? ldsBase + mine * (unsigned)stride : padOff;
+            }
+        }
         const uint2 bndCur = bndNext;
         if (hasPrev && s + 1 < slotLen) bndNext = p.bnd[bndIdx(s + 1)];
 
@@ -392,8 +512,8 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
             const int nxt = topHv - Ge;
             topHv = (nxt < V::clampv(LLONG_MIN / 2) || nxt > topHv) ? V::clampv(LLONG_MIN / 2) : nxt;
         }
-        reg inH = (reg)shr1((unsigned)outH, 0u);
-        reg inF = (reg)shr1((unsigned)outF, 0u);
+        reg inH = (reg)shr1((unsigned)outH);
+        reg inF = (reg)shr1((unsigned)outF);
         if (SKEW) {
             inH = V::subs(inH, SR1v);
             inF = V::subs(inF, SR1v);
@@ -403,6 +523,10 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
                 if (MODE == MODE_NW) { inH = V::splat(-Go - Ge); inF = V::splat(-2 * Go); }
                 else { inH = V::subs(sRv, Rv); inF = V::subs(sRv, Qv); }
             }
+        } else if (MODE == MODE_SW && !MULTI) {
+            // top boundary of local alignment: H = 0 and F input = 0 for lane 0 of every slot (two selects, no branch)
+            inH = (k == 0) ? (reg)0 : inH;
+            inF = (k == 0) ? (reg)0 : inF;
         } else if (k == 0) {
             if (hasPrev) {
                 inH = (reg)bndCur.x;
@@ -414,12 +538,9 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
         }
 #pragma unroll
         for (int h = 0; h < NH; h++) {
-            unsigned mine;
-            if (NH == 2) mine = (h == 0) ? (tok & 0xffu) : ((tok >> 8) & 0xffu);
-            else mine = half0 ? ((tok >> 8) & 0xffu) : (tok & 0xffu);
-            mine = (s < len[h]) ? mine * (unsigned)stride : padOff;
-            const unsigned shifted = shr1(offv[h], 0u) + (unsigned)LANE_BYTES;
-            offv[h] = (k == 0) ? mine : shifted;
+            const unsigned shifted = shr1(offv[h]) + (unsigned)LANE_BYTES;
+            offv[h] = (k == 0) ? tokq[h] : shifted;
+            tokq[h] = shl1(tokq[h]);
         }
         const int c = s - k;  // my column
 
@@ -427,47 +548,48 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
             reg diag = diagIn;
             reg f = inF;
             reg h = 0;
-            // SW with end location: this column's maximum over my rows, kept per block of 8 rows so that the row scan
-            // below only has to look inside the block that holds it
-            constexpr int NB = (S + 7) / 8;
-            reg cmb[NB];
-#pragma unroll
-            for (int b = 0; b < NB; b++) cmb[b] = 0;
-            if constexpr (WIDTH == 17) {
-                // Plain 16-bit path: profile reads run one block of 4 rows ahead, the diagonal add of row
-                // j+1 is issued before row j's block so that H[j][c-1]'s register is free for H[j][c].
-                int4 pc = *reinterpret_cast<const int4*>(__builtin_assume_aligned(lds + offv[0], 16));
-                reg d = V::adds(diag, (reg)pc.x);
-#pragma unroll
-                for (int rb = 0; rb < SPAD / RB; rb++) {
+            reg cm = 0;  // SW with end location: this column's maximum over my rows
+            if constexpr (PLAIN) {
+                // Plain 16-bit path: one asm statement per block of 4 rows (one ds_read_b128 of profile entries), the
+                // profile read of the next block issued before the current block's arithmetic. Inside a block the
+                // diagonal add of row j+1 comes before row j's recurrence, so H[j][c-1]'s register is free for H[j][c].
+                constexpr int KIND = MODE == MODE_SW ? ROWS_SW : (SKEW ? ROWS_SKEW : ROWS_GLOBAL);
+                constexpr int NBLK = SPAD / RB;   // LDS reads per column (RB rows each: 4 with 4-byte entries, 8 with 2-byte ones)
+                int4 pc = lds_ld16(offv[0]);
+                reg d = V::adds(diag, (reg)pc.x), t = 0;  // (a 16-bit add reads the low half only)
+                static_for<NBLK>([&](auto rbc) {
+                    constexpr int rb = decltype(rbc)::value;
                     int4 pn = pc;
-                    if (rb + 1 < SPAD / RB)
-                        pn = *reinterpret_cast<const int4*>(__builtin_assume_aligned(lds + offv[0] + (rb + 1) * RB * ES, 16));
-                    const reg P[RB + 1] = {(reg)pc.x, (reg)pc.y, (reg)pc.z, (reg)pc.w, (reg)pn.x};
-#pragma unroll
-                    for (int i = 0; i < RB; i++) {
-                        const int j = rb * RB + i;
-                        if (j < S) {
-                            reg dn = 0;
-                            if (j + 1 < S) dn = V::adds(Hp[j], P[i + 1]);  // diagonal of the next row: last use of H[j][c-1]
-                            if (MODE == MODE_SW) V::row_sw(d, En[j], f, SWEND ? cmb[j / 8] : mx, h, Qv, Rv);
-                            else if (SKEW) V::row_skew(d, En[j], f, h, GQv);
-                            else V::row_global(d, En[j], f, h, Qv, Rv);
-                            Hp[j] = h;
-                            d = dn;
-                        }
+                    if constexpr (rb + 1 < NBLK) pn = lds_ld16(offv[0] + (rb + 1) * RB * ES);
+                    reg Pv[RB + 1];  // profile values of this block's rows, then of the next block's first row
+                    if constexpr (ES == 4) {
+                        Pv[0] = (reg)pc.x; Pv[1] = (reg)pc.y; Pv[2] = (reg)pc.z; Pv[3] = (reg)pc.w;
+                    } else {
+                        Pv[0] = (reg)pc.x; Pv[1] = (reg)pc.x >> 16; Pv[2] = (reg)pc.y; Pv[3] = (reg)pc.y >> 16;
+                        Pv[4] = (reg)pc.z; Pv[5] = (reg)pc.z >> 16; Pv[6] = (reg)pc.w; Pv[7] = (reg)pc.w >> 16;
                     }
+                    Pv[RB] = (reg)pn.x;
+                    static_for<RB / 4>([&](auto subc) {
+                        constexpr int j0 = rb * RB + decltype(subc)::value * 4;  // first row of this asm block
+                        if constexpr (j0 < S) {
+                            constexpr int n = (S - j0) < 4 ? (S - j0) : 4;
+                            constexpr bool last = j0 + n == S;
+                            const reg* Pn = &Pv[j0 - rb * RB + 1];  // profile of the row BELOW each row
+                            reg& acc = SWEND ? cm : mx;
+                            V::template rows<KIND, n, last>(&Hp[j0], &En[j0], Pn, f, acc, d, t, SKEW ? GQs : Qs, Rs);
+                        }
+                    });
                     pc = pn;
-                }
+                });
+                h = Hp[S - 1];
             } else {
 #pragma unroll
             for (int rb = 0; rb < SPAD / RB; rb++) {
                 reg P[RB];
                 if constexpr (WIDTH == 16) {
-                    const uint4 a = *reinterpret_cast<const uint4*>(
-                        __builtin_assume_aligned(lds + offv[0] + rb * RB * ES, 16));
-                    const uint4 b = *reinterpret_cast<const uint4*>(
-                        __builtin_assume_aligned(lds + offv[1] + rb * RB * ES, 16));
+                    const int4 ai = lds_ld16(offv[0] + rb * RB * ES), bi = lds_ld16(offv[1] + rb * RB * ES);
+                    const uint4 a = make_uint4((unsigned)ai.x, (unsigned)ai.y, (unsigned)ai.z, (unsigned)ai.w);
+                    const uint4 b = make_uint4((unsigned)bi.x, (unsigned)bi.y, (unsigned)bi.z, (unsigned)bi.w);
                     P[0] = __builtin_amdgcn_perm(b.x, a.x, 0x05040100u);
                     P[1] = __builtin_amdgcn_perm(b.x, a.x, 0x07060302u);
                     P[2] = __builtin_amdgcn_perm(b.y, a.y, 0x05040100u);
@@ -477,8 +599,7 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
                     P[6] = __builtin_amdgcn_perm(b.w, a.w, 0x05040100u);
                     P[7] = __builtin_amdgcn_perm(b.w, a.w, 0x07060302u);
                 } else {
-                    const int4 a = *reinterpret_cast<const int4*>(
-                        __builtin_assume_aligned(lds + offv[0] + rb * RB * ES, 16));
+                    const int4 a = lds_ld16(offv[0] + rb * RB * ES);
                     P[0] = a.x; P[1] = a.y; P[2] = a.z; P[3] = a.w;
                 }
 #pragma unroll
@@ -494,7 +615,7 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
                         reg hq;
                         if (MODE == MODE_SW) {
                             // E, F are kept >= 0 by unsigned saturation, so H >= 0 needs no extra max
-                            if (SWEND) cmb[j / 8] = V::maxs(cmb[j / 8], h); else mx = V::maxs(mx, h);
+                            if (SWEND) cm = V::maxs(cm, h); else mx = V::maxs(mx, h);
                             hq = V::subu(h, Qv);
                             En[j] = V::maxs(V::subu(e, Rv), hq);
                             f = V::maxs(V::subu(f, Rv), hq);
@@ -516,12 +637,10 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
             if (MODE == MODE_SW && SWEND) {
                 // End location in the same pass. cm = this column's maximum over my rows. Only a STRICT
                 // improvement of my running maximum can be the first cell holding the final score
-                // (smallest column first, opal.h:44-45); the row scan below runs for those columns only, and only
-                // inside the 8-row blocks whose maximum is the column's (some lane of a wave improves in almost
-                // every column, so the scan's cost is per step, not per improvement).
-                reg cm = cmb[0];
-#pragma unroll
-                for (int b = 1; b < NB; b++) cm = V::maxs(cm, cmb[b]);
+                // (smallest column first, opal.h:44-45); the row scan below runs for those columns only.
+                // (Some lane of a wave improves in most columns, so in practice the scan is paid per step: measured
+                // +2.6 instructions per cell, the same relative price the reference pays for end locations. A scan
+                // restricted to 8-row blocks was tried in round 2 and was no faster: lanes improve in different blocks.)
                 const reg nm = V::maxs(mx, cm);
                 bool improved = false;
 #pragma unroll
@@ -532,13 +651,17 @@ __global__ void __launch_bounds__(MAX_WAVES_PER_BLOCK * 64) opal_dp_kernel(const
                         const int cv = V::half(cm, hh);
                         if (cv > V::half(mx, hh)) {
                             int r = 0;
+                            if constexpr (PLAIN) {
+                                constexpr int NBLK4 = (S + 3) / 4;
+                                static_for<NBLK4>([&](auto bc) {  // highest block first: the smallest row holding it wins
+                                    constexpr int b = NBLK4 - 1 - decltype(bc)::value;
+                                    constexpr int n = (S - 4 * b) < 4 ? (S - 4 * b) : 4;
+                                    V::template scan_rows<n, 4 * b>(&Hp[4 * b], cm, r);
+                                });
+                            } else {
 #pragma unroll
-                            for (int b = NB - 1; b >= 0; b--) {  // descending: the smallest block (then row) holding it wins
-                                if (V::same(cmb[b], cm, hh)) {
-#pragma unroll
-                                    for (int j = (8 * b + 8 < S ? 8 * b + 8 : S) - 1; j >= 8 * b; j--)
-                                        if (V::same(Hp[j], cm, hh)) r = j;
-                                }
+                                for (int j = S - 1; j >= 0; j--)
+                                    if (V::same(Hp[j], cm, hh)) r = j;  // smallest row of the column holding it
                             }
                             endRow[hh] = r0 + r;
                             endCol[hh] = c;
@@ -685,6 +808,8 @@ KernelFn opal_kernel_w16(int mode, int flags, int rows);  // width 16, the other
 KernelFn opal_kernel_w32(int mode, int flags, int rows);  // width 32: rows 8,16,24,32,40
 KernelFn opal_kernel_s16sw(int rows);                     // width 17, SW, score only: rows 1..40
 KernelFn opal_kernel_s16swend(int rows);                  // width 17, SW, score + end location: rows 1..40
+KernelFn opal_kernel_s18(int mode, int flags, int rows);   // width 18 (2-byte profile entries): rows 8,16,..,40
+KernelFn opal_kernel_s16skew(int mode, int rows);           // width 17, NW/HW/OV, FLAG_SKEW: rows 1..40
 KernelFn opal_kernel_s16(int mode, int flags, int rows);  // width 17, other variants incl. FLAG_MULTI: rows 4,8,..,40
 KernelFn opal_kernel_w16_multi(int mode, int flags, int rows);  // FLAG_MULTI variants
 KernelFn opal_kernel_w32_multi(int mode, int flags, int rows);

@@ -12,9 +12,9 @@ KernelFn opal_kernel_s16(int mode, int flags, int rows) {
     using Seq = std::make_integer_sequence<int, 10>;
     const bool multi = flags & FLAG_MULTI, end = flags & FLAG_SWEND, skew = (flags & FLAG_SKEW) && !multi;
     switch (mode) {
-    case MODE_NW: return multi ? pick<MODE_NW, FLAG_MULTI>(rows, Seq{}) : skew ? pick<MODE_NW, FLAG_SKEW>(rows, Seq{}) : pick<MODE_NW, 0>(rows, Seq{});
-    case MODE_HW: return multi ? pick<MODE_HW, FLAG_MULTI>(rows, Seq{}) : skew ? pick<MODE_HW, FLAG_SKEW>(rows, Seq{}) : pick<MODE_HW, 0>(rows, Seq{});
-    case MODE_OV: return multi ? pick<MODE_OV, FLAG_MULTI>(rows, Seq{}) : skew ? pick<MODE_OV, FLAG_SKEW>(rows, Seq{}) : pick<MODE_OV, 0>(rows, Seq{});
+    case MODE_NW: return multi ? pick<MODE_NW, FLAG_MULTI>(rows, Seq{}) : skew ? opal_kernel_s16skew(mode, rows) : pick<MODE_NW, 0>(rows, Seq{});
+    case MODE_HW: return multi ? pick<MODE_HW, FLAG_MULTI>(rows, Seq{}) : skew ? opal_kernel_s16skew(mode, rows) : pick<MODE_HW, 0>(rows, Seq{});
+    case MODE_OV: return multi ? pick<MODE_OV, FLAG_MULTI>(rows, Seq{}) : skew ? opal_kernel_s16skew(mode, rows) : pick<MODE_OV, 0>(rows, Seq{});
     case MODE_SW:
         if (multi) return end ? pick<MODE_SW, FLAG_SWEND | FLAG_MULTI>(rows, Seq{}) : pick<MODE_SW, FLAG_MULTI>(rows, Seq{});
         return end ? opal_kernel_s16swend(rows) : opal_kernel_s16sw(rows);

@@ -361,7 +361,16 @@ struct SearchCtx {
 // instruction per ~4 clocks per SIMD. A lane's column step costs about (12*rows + 25) instructions.
 static double step_clocks(int width, int rows) {
     if (width == 17) return 2.15 * 9.5 * rows + 90.0;  // full-rate scalar 16-bit ops, fixed per-step overhead
+    if (width == 18) return 2.15 * 10.0 * rows + 90.0; // + one shift per two rows (2-byte profile entries)
     return 4.3 * (11.0 * rows + 12.0);
+}
+
+// A wave that is alone on its critical path (the longest sequences of a database) issues one instruction per ~4.8
+// clocks whatever the pipe could take (profiles/r01_ubench_rowblock.txt: 42.9 clk per 9-instruction row on one wave):
+// clocks per column step of such a wave.
+static double lone_step_clocks(int width, int rows) {
+    if (width == 17 || width == 18) return 4.8 * (9.5 * rows + 16.0);
+    return 4.8 * (11.0 * rows + 14.0);
 }
 
 // Registers per lane of a kernel variant, asked once per variant from the code object.
@@ -380,6 +389,13 @@ static int kernel_vgprs(int width, int mode, int swEndPass, int multi, int skew,
     return v;
 }
 
+// Measured: one wave per SIMD issues at half rate; two fill the VALU pipe of a pure-arithmetic loop (r01 ubench) but the
+// real kernels (LDS reads with bank conflicts, DPP hand-offs) run 10-16 % slower on 2 or 3 waves than on 4
+// (round 2: the OV kernel at 38 rows per lane, 129 VGPRs -> 2 waves, against 40 rows, 125 VGPRs -> 4 waves).
+static double issue_factor(int wavesPerSimd) {
+    return wavesPerSimd <= 1 ? 0.5 : wavesPerSimd == 2 ? 0.86 : wavesPerSimd == 3 ? 0.8 : 1.0;
+}
+
 /*
  * Occupancy of one kernel shape (profiles/r01_ubench_rowblock.txt: one wave per SIMD issues at half
  * rate, odd wave counts lose, two or four fill the pipe). Registers: 512 per lane per SIMD in granules
@@ -388,12 +404,13 @@ static int kernel_vgprs(int width, int mode, int swEndPass, int multi, int skew,
  * give an odd number of waves, an LDS request padded so that fewer workgroups fit) giving every SIMD
  * an even number of waves. Returns waves per SIMD; `ldsPad` is the LDS bytes to request (0: the profile's own size).
  */
-static int pick_occupancy(int vgprs, size_t ldsBytes, int* wpbOut, int* ldsPadOut) {
+static int pick_occupancy(int vgprs, size_t ldsBytes, int* wpbOut, int* ldsPadOut, int maxWpb = 8) {
     const int alloc = vgprs > 0 ? (vgprs + 7) / 8 * 8 : 128;
     const int regWaves = std::max(1, std::min(8, 512 / alloc));
     int bestW = 0, bestWpb = 4, bestPad = 0;
     double bestScore = -1;
-    for (int wpb : {4, 8}) {
+    for (int wpb : {4, 8, 16}) {
+        if (wpb > maxWpb) continue;
         const int perSimdPerBlock = wpb / 4;
         const int blocksByLds = (int)std::max<size_t>(1, (160 * 1024) / std::max<size_t>(ldsBytes, 1));
         int blocks = std::min({blocksByLds, 32 / wpb, regWaves / perSimdPerBlock});
@@ -412,15 +429,13 @@ static int pick_occupancy(int vgprs, size_t ldsBytes, int* wpbOut, int* ldsPadOu
                 if (pad) w = w - 1;
             }
         }
-        const double score = (w == 1 ? 0.5 : (w & 1) ? 0.8 : 1.0) + 0.001 * w + (wpb == 4 ? 0.0005 : 0.0);
+        const double score = issue_factor(w) + 0.001 * w + (wpb == 4 ? 0.0005 : 0.0);
         if (score > bestScore) { bestScore = score; bestW = w; bestWpb = wpb; bestPad = pad; }
     }
     *wpbOut = bestWpb;
     *ldsPadOut = bestPad;
     return bestW;
 }
-static double issue_factor(int wavesPerSimd) { return wavesPerSimd <= 1 ? 0.5 : (wavesPerSimd & 1) ? 0.8 : 1.0; }
-
 /*
  * Split the item range [first, first+count) (sorted by length, longest first) into classes of
  * equal wave geometry. Each sequence (pair) is spread over G lanes; a wave therefore needs
@@ -445,15 +460,26 @@ static std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass,
         if (forceG && *forceG && atoi(forceG) != G) continue;
         const int need = (Q + G - 1) / G;
         if (need > OPAL_HIP_MAX_ROWS) continue;
-        const int rows = opal_hip_rows_supported(width, mode, swEndPass, need);
-        if (!rows) continue;
-        const size_t lds = opal_hip_lds_bytes(width, G, rows, A);
-        if (lds > 160 * 1024) continue;
-        if (G > 1 && (G / 2) * rows >= Q && !(forceG && *forceG)) continue;  // half the lanes would hold padding only
-        int wpb = 4, ldsPad = 0;
-        const int waves = pick_occupancy(kernel_vgprs(width, mode, swEndPass, 0, skew, rows), lds, &wpb, &ldsPad);
-        const double eff = ((double)Q / (G * rows)) * (rows / step_clocks(width, rows)) * (lavg / (lavg + G - 1)) * issue_factor(waves);
-        cands.push_back({G, rows, wpb, ldsPad, eff});
+        // rows per lane: the smallest instantiated value, or up to 3 more if that one compiles to a register count
+        // that leaves fewer waves per SIMD (a few padding rows cost less than an odd or halved occupancy)
+        Cand best{0, 0, 4, 0, -1.0};
+        int prevRows = 0;
+        for (int want = need; want <= need + 3 && want <= OPAL_HIP_MAX_ROWS; want++) {
+            const int rows = opal_hip_rows_supported(width, mode, swEndPass | (skew ? 4 : 0), want);
+            if (!rows || rows == prevRows) continue;
+            prevRows = rows;
+            const size_t lds = opal_hip_lds_bytes(width, G, rows, A);
+            if (lds > 160 * 1024) continue;
+            if (G > 1 && (G / 2) * rows >= Q && !(forceG && *forceG)) continue;  // half the lanes would hold padding only
+            int wpb = 4, ldsPad = 0;
+            const int waves = pick_occupancy(kernel_vgprs(width, mode, swEndPass, 0, skew, rows), lds, &wpb, &ldsPad, opal_hip_max_waves_per_block(width));
+            const double eff = ((double)Q / (G * rows)) * (rows / step_clocks(width, rows)) * (lavg / (lavg + G - 1)) * issue_factor(waves);
+            if (debug_on())
+                fprintf(stderr, "[opal] plan width=%d mode=%d G=%d rows=%d: %d VGPRs, %zu B LDS -> %d waves/SIMD (waves/block %d, ldsPad %d), eff %.5f\n",
+                        width, mode, G, rows, kernel_vgprs(width, mode, swEndPass, 0, skew, rows), lds, waves, wpb, ldsPad, eff);
+            if (eff > best.eff) best = Cand{G, rows, wpb, ldsPad, eff};
+        }
+        if (best.eff > 0) cands.push_back(best);
     }
     if (cands.empty()) return out;
     size_t base = 0;
@@ -468,7 +494,15 @@ static std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass,
     // walk from the longest item: the smallest geometry (>= base) whose lone-wave time fits the budget
     size_t ci = cands.size() - 1;
     int start = first;
-    auto fits = [&](size_t c, int len) { return (len + cands[c].G - 1) * step_clocks(width, cands[c].rows) <= budget; };
+    // Measured (round 2, C2 database): moving more than the few hundred longest sequences into the high-G classes makes
+    // the search slower (1.6 -> 1.9-2.3 ms: their prioritised waves starve the bulk launch), so the boundary stays where
+    // the pipe-rate model puts it; OPAL_HIP_TAIL_MODEL=lone switches to the lone-wave timing for experiments.
+    const char* tm = getenv("OPAL_HIP_TAIL_MODEL");
+    const bool loneModel = tm && !strcmp(tm, "lone");
+    auto fits = [&](size_t c, int len) {
+        const double per = loneModel ? lone_step_clocks(width, cands[c].rows) : step_clocks(width, cands[c].rows);
+        return (len + cands[c].G - 1) * per <= budget;
+    };
     auto cls = [&](int s, int n, size_t c) { return LaunchClass{s, n, cands[c].G, cands[c].rows, cands[c].wpb, cands[c].ldsPad}; };
     int i = first;
     while (i < first + count) {
@@ -486,7 +520,10 @@ static std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass,
         i += 64 / cands[ci].G;
     }
     out.push_back(cls(start, first + count - start, ci));
-    while (out.size() > 4) {  // at most three side streams: fold the two longest classes together
+    // At most TWO side streams: HIP multiplexes streams onto 4 hardware queues and the caller's own streams (torch's,
+    // the null stream) take part of them; with three side streams plus the main one, two launches of a search ended up
+    // on one queue and ran one after the other (round 2 kernel trace).
+    while (out.size() > 3) {  // fold the two longest classes together
         out[1].count += out[0].count;
         out[1].first = out[0].first;
         out[1].G = out[0].G; out[1].rows = out[0].rows; out[1].wpb = out[0].wpb; out[1].ldsPad = out[0].ldsPad;
@@ -578,7 +615,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
     // The last class (the bulk of the database) runs on the main stream; the classes of long
     // sequences run beside it on up to three side streams (one hardware queue each), forked from and
     // joined back into the main stream with events, longest sequences enqueued first.
-    const int nside = std::min<int>((int)classes.size() - 1, 3);
+    const int nside = std::min<int>((int)classes.size() - 1, 2);
     void* fork = nullptr;
     if (nside > 0) {
         fork = db->event(0);
@@ -587,16 +624,26 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
     int err = 0;
     int recorded = 0;
     for (size_t ki = 0; ki < classes.size() && !err; ki++) {
-        const LaunchClass& k = classes[ki];
+        LaunchClass k = classes[ki];
+        const int skew = maySkew && skew_ok(k.first);
+        {   // the plan assumed the skewed kernels (every rows-per-lane value exists); a class that cannot use them
+            // takes the plain kernel's next instantiated value
+            const int rows = opal_hip_rows_supported(width, c.mode, swEndPass | (skew ? 4 : 0), (c.Q + k.G - 1) / k.G);
+            if (rows && rows != k.rows && opal_hip_lds_bytes(width, k.G, rows, c.A) <= 160 * 1024) {
+                k.rows = rows;
+                pick_occupancy(kernel_vgprs(width, c.mode, swEndPass, 0, skew, rows), opal_hip_lds_bytes(width, k.G, rows, c.A), &k.wpb, &k.ldsPad,
+                               opal_hip_max_waves_per_block(width));
+            }
+        }
         OpalHipLaunch a;
         fill_launch(a, c, width, swEndPass, detectWrap, work, ovfCounter);
         a.lanes_per_seq = k.G; a.rows_per_lane = k.rows; a.waves_per_block = k.wpb; a.lds_bytes_min = k.ldsPad;
         a.first_item = k.first; a.num_items = k.count;
-        const int skew = maySkew && skew_ok(k.first);
         a.skew = skew;
         const bool side = (int)ki < nside;
         if (side) a.stream = db->stream((int)ki);
         a.priority = side ? 1 : 0;
+        if (const char* pe = getenv("OPAL_HIP_SIDE_PRIO")) a.priority = side ? atoi(pe) : 0;  // tuning hook
         if (debug_on())
             fprintf(stderr, "[opal] launch width=%d mode=%d end=%d items=[%d,+%d) G=%d rows=%d waves/block=%d ldsPad=%d%s%s\n", width,
                     c.mode, swEndPass, k.first, k.count, k.G, k.rows, k.wpb, k.ldsPad, skew ? " skew" : "", side ? " (side stream)" : "");
@@ -704,22 +751,27 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
     bool fits16 = Go <= 32767 && Ge <= 32767 && maxS <= 32767 && minS >= -32768;
     if (const char* e = getenv("OPAL_HIP_FORCE_WIDTH")) { if (atoi(e) == 32) fits16 = false; }  // test / profiling hook
 
-    // Narrow rung: 17 = plain 16-bit, one sequence per lane (full-rate VALU, 4-byte LDS profile entries);
-    // 16 = packed pairs (half-rate VALU, 2-byte entries: used when the wider profile does not fit LDS).
+    // Narrow rung: 17 = plain 16-bit, one sequence per lane (full-rate VALU, 4-byte LDS profile entries); 18 = the same
+    // with 2-byte entries (+0.5 instructions per cell: long queries whose 4-byte profile exceeds LDS); 16 = packed pairs
+    // (half-rate VALU, 2-byte entries: what is left, e.g. multi-chunk queries).
     int narrow = 17;
-    if (const char* e = getenv("OPAL_HIP_NARROW")) narrow = atoi(e) == 16 ? 16 : 17;
+    if (const char* e = getenv("OPAL_HIP_NARROW")) { const int v = atoi(e); narrow = (v == 16 || v == 18) ? v : 17; }
     {
-        bool fits17 = false;  // does some single-launch geometry hold the query with 4-byte profile entries?
-        for (int G = 1; G <= 64 && !fits17; G *= 2) {
-            const int need = (Q + G - 1) / G;
-            if (need > OPAL_HIP_MAX_ROWS) continue;
-            const int rows = opal_hip_rows_supported(17, mode, 0, need);
-            fits17 = rows && opal_hip_lds_bytes(17, G, rows, A) <= 160 * 1024;
-        }
-        const char* force = getenv("OPAL_HIP_NARROW_FORCE");  // "17": run width 17 in row chunks rather than packed pairs
-        if (!fits17 && !(force && atoi(force) == 17)) narrow = 16;
+        auto fits = [&](int width) {  // does some single-launch geometry hold the query at this width?
+            for (int G = 1; G <= 64; G *= 2) {
+                const int need = (Q + G - 1) / G;
+                if (need > OPAL_HIP_MAX_ROWS) continue;
+                const int rows = opal_hip_rows_supported(width, mode, 0, need);
+                if (rows && opal_hip_lds_bytes(width, G, rows, A) <= 160 * 1024) return true;
+            }
+            return false;
+        };
+        const char* force = getenv("OPAL_HIP_NARROW_FORCE");  // "17": run width 17 in row chunks rather than switching width
+        if (narrow == 17 && !fits(17) && !(force && atoi(force) == 17)) narrow = fits(18) ? 18 : 16;
+        if (narrow == 18 && !fits(18)) narrow = 16;
     }
-    const int satLimit = narrow == 17 ? (int)(32767 - maxS) : 32767;
+    const bool plain = narrow != 16;
+    const int satLimit = plain ? (int)(32767 - maxS) : 32767;
     SearchCtx c{db, Q, A, Go, Ge, mode, wantEnd, dScore, dEndQ, dEndT, satLimit, mode == OPAL_MODE_SW ? -satLimit : 0, maxS};
     const int nNarrow = narrow == 16 ? P : 2 * P;  // items of the narrow rung: pairs or sequences
     auto pairLenOf = [db](int p) { return db->pairLen[2 * (size_t)p]; };   // width-16 items are pairs
@@ -737,7 +789,7 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
         std::vector<int> rerun;  // the re-run list, longest sequence first
         if (fits16) {
             if (narrow == 16) rc = launch_range(c, 16, wantEnd, 0, nullptr, 0, nNarrow, pairLenOf, db->ovfCount.p);
-            else rc = launch_range(c, 17, wantEnd, 0, nullptr, 0, nNarrow, seqLenOf, db->ovfCount.p);
+            else rc = launch_range(c, narrow, wantEnd, 0, nullptr, 0, nNarrow, seqLenOf, db->ovfCount.p);
             if (rc) return rc;
             int cnt = 0;
             if (opal_hip_memcpy_d2h(&cnt, db->ovfCount.p, sizeof(int), st) || opal_hip_stream_sync(st))
@@ -810,7 +862,7 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
             return OPAL_ERR_NO_SIMD_SUPPORT;
         if (P > p32) {
             const int e = narrow == 16 ? launch_range(c, 16, 0, 0, nullptr, p32, P - p32, pairLenOf, db->ovfCount.p)
-                                       : launch_range(c, 17, 0, 0, nullptr, 2 * p32, 2 * (P - p32), seqLenOf, db->ovfCount.p);
+                                       : launch_range(c, narrow, 0, 0, nullptr, 2 * p32, 2 * (P - p32), seqLenOf, db->ovfCount.p);
             if (e) return OPAL_ERR_NO_SIMD_SUPPORT;
         }
     }

@@ -173,7 +173,7 @@ extern "C" int opal_hip_scatter_results(const int* quads, int count, int* score,
 }
 
 static size_t lds_bytes(int width, int G, int rows, int A) {
-    const int es = width == 16 ? 2 : 4;  // width 17 keeps 4-byte profile entries (value in the low half)
+    const int es = (width == 16 || width == 18) ? 2 : 4;  // widths 17 and 32 keep 4-byte profile entries
     return (size_t)(A + 1) * (size_t)opal_profile_stride(es, G, rows) + 16;
 }
 
@@ -189,6 +189,7 @@ static KernelFn pick_kernel(int width, int mode, int flags, int rows) {
         return nullptr;
     }
     if (width == 17) return opal_kernel_s16(mode, flags, rows);
+    if (width == 18) return opal_kernel_s18(mode, flags, rows);
     if (width == 16) return opal_kernel_w16(mode, flags, rows);
     if (width == 32) return opal_kernel_w32(mode, flags, rows);
     return nullptr;
@@ -208,6 +209,7 @@ extern "C" int opal_hip_rows_supported(int width, int mode, int want_end, int mi
     memset(&a, 0, sizeof a);
     a.width = width; a.mode = mode; a.want_end = want_end & 1;
     a.chunk_flags = (want_end & 2) ? 1 : 0;  /* bit1 of want_end: ask about the multi-chunk variants */
+    a.skew = (want_end & 4) ? 1 : 0;         /* bit2: the diagonal-skewed variants */
     for (int r = min_rows < 1 ? 1 : min_rows; r <= OPAL_HIP_MAX_ROWS; r++)
         if (pick_kernel(width, mode, launch_flags(&a), r)) return r;
     return 0;
@@ -222,6 +224,8 @@ extern "C" int opal_hip_kernel_vgprs(const OpalHipLaunch* a) {
     if (hipFuncGetAttributes(&attr, (const void*)fn) != hipSuccess) return 0;
     return attr.numRegs;
 }
+
+extern "C" int opal_hip_max_waves_per_block(int width) { return opal_max_waves_per_block(width); }
 
 extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
     const int G = a->lanes_per_seq;
@@ -259,8 +263,9 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
     p.negPad = a->neg_pad;
     const int slots = 64 / G;
     const int jobs = (a->num_items + slots - 1) / slots;
-    int wpb = (a->waves_per_block >= 1 && a->waves_per_block <= MAX_WAVES_PER_BLOCK) ? a->waves_per_block : WAVES_PER_BLOCK;
-    if (const char* e = getenv("OPAL_HIP_WAVES_PER_BLOCK")) { const int w = atoi(e); if (w >= 1 && w <= MAX_WAVES_PER_BLOCK) wpb = w; }
+    const int maxWpb = opal_max_waves_per_block(a->width);
+    int wpb = (a->waves_per_block >= 1 && a->waves_per_block <= maxWpb) ? a->waves_per_block : WAVES_PER_BLOCK;
+    if (const char* e = getenv("OPAL_HIP_WAVES_PER_BLOCK")) { const int w = atoi(e); if (w >= 1 && w <= maxWpb) wpb = w; }
     const int blocks = (jobs + wpb - 1) / wpb;
     size_t lds = lds_bytes(a->width, G, a->rows_per_lane, a->alphabet_length);
     if (a->lds_bytes_min > 0 && (size_t)a->lds_bytes_min > lds && a->lds_bytes_min <= 160 * 1024) lds = (size_t)a->lds_bytes_min;

@@ -407,7 +407,29 @@ def test_reentrant_from_host_threads(ours, oracle):
         _check(out[i], oracle.search(q, db, 3, 1, m, 1, MODES[mode]), mode, f"thread {i} {mode}")
 
 
-@pytest.mark.parametrize("narrow", ["16", "17"])
+@pytest.mark.parametrize("mode", ["SW", "NW", "HW", "OV"])
+@pytest.mark.parametrize("qlen", [513, 1100, 2000])
+def test_width18_two_byte_profile_kernels(mode, qlen, ours, oracle, monkeypatch):
+    """The plain-16-bit kernels with 2-byte profile entries (width 18: what 2000-aa queries run on), forced also for
+    shorter queries: every rows-per-lane instantiation family (8/16/24/32/40), score + end location and score only."""
+    from opal_amd import synth
+    from opal_amd.score_matrix import blosum50
+    monkeypatch.setenv("OPAL_HIP_NARROW", "18")
+    res, offs, lens = synth.database(260, seed=42, first=70000 + qlen)
+    db = [res[offs[i]:offs[i + 1]] for i in range(260)] + [synth.query(qlen, seed=7)[: qlen - 3].copy()]
+    q = synth.query(qlen, seed=7)
+    m = blosum50()[1]
+    for lanes in (("", "64") if qlen > 1280 else ("", "32", "64")):
+        if lanes:
+            monkeypatch.setenv("OPAL_HIP_LANES_PER_SEQ", lanes)
+        got = ours.search(q, db, 3, 1, m, 1, MODES[mode])[:4]
+        _check(got, oracle.search(q, db, 3, 1, m, 1, MODES[mode]), mode, f"width 18 q{qlen} {mode} lanes={lanes or 'auto'}")
+    if mode == "SW":
+        got0 = ours.search(q, db, 11, 1, m, 0, MODES[mode])[:4]
+        _check(got0, oracle.search(q, db, 11, 1, m, 0, MODES[mode]), mode, f"width 18 q{qlen} score only")
+
+
+@pytest.mark.parametrize("narrow", ["16", "17", "18"])
 def test_many_saturated_scores_rerun(narrow, ours, oracle, monkeypatch):
     """Most of the database exceeds the 16-bit rung: the ballot-built re-run list must hold every one of them
     exactly once (scores and end locations come from the 32-bit kernels), the rest stays at 16 bit."""
