@@ -156,15 +156,18 @@ struct OpalxDb {
     DevBuf<uint16_t> tokens;
     DevBuf<uint64_t> pairOff;
     DevBuf<int> dPairLen, dPairSeq;
-    DevBuf<int> ovfCount;  // [2] counters: narrow-rung overflow list length, width-32 wrap count
+    // One "search header" per search, uploaded with a single copy: {counters[4], score matrix, query}. ovfCount[0] =
+    // length of the 16-bit rung's re-run list, [1] = width-32 wrap count.
+    DevBuf<unsigned char> header;
+    PinBuf<unsigned char> hHeader;
+    struct View32 { int* p = nullptr; } ovfCount, matrix;
+    struct View8 { unsigned char* p = nullptr; } query;
     DevBuf<int> ovfItems;  // [2P]
     // device: per-search scratch
     DevBuf<unsigned char> boundary;  // 16 B per token: chunk-boundary rows of long queries (allocated on first use)
     DevBuf<int> scratch;             // [2N] per-sequence values carried across query chunks
     DevBuf<int> results;             // [3N] device staging of host-array searches
     DevBuf<int> quads;               // degenerate results on their way to the scatter kernel
-    DevBuf<unsigned char> query;
-    DevBuf<int> matrix;
     // start-location pass (rev_kernel.hip): caller index -> pair*2+half, flags and the host-redo list
     DevBuf<int> seqItem;
     bool seqItemValid = false;
@@ -223,8 +226,9 @@ static bool device_ok() {
 
 static void db_release(OpalxDb* db) {
     db->tokens.release(); db->pairOff.release(); db->dPairLen.release(); db->dPairSeq.release();
-    db->ovfCount.release(); db->ovfItems.release(); db->boundary.release(); db->scratch.release();
-    db->results.release(); db->quads.release(); db->query.release(); db->matrix.release();
+    db->header.release(); db->hHeader.release(); db->ovfItems.release(); db->boundary.release(); db->scratch.release();
+    db->results.release(); db->quads.release();
+    db->ovfCount.p = nullptr; db->matrix.p = nullptr; db->query.p = nullptr;
     db->seqItem.release(); db->revFlags.release(); db->redo.release();
     db->raw.release(); db->rawOff.release(); db->hRaw.release(); db->hResults.release();
     for (void*& st : db->streams) { opal_hip_stream_destroy(st); st = nullptr; }
@@ -257,7 +261,7 @@ static bool db_fill(OpalxDb* db, HostPack& hp, RawKind kind, const std::function
     const double slack = db->cached ? 1.15 : 1.0;
     void* st = db->main();
     bool ok = st && db->tokens.ensure(db->numTokens, slack) && db->pairOff.ensure(P, slack) && db->dPairLen.ensure(2 * P, slack) &&
-              db->dPairSeq.ensure(2 * P, slack) && db->ovfCount.ensure(2) && db->ovfItems.ensure(2 * P, slack) &&
+              db->dPairSeq.ensure(2 * P, slack) && db->ovfItems.ensure(2 * P, slack) &&
               db->rawOff.ensure(2 * P, slack);
     if (!ok) return false;
     if (!P) return true;
@@ -490,17 +494,17 @@ static std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass,
     const int slotsBase = 64 / cands[base].G;
     const double totalClocks = lenSum * sample / slotsBase * step_clocks(width, cands[base].rows) / simds;
     const char* budEnv = getenv("OPAL_HIP_TAIL_FRACTION");
-    const double budget = std::max(totalClocks * (budEnv && *budEnv ? atof(budEnv) : 0.35), 20000.0);
+    const double budget = std::max(totalClocks * (budEnv && *budEnv ? atof(budEnv) : 0.5), 20000.0);
     // walk from the longest item: the smallest geometry (>= base) whose lone-wave time fits the budget
     size_t ci = cands.size() - 1;
     int start = first;
-    // Measured (round 2, C2 database): moving more than the few hundred longest sequences into the high-G classes makes
-    // the search slower (1.6 -> 1.9-2.3 ms: their prioritised waves starve the bulk launch), so the boundary stays where
-    // the pipe-rate model puts it; OPAL_HIP_TAIL_MODEL=lone switches to the lone-wave timing for experiments.
+    // A class of long sequences is a handful of waves, each the oldest wave of its SIMD and therefore running at the
+    // lone-wave rate: that is the time a boundary candidate is judged by. (Round 2, C2 database, 100 000 / 50 000
+    // sequences: 1.594 -> 1.567 ms and 1.013 -> 0.967 ms against the pipe-rate model; OPAL_HIP_TAIL_MODEL=pipe restores it.)
     const char* tm = getenv("OPAL_HIP_TAIL_MODEL");
-    const bool loneModel = tm && !strcmp(tm, "lone");
+    const bool pipeModel = tm && !strcmp(tm, "pipe");
     auto fits = [&](size_t c, int len) {
-        const double per = loneModel ? lone_step_clocks(width, cands[c].rows) : step_clocks(width, cands[c].rows);
+        const double per = pipeModel ? step_clocks(width, cands[c].rows) : lone_step_clocks(width, cands[c].rows);
         return (len + cands[c].G - 1) * per <= budget;
     };
     auto cls = [&](int s, int n, size_t c) { return LaunchClass{s, n, cands[c].G, cands[c].rows, cands[c].wpb, cands[c].ldsPad}; };
@@ -628,7 +632,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
         const int skew = maySkew && skew_ok(k.first);
         {   // the plan assumed the skewed kernels (every rows-per-lane value exists); a class that cannot use them
             // takes the plain kernel's next instantiated value
-            const int rows = opal_hip_rows_supported(width, c.mode, swEndPass | (skew ? 4 : 0), (c.Q + k.G - 1) / k.G);
+            const int rows = opal_hip_rows_supported(width, c.mode, swEndPass | (skew ? 4 : 0), k.rows);  // k.rows if it exists
             if (rows && rows != k.rows && opal_hip_lds_bytes(width, k.G, rows, c.A) <= 160 * 1024) {
                 k.rows = rows;
                 pick_occupancy(kernel_vgprs(width, c.mode, swEndPass, 0, skew, rows), opal_hip_lds_bytes(width, k.G, rows, c.A), &k.wpb, &k.ldsPad,
@@ -670,11 +674,20 @@ static bool args_fit_int32(int Go, int Ge, const int* M, int A) {
     return true;
 }
 
+// Query, score matrix and zeroed counters reach the device as ONE copy from pinned memory (three separate small
+// copies and a memset cost ~10 us of stream time each, on a search whose kernels take 1.6 ms).
 static int ensure_query_buffers(OpalxDb* db, const unsigned char* query, int Q, const int* M, int A) {
-    const size_t qb = (size_t)std::max(Q, 1), mb = (size_t)A * A;
-    if (!db->query.ensure(qb) || !db->matrix.ensure(mb)) return 1;
-    if (Q && opal_hip_memcpy_h2d(db->query.p, query, (size_t)Q, db->main())) return 1;
-    if (opal_hip_memcpy_h2d(db->matrix.p, M, mb * sizeof(int), db->main())) return 1;
+    const size_t mb = (size_t)A * A * sizeof(int);
+    const size_t bytes = (16 + mb + (size_t)std::max(Q, 1) + 15) / 16 * 16;
+    if (!db->header.ensure(bytes, 1.5) || !db->hHeader.ensure(bytes, 1.5)) return 1;
+    unsigned char* h = db->hHeader.p;
+    memset(h, 0, 16);
+    memcpy(h + 16, M, mb);
+    if (Q) memcpy(h + 16 + mb, query, (size_t)Q);
+    if (opal_hip_memcpy_h2d(db->header.p, h, 16 + mb + (size_t)Q, db->main())) return 1;
+    db->ovfCount.p = (int*)db->header.p;
+    db->matrix.p = (int*)(db->header.p + 16);
+    db->query.p = db->header.p + 16 + mb;
     return 0;
 }
 
@@ -743,17 +756,16 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
     }
     if (Q == 0 || P == 0) return opal_hip_stream_sync(st) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
 
-    if (ensure_query_buffers(db, query, Q, M, A)) return OPAL_ERR_NO_SIMD_SUPPORT;
-    if (opal_hip_memset(db->ovfCount.p, 0, 2 * sizeof(int), st)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (ensure_query_buffers(db, query, Q, M, A)) return OPAL_ERR_NO_SIMD_SUPPORT;  // (also zeroes the counters)
 
     long long maxS = 0, minS = 0;
     for (int i = 0; i < A * A; i++) { maxS = std::max<long long>(maxS, M[i]); minS = std::min<long long>(minS, M[i]); }
     bool fits16 = Go <= 32767 && Ge <= 32767 && maxS <= 32767 && minS >= -32768;
     if (const char* e = getenv("OPAL_HIP_FORCE_WIDTH")) { if (atoi(e) == 32) fits16 = false; }  // test / profiling hook
 
-    // Narrow rung: 17 = plain 16-bit, one sequence per lane (full-rate VALU, 4-byte LDS profile entries); 18 = the same
-    // with 2-byte entries (+0.5 instructions per cell: long queries whose 4-byte profile exceeds LDS); 16 = packed pairs
-    // (half-rate VALU, 2-byte entries: what is left, e.g. multi-chunk queries).
+    // Narrow rung: 17 = plain 16-bit, one sequence per lane (full-rate VALU, 4-byte LDS profile entries); 16 = packed
+    // pairs (half-rate VALU, 2-byte entries: queries whose 4-byte profile exceeds LDS); 18 = plain with 2-byte entries
+    // (+0.5 instructions per cell; experimental, on request only).
     int narrow = 17;
     if (const char* e = getenv("OPAL_HIP_NARROW")) { const int v = atoi(e); narrow = (v == 16 || v == 18) ? v : 17; }
     {
@@ -767,7 +779,9 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
             return false;
         };
         const char* force = getenv("OPAL_HIP_NARROW_FORCE");  // "17": run width 17 in row chunks rather than switching width
-        if (narrow == 17 && !fits(17) && !(force && atoi(force) == 17)) narrow = fits(18) ? 18 : 16;
+        // (width 18 measured SLOWER than the packed pairs on the 2000-aa workload, 15.1 vs 14.8 ms, so it is never
+        // chosen automatically: OPAL_HIP_NARROW=18 selects it for experiments)
+        if (narrow == 17 && !fits(17) && !(force && atoi(force) == 17)) narrow = 16;
         if (narrow == 18 && !fits(18)) narrow = 16;
     }
     const bool plain = narrow != 16;
@@ -792,7 +806,11 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
             else rc = launch_range(c, narrow, wantEnd, 0, nullptr, 0, nNarrow, seqLenOf, db->ovfCount.p);
             if (rc) return rc;
             int cnt = 0;
-            if (opal_hip_memcpy_d2h(&cnt, db->ovfCount.p, sizeof(int), st) || opal_hip_stream_sync(st))
+            // The re-run list can only be non-empty if some score can reach the rung's limit at all: with
+            // min(Q, longest sequence) * max(matrix) below it (a 300-aa query on BLOSUM50: 4 500 against 32 752) the
+            // count need not be read back, and the search has no host round trip between its launches and its end.
+            const bool canSaturate = (long long)std::min<long long>(Q, db->pairLen[0]) * maxS >= (long long)satLimit;
+            if (canSaturate && (opal_hip_memcpy_d2h(&cnt, db->ovfCount.p, sizeof(int), st) || opal_hip_stream_sync(st)))
                 return OPAL_ERR_NO_SIMD_SUPPORT;
             if (cnt > 0) {
                 // The kernels append in completion order: sort the list by length so that the width-32 launch
