@@ -492,9 +492,15 @@ __global__ void __launch_bounds__(opal_max_waves_per_block(WIDTH) * 64) opal_dp_
     uint2 bndNext = make_uint2(0u, 0u);
     if (hasPrev && 0 < slotLen) bndNext = p.bnd[bndIdx(0)];
 
+    int slotMax = 0;                         // SW end location: slot-wide running maximum (see the scan filter)
     int topHv = V::clampv(-(long long)Go);  // NW: H[-1][0]
     reg sRv = 0;                             // SKEW: s*Ge as a 16-bit value
     for (int s = 0; s < nsteps; s++) {
+        if (MODE == MODE_SW && SWEND && NH == 1 && (s & 7) == 0) {
+            int v = V::half(mx, 0);
+            for (int d = 1; d < G; d <<= 1) { const int o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+            slotMax = v;
+        }
         if ((s & (G - 1)) == 0) {  // wave-uniform: refill the queue with columns s .. s+G-1
             const unsigned tok = tokNext;
             const int col = s + k;
@@ -647,32 +653,42 @@ __global__ void __launch_bounds__(opal_max_waves_per_block(WIDTH) * 64) opal_dp_
                 // +2.6 instructions per cell, the same relative price the reference pays for end locations. A scan
                 // restricted to 8-row blocks was tried in round 2 and was no faster: lanes improve in different blocks.)
                 const reg nm = V::maxs(mx, cm);
-                bool improved = false;
+                auto scan = [&](int hh) {
+                    int r = 0;
+                    if constexpr (PLAIN) {
+                        constexpr int NBLK4 = (S + 3) / 4;
+                        static_for<NBLK4>([&](auto bc) {  // highest block first: the smallest row holding it wins
+                            constexpr int b = NBLK4 - 1 - decltype(bc)::value;
+                            constexpr int n = (S - 4 * b) < 4 ? (S - 4 * b) : 4;
+                            V::template scan_rows<n, 4 * b>(&Hp[4 * b], cm, r);
+                        });
+                    } else {
 #pragma unroll
-                for (int hh = 0; hh < NH; hh++) improved |= V::half(nm, hh) != V::half(mx, hh);
-                if (improved) {
-#pragma unroll
-                    for (int hh = 0; hh < NH; hh++) {
-                        const int cv = V::half(cm, hh);
-                        if (cv > V::half(mx, hh)) {
-                            int r = 0;
-                            if constexpr (PLAIN) {
-                                constexpr int NBLK4 = (S + 3) / 4;
-                                static_for<NBLK4>([&](auto bc) {  // highest block first: the smallest row holding it wins
-                                    constexpr int b = NBLK4 - 1 - decltype(bc)::value;
-                                    constexpr int n = (S - 4 * b) < 4 ? (S - 4 * b) : 4;
-                                    V::template scan_rows<n, 4 * b>(&Hp[4 * b], cm, r);
-                                });
-                            } else {
-#pragma unroll
-                                for (int j = S - 1; j >= 0; j--)
-                                    if (V::same(Hp[j], cm, hh)) r = j;  // smallest row of the column holding it
-                            }
-                            endRow[hh] = r0 + r;
-                            endCol[hh] = c;
-                        }
+                        for (int j = S - 1; j >= 0; j--)
+                            if (V::same(Hp[j], cm, hh)) r = j;  // smallest row of the column holding it
                     }
+                    endRow[hh] = r0 + r;
+                    endCol[hh] = c;
+                };
+                if constexpr (NH == 1) {
+                    // One sequence per lane: a strict improvement is worth scanning only if it reaches the SLOT-wide
+                    // running maximum (slotMax, refreshed every 8 steps from all lanes of the slot; a stale = smaller
+                    // value only lets more scans through). A value below it can never be the final score, and the cell
+                    // that holds the final score passes the filter whenever it occurs (ties included: the final
+                    // reduction breaks them by column, then lane). This cuts the scans from most steps to about a third.
+                    const int cv = V::half(cm, 0);
+                    if (cv > V::half(mx, 0) && cv >= slotMax) scan(0);
                     mx = nm;
+                } else {
+                    bool improved = false;
+#pragma unroll
+                    for (int hh = 0; hh < NH; hh++) improved |= V::half(nm, hh) != V::half(mx, hh);
+                    if (improved) {
+#pragma unroll
+                        for (int hh = 0; hh < NH; hh++)
+                            if (V::half(cm, hh) > V::half(mx, hh)) scan(hh);
+                        mx = nm;
+                    }
                 }
             }
             if (MODE == MODE_NW) {
