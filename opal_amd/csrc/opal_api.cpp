@@ -626,8 +626,15 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
         if (!fork || opal_hip_event_record(fork, db->main())) return OPAL_ERR_NO_SIMD_SUPPORT;
     }
     int err = 0;
-    int recorded = 0;
-    for (size_t ki = 0; ki < classes.size() && !err; ki++) {
+    bool recorded[3] = {false, false, false};
+    // submission order: experiment hook OPAL_HIP_MAIN_FIRST=1 submits the bulk launch before the side launches
+    std::vector<size_t> order;
+    const char* mf = getenv("OPAL_HIP_MAIN_FIRST");
+    if (mf && *mf == '1') order.push_back(classes.size() - 1);
+    for (size_t ki = 0; ki < classes.size(); ki++)
+        if (!(mf && *mf == '1' && ki == classes.size() - 1)) order.push_back(ki);
+    for (size_t oi = 0; oi < order.size() && !err; oi++) {
+        const size_t ki = order[oi];
         LaunchClass k = classes[ki];
         const int skew = maySkew && skew_ok(k.first);
         {   // the plan assumed the skewed kernels (every rows-per-lane value exists); a class that cannot use them
@@ -656,11 +663,11 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
         if (side) {
             void* done = db->event(1 + (int)ki);
             if (!done || opal_hip_event_record(done, a.stream)) { err = 1; break; }
-            recorded = (int)ki + 1;
+            recorded[ki] = true;
         }
     }
-    for (int i = 0; i < recorded; i++)
-        if (opal_hip_stream_wait_event(db->main(), db->event(1 + i))) err = 1;
+    for (int i = 0; i < 3; i++)
+        if (recorded[i] && opal_hip_stream_wait_event(db->main(), db->event(1 + i))) err = 1;
     if (err) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }  // nothing of this call stays in flight
     return 0;
 }
@@ -963,10 +970,21 @@ static std::vector<int> call_devices() {
  * so far. Returns shard[k] = list of positions into `lens`.
  */
 static std::vector<std::vector<int>> deal_groups(const int* lens, int n, int parts) {
+    // order by length, longest first (counting sort, stable; a comparison sort of 100 000 lengths costs milliseconds)
+    int maxLen = 0;
+    for (int i = 0; i < n; i++) maxLen = std::max(maxLen, lens[i]);
     std::vector<int> order((size_t)n);
-    for (int i = 0; i < n; i++) order[(size_t)i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lens[a] > lens[b]; });
+    if (maxLen <= (1 << 22)) {
+        std::vector<int> start((size_t)maxLen + 2, 0);
+        for (int i = 0; i < n; i++) start[(size_t)maxLen - std::max(lens[i], 0) + 1]++;
+        for (size_t b = 1; b < start.size(); b++) start[b] += start[b - 1];
+        for (int i = 0; i < n; i++) order[(size_t)start[(size_t)maxLen - std::max(lens[i], 0)]++] = i;
+    } else {
+        for (int i = 0; i < n; i++) order[(size_t)i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lens[a] > lens[b]; });
+    }
     std::vector<std::vector<int>> shard((size_t)parts);
+    for (auto& v : shard) v.reserve((size_t)n / parts + 64);
     std::vector<long long> load((size_t)parts, 0);
     for (int g = 0; g < n; g += 64) {
         const int e = std::min(n, g + 64);
