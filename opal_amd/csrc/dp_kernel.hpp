@@ -292,17 +292,26 @@ __device__ __forceinline__ int4 lds_ld16(unsigned addr) {
 // cycles): a lane's segment of a letter's profile is padded to a multiple of 16 bytes, and the letter
 // stride is an ODD multiple of 16 bytes so that different letters fall into different 16-byte bank slots.
 __host__ __device__ inline int opal_rows_per_read(int es) { return 16 / es; }
-__host__ __device__ inline int opal_profile_stride(int es, int G, int S) {
+// Bytes of one lane's segment of a letter's profile. For width 18 (es == 2 with plain arithmetic, G = 64) the segment
+// is padded to an ODD number of 16-byte units: with 32 rows x 2 B = 4 units the 16 lanes of a read group would fall on
+// 4 bank positions only (4-way conflicts even when every lane reads the same letter).
+__host__ __device__ constexpr int opal_lane_bytes(int es, int S, int padOdd) {
     const int rpr = 16 / es;
-    const int rowsPad = (S + rpr - 1) / rpr * rpr;
-    int stride = G * rowsPad * es;        // one target letter's profile
+    int b = (S + rpr - 1) / rpr * rpr * es;
+    if (padOdd && ((b / 16) & 1) == 0) b += 16;
+    return b;
+}
+__host__ __device__ inline int opal_profile_stride(int es, int G, int S, int padOdd = 0) {
+    int stride = G * opal_lane_bytes(es, S, padOdd);        // one target letter's profile
     if (((stride / 16) & 1) == 0) stride += 16;
     return stride;
 }
 
 // ------------------------------------------------------------------ the DP kernel
+// (the second launch bound asks the register allocator for 4 waves per SIMD, i.e. at most 128 VGPRs, on the single-launch
+// plain-16-bit kernels: OV at 38-39 rows per lane compiled to 129-131 registers without it, one wave per SIMD less)
 template <int WIDTH, int MODE, int FLAGS, int S>
-__global__ void __launch_bounds__(opal_max_waves_per_block(WIDTH) * 64) opal_dp_kernel(const KParams p) {
+__global__ void __launch_bounds__(opal_max_waves_per_block(WIDTH) * 64, (WIDTH == 17 && !(FLAGS & FLAG_MULTI)) ? 4 : 1) opal_dp_kernel(const KParams p) {
     using V = Vec<WIDTH>;
     using reg = typename V::reg;
     using elem = typename V::elem;
@@ -310,7 +319,7 @@ __global__ void __launch_bounds__(opal_max_waves_per_block(WIDTH) * 64) opal_dp_
     constexpr int ES = (int)sizeof(elem);  // bytes per profile entry
     constexpr int RB = 16 / ES;            // rows fetched per LDS read (one ds_read_b128)
     constexpr int SPAD = (S + RB - 1) / RB * RB;
-    constexpr int LANE_BYTES = SPAD * ES;  // one lane's segment of a profile row
+    constexpr int LANE_BYTES = opal_lane_bytes(ES, S, WIDTH == 18);  // one lane's segment of a profile row
     constexpr bool SWEND = (FLAGS & FLAG_SWEND) != 0;
     constexpr bool WRAP = (FLAGS & FLAG_WRAP) != 0;
     constexpr bool MULTI = (FLAGS & FLAG_MULTI) != 0;
@@ -320,7 +329,7 @@ __global__ void __launch_bounds__(opal_max_waves_per_block(WIDTH) * 64) opal_dp_
 
     const int log2G = p.log2G;
     const int G = 1 << log2G;
-    const int stride = opal_profile_stride(ES, G, S);
+    const int stride = opal_profile_stride(ES, G, S, WIDTH == 18);
     const int Q = p.Q, A = p.A;
     // Query rows are spread over G*S >= Q lane registers. NW pads BELOW the query (pad rows never
     // feed a real row). SW/HW/OV pad ABOVE it: a virtual row with profile 0, H[r][-1] = 0 and

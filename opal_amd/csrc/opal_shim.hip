@@ -174,7 +174,7 @@ extern "C" int opal_hip_scatter_results(const int* quads, int count, int* score,
 
 static size_t lds_bytes(int width, int G, int rows, int A) {
     const int es = (width == 16 || width == 18) ? 2 : 4;  // widths 17 and 32 keep 4-byte profile entries
-    return (size_t)(A + 1) * (size_t)opal_profile_stride(es, G, rows) + 16;
+    return (size_t)(A + 1) * (size_t)opal_profile_stride(es, G, rows, width == 18) + 16;
 }
 
 extern "C" size_t opal_hip_lds_bytes(int width, int lanes_per_seq, int rows_per_lane, int alphabet_length) {
