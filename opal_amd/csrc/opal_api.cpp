@@ -54,10 +54,13 @@ static bool debug_on() {
 
 // ------------------------------------------------------------------------------------ buffers
 // Device / pinned-host buffers that only ever grow: a cached context keeps them across calls.
+// (A cached context that once held a multi-gigabyte database does not keep those buffers for a later small one:
+// a buffer more than 4x too large and above 256 MiB is given back first.)
 template <typename T> struct DevBuf {
     T* p = nullptr;
     size_t cap = 0;  // elements
     bool ensure(size_t n, double slack = 1.0) {
+        if (p && cap > 4 * std::max<size_t>(n, 1) && cap * sizeof(T) > (256u << 20)) release();
         if (n <= cap && p) return true;
         opal_hip_free(p);
         const size_t want = std::max<size_t>((size_t)((double)n * slack), 1);
@@ -71,6 +74,7 @@ template <typename T> struct PinBuf {
     T* p = nullptr;
     size_t cap = 0;
     bool ensure(size_t n, double slack = 1.0) {
+        if (p && cap > 4 * std::max<size_t>(n, 1) && cap * sizeof(T) > (256u << 20)) release();
         if (n <= cap && p) return true;
         opal_hip_host_free(p);
         const size_t want = std::max<size_t>((size_t)((double)n * slack), 1);
@@ -1346,9 +1350,13 @@ extern "C" int opalSearchDatabase(unsigned char query[], int queryLength, unsign
                                        alphabetLength, results, searchType, mode, searchType != OPAL_SEARCH_ALIGNMENT,
                                        searchType == OPAL_SEARCH_ALIGNMENT ? starts.data() : nullptr);
     if (rc) return rc;
-    if (searchType == OPAL_SEARCH_ALIGNMENT)
-        return opalx_find_alignments_from(query, queryLength, db, dbLength, dbSeqLengths, gapOpen, gapExt, scoreMatrix,
-                                          alphabetLength, results, mode, starts.data(), starts.data() + dbLength);
+    if (searchType == OPAL_SEARCH_ALIGNMENT) {
+        const double t0 = now_ms();
+        const int arc = opalx_find_alignments_from(query, queryLength, db, dbLength, dbSeqLengths, gapOpen, gapExt, scoreMatrix,
+                                                   alphabetLength, results, mode, starts.data(), starts.data() + dbLength);
+        if (debug_on()) fprintf(stderr, "[opal] host traceback of %d alignments: %.2f ms\n", dbLength, now_ms() - t0);
+        return arc;
+    }
     return 0;
 }
 

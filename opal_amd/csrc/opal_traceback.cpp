@@ -57,35 +57,51 @@ struct Aligned {
  * NW), stop at the first column where a cell the mode allows as an end reaches `scoreLimit`
  * (reference opal.cpp:1236-1431).
  */
-static void find_alignment(const unsigned char* q, int Q, const unsigned char* t, int T, int Go, int Ge, const int* M, int A,
-                           int scoreLimit, int mode, Aligned& out) {
-    std::vector<int> Hp((size_t)Q), Ep((size_t)Q), Hc((size_t)Q), Ec((size_t)Q);
-    for (int r = 0; r < Q; r++) { Hp[r] = -Go - r * Ge; Ep[r] = NEG; }  // initial column (opal.cpp:1266-1269)
+// Buffers a host thread keeps across the alignments it traces (no allocation per alignment in the steady state).
+struct Workspace {
+    std::vector<int> Hp, Ep, Hc, Ec;
     std::vector<uint8_t> dirs;
-    dirs.reserve((size_t)Q * (size_t)std::min(T, 1024));
+    std::vector<unsigned char> rTarget;
+};
+
+// `prof` = the query profile of q: prof[letter * profStride + r] = M[q[r]][letter] (built once per call for the whole
+// reversed query; an alignment's rows are a suffix of it), so the inner loop reads its scores sequentially.
+static void find_alignment(const unsigned char* q, int Q, const unsigned char* t, int T, int Go, int Ge, const int* prof,
+                           int profStride, int scoreLimit, int mode, Aligned& out, Workspace& ws) {
+    std::vector<int>&Hv = ws.Hp, &Ev = ws.Ep;  // one column of H and E, updated in place
+    Hv.resize((size_t)Q); Ev.resize((size_t)Q);
+    for (int r = 0; r < Q; r++) { Hv[r] = -Go - r * Ge; Ev[r] = NEG; }  // initial column (opal.cpp:1266-1269)
+    std::vector<uint8_t>& dirs = ws.dirs;
+    if (dirs.size() < (size_t)Q * (size_t)std::min(T, 64)) dirs.resize((size_t)Q * (size_t)std::min(T, 64));
     int maxScore = INT_MIN, H = INT_MIN, c = 0;
+    int* const Hc = Hv.data();
+    int* const Ec = Ev.data();
     for (c = 0; c < T && maxScore < scoreLimit; c++) {
-        dirs.resize((size_t)(c + 1) * Q);
+        if (dirs.size() < (size_t)(c + 1) * Q) dirs.resize(std::max((size_t)(c + 1) * Q, dirs.size() * 2));  // grows, never shrinks
         uint8_t* d = dirs.data() + (size_t)c * Q;
+        const int* pc = prof + (size_t)t[c] * profStride;
         int uF = NEG, uH = -Go - c * Ge, ulH = c == 0 ? 0 : uH + Ge;
+        int colMax = INT_MIN;
         for (int r = 0; r < Q; r++) {
-            const int eo = Hp[r] - Go, ee = Ep[r] - Ge;
-            const int E = std::max(eo, ee);
+            const int hPrev = Hc[r];  // H[r][c-1]
+            const int eo = hPrev - Go, ee = Ec[r] - Ge;
+            const int E = eo > ee ? eo : ee;
             const int fo = uH - Go, fe = uF - Ge;
-            const int F = std::max(fo, fe);
-            const int diag = ulH + M[q[r] * A + t[c]];
-            H = std::max(E, std::max(F, diag));
-            uint8_t f = (H == E) ? H_FROM_E : (H == F) ? H_FROM_F : H_FROM_DIAG;
-            if (E == eo) f |= E_OPENS;
-            if (F == fo) f |= F_OPENS;
-            d[r] = f;
-            if (mode == OPAL_MODE_SW || (mode == OPAL_MODE_OV && c == T - 1)) maxScore = std::max(maxScore, H);
-            uF = F; uH = H; ulH = Hp[r];
+            const int F = fo > fe ? fo : fe;
+            const int diag = ulH + pc[r];
+            const int ef = E > F ? E : F;
+            H = ef > diag ? ef : diag;
+            // H prefers E, then F, then the diagonal (opal.cpp:1378-1386); E_OPENS / F_OPENS: the gap starts here
+            const unsigned f = (H == E ? H_FROM_E : (H == F ? H_FROM_F : H_FROM_DIAG)) | (E == eo ? E_OPENS : 0u) | (F == fo ? F_OPENS : 0u);
+            d[r] = (uint8_t)f;
+            colMax = H > colMax ? H : colMax;
+            uF = F; uH = H; ulH = hPrev;
             Hc[r] = H; Ec[r] = E;
         }
+        if (mode == OPAL_MODE_SW || (mode == OPAL_MODE_OV && c == T - 1)) maxScore = std::max(maxScore, colMax);
         if (mode == OPAL_MODE_HW || mode == OPAL_MODE_OV) maxScore = std::max(maxScore, H);  // last row
-        Hp.swap(Hc); Ep.swap(Ec);
     }
+    std::vector<int>& Hp = Hv;  // the last computed column
     const int lastCol = c - 1;
     // score and end cell (opal.cpp:1340-1362); Hp now holds the last computed column
     if (mode == OPAL_MODE_NW) {
@@ -129,12 +145,17 @@ static void find_alignment(const unsigned char* q, int Q, const unsigned char* t
 class ByteBudget {
 public:
     explicit ByteBudget(uint64_t total) : total_(total) {}
+    // Requests below 32 MiB (a 300 x 350 alignment is 0.1 MB) bypass the budget: a lock and a wake-up per alignment
+    // cost more than the alignment itself (20 000 alignments: 390 ms -> see profiles/r02_align_demo.txt).
+    static bool small(uint64_t n) { return n < (32ull << 20); }
     void acquire(uint64_t n) {
+        if (small(n)) return;
         std::unique_lock<std::mutex> lk(m_);
         cv_.wait(lk, [&] { return used_ == 0 || used_ + n <= total_; });
         used_ += n;
     }
     void release(uint64_t n) {
+        if (small(n)) return;
         { std::lock_guard<std::mutex> lk(m_); used_ -= n; }
         cv_.notify_all();
     }
@@ -154,8 +175,9 @@ static void emit(OpalSearchResult* res, const Aligned& a, int aq, int at) {
 
 // knownStartQ/T: start cell if already known (>= 0), else INT_MIN -> the full score-limited reverse pass finds it.
 static void align_one(const unsigned char* rQuery, int queryLength, const unsigned char* target, int Go, int Ge,
-                      const int* M, int A, OpalSearchResult* res, int mode, std::vector<unsigned char>& rTarget,
+                      const int* profR, OpalSearchResult* res, int mode, Workspace& ws,
                       int knownStartQ, int knownStartT, ByteBudget& budget) {
+    std::vector<unsigned char>& rTarget = ws.rTarget;
     if (mode == OPAL_MODE_SW && res->score == 0) {  // no alignment at all (opal.cpp:1479-1483)
         res->alignment = NULL; res->alignmentLength = 0;
         res->startLocationQuery = res->startLocationTarget = -1;
@@ -178,7 +200,7 @@ static void align_one(const unsigned char* rQuery, int queryLength, const unsign
         const uint64_t bytes = (uint64_t)bq * (uint64_t)bt;
         budget.acquire(bytes);
         struct Rel { ByteBudget& b; uint64_t n; ~Rel() { b.release(n); } } rel{budget, bytes};
-        find_alignment(alignQuery, bq, rTarget.data(), bt, Go, Ge, M, A, INT_MAX, OPAL_MODE_NW, a);
+        find_alignment(alignQuery, bq, rTarget.data(), bt, Go, Ge, profR + (queryLength - aq), queryLength, INT_MAX, OPAL_MODE_NW, a, ws);
         if (a.score == res->score) { emit(res, a, aq, at); return; }
         // the given start does not carry the score: fall through to the full pass (never seen; kept for safety)
         if (getenv("OPAL_HIP_DEBUG")) fprintf(stderr, "[opal] traceback: start (%d,%d) gives %d, expected %d; full pass\n", knownStartQ, knownStartT, a.score, res->score);
@@ -186,7 +208,7 @@ static void align_one(const unsigned char* rQuery, int queryLength, const unsign
     const uint64_t bytes = (uint64_t)aq * (uint64_t)at;  // upper bound (the pass stops at the start column)
     budget.acquire(bytes);
     struct Rel { ByteBudget& b; uint64_t n; ~Rel() { b.release(n); } } rel{budget, bytes};
-    find_alignment(alignQuery, aq, rTarget.data(), at, Go, Ge, M, A, res->score, mode, a);
+    find_alignment(alignQuery, aq, rTarget.data(), at, Go, Ge, profR + (queryLength - aq), queryLength, res->score, mode, a, ws);
     emit(res, a, aq, at);
 }
 
@@ -198,6 +220,10 @@ extern "C" int opalx_find_alignments_from(unsigned char query[], int queryLength
     (void)dbSeqLengths;
     std::vector<unsigned char> rQuery((size_t)std::max(queryLength, 1));
     for (int i = 0; i < queryLength; i++) rQuery[i] = query[queryLength - 1 - i];
+    // profile of the reversed query: profR[letter * queryLength + r] = M[rQuery[r]][letter]
+    std::vector<int> profR((size_t)std::max(queryLength, 1) * (size_t)std::max(alphabetLength, 1));
+    for (int l = 0; l < alphabetLength; l++)
+        for (int r = 0; r < queryLength; r++) profR[(size_t)l * queryLength + r] = scoreMatrix[(int)rQuery[r] * alphabetLength + l];
     uint64_t total = 8ull << 30;
     if (const char* e = getenv("OPAL_TRACEBACK_BYTES")) { const long long v = atoll(e); if (v > 0) total = (uint64_t)v; }
     ByteBudget budget(total);
@@ -205,11 +231,11 @@ extern "C" int opalx_find_alignments_from(unsigned char query[], int queryLength
     HostPool& pool = HostPool::get();
     const int tasks = std::max(1, std::min(dbLength, pool.width() * 4));
     pool.parallel_for(tasks, [&](int t) {
-        std::vector<unsigned char> rTarget;
+        Workspace ws;
         for (int i = t; i < dbLength; i += tasks) {
             if (failed.load(std::memory_order_relaxed)) return;
             try {
-                align_one(rQuery.data(), queryLength, db[i], gapOpen, gapExt, scoreMatrix, alphabetLength, results[i], mode, rTarget,
+                align_one(rQuery.data(), queryLength, db[i], gapOpen, gapExt, profR.data(), results[i], mode, ws,
                           startQuery ? startQuery[i] : INT_MIN, startTarget ? startTarget[i] : INT_MIN, budget);
             } catch (const std::bad_alloc&) {
                 failed.store(1);
