@@ -66,7 +66,6 @@ struct KParams {
     int* ovfCount;
     int* ovfItems;
     int prio;
-    int stagger;   // experiment: desynchronise the waves of a launch at their start (0: off)
     // FLAG_MULTI only: this launch covers query rows [q0, q0+chunkRows); chunkFlags bit0 = a chunk above
     // exists (read its bottom row from `bnd`), bit1 = a chunk below exists (write ours to `bnd`).
     int q0, chunkRows, chunkFlags;
@@ -391,10 +390,6 @@ __global__ void __launch_bounds__(opal_max_waves_per_block(WIDTH) * 64, (WIDTH =
 
     // waves of the long-sequence classes take issue priority over co-resident waves of other launches
     if (p.prio > 0) __builtin_amdgcn_s_setprio(2);
-    if (p.stagger > 0) {  // waves of a launch start in lock-step: spread their phases over about one column step
-        const int n = ((int)blockIdx.x * 5 + (int)(threadIdx.x >> 6) * 3) & 7;
-        for (int i = 0; i < n * p.stagger; i++) __builtin_amdgcn_s_sleep(1);  // 64 clocks each
-    }
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;

@@ -21,6 +21,18 @@ public:
         static HostPool* pool = new HostPool(default_threads());
         return *pool;
     }
+    // Compute-bound host work (the alignment traceback) scales past the 64 threads that saturate memory copies:
+    // a second pool over every hardware thread, created only if such work is ever asked for.
+    static HostPool& get_wide() {
+        static HostPool* pool = [] {
+            unsigned nt = std::thread::hardware_concurrency();
+            if (nt == 0) nt = 1;
+            if (nt > 256) nt = 256;
+            if (const char* e = getenv("OPAL_HOST_THREADS")) { const int v = atoi(e); if (v >= 1) nt = (unsigned)v; }
+            return (int)nt <= default_threads() ? &get() : new HostPool((int)nt);
+        }();
+        return *pool;
+    }
     // number of threads a job can run on (workers + the submitting thread)
     int width() const { return (int)workers_.size() + 1; }
 

@@ -631,14 +631,9 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
     }
     int err = 0;
     bool recorded[3] = {false, false, false};
-    // submission order: experiment hook OPAL_HIP_MAIN_FIRST=1 submits the bulk launch before the side launches
-    std::vector<size_t> order;
-    const char* mf = getenv("OPAL_HIP_MAIN_FIRST");
-    if (mf && *mf == '1') order.push_back(classes.size() - 1);
-    for (size_t ki = 0; ki < classes.size(); ki++)
-        if (!(mf && *mf == '1' && ki == classes.size() - 1)) order.push_back(ki);
-    for (size_t oi = 0; oi < order.size() && !err; oi++) {
-        const size_t ki = order[oi];
+    // Submission order matters: the side launches (long sequences) go first. Submitting the bulk launch first was
+    // measured at 2.2 ms instead of 1.55 ms on C2: its workgroups fill every CU and the long sequences start late.
+    for (size_t ki = 0; ki < classes.size() && !err; ki++) {
         LaunchClass k = classes[ki];
         const int skew = maySkew && skew_ok(k.first);
         {   // the plan assumed the skewed kernels (every rows-per-lane value exists); a class that cannot use them

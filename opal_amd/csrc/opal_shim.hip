@@ -254,8 +254,6 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
     p.outScore = a->out_score; p.outEndQ = a->out_end_query; p.outEndT = a->out_end_target;
     p.ovfCount = a->overflow_count; p.ovfItems = a->overflow_items;
     p.prio = a->priority;
-    p.stagger = 0;
-    if (const char* e = getenv("OPAL_HIP_STAGGER")) p.stagger = atoi(e);
     p.q0 = a->chunk_flags ? a->chunk_row0 : 0;
     p.chunkRows = a->chunk_flags ? a->chunk_rows : a->query_length;
     p.chunkFlags = a->chunk_flags;

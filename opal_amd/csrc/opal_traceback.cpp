@@ -228,10 +228,14 @@ extern "C" int opalx_find_alignments_from(unsigned char query[], int queryLength
     if (const char* e = getenv("OPAL_TRACEBACK_BYTES")) { const long long v = atoll(e); if (v > 0) total = (uint64_t)v; }
     ByteBudget budget(total);
     std::atomic<int> failed{0};
-    HostPool& pool = HostPool::get();
+    // (the wide pool did not help: 20 000 alignments took 480 ms on 256 threads against 380 ms on 64; OPAL_HOST_WIDE=1 selects it)
+    const char* wide = getenv("OPAL_HOST_WIDE");
+    HostPool& pool = (wide && *wide == '1' && dbLength >= 512) ? HostPool::get_wide() : HostPool::get();
     const int tasks = std::max(1, std::min(dbLength, pool.width() * 4));
     pool.parallel_for(tasks, [&](int t) {
-        Workspace ws;
+        // one workspace per host thread for the life of the process: its buffers grow once (fresh pages and mmap calls
+        // from many threads at a time serialise on the process's memory map)
+        static thread_local Workspace ws;
         for (int i = t; i < dbLength; i += tasks) {
             if (failed.load(std::memory_order_relaxed)) return;
             try {
