@@ -243,13 +243,23 @@ def main():
 
     want_end = args.search_type != 0
     nres = 3 if want_end else 1
-    out = torch.zeros(nres * npad, dtype=torch.int32, device=dev)  # {score, endQ, endT} blocks, padded to the largest shard
-    score, endq, endt = out[:npad], (out[npad:2 * npad] if want_end else None), (out[2 * npad:] if want_end else None)
+    # {score, endQ, endT} blocks, padded to the largest shard. Two result buffers used in turn: the search runs on the
+    # library's own stream, the gather / permutation on torch's, so step i+1 must not overwrite what step i's gather is
+    # still reading; a buffer is reused two steps later, after waiting on the event recorded behind its last reader.
+    outs = [torch.zeros(nres * npad, dtype=torch.int32, device=dev) for _ in range(2)]
+    done = [None, None]
     owned_dev = [torch.as_tensor(o, device=dev) for o in owned_lists] if rank == 0 else None
     glob = torch.zeros(nres * total, dtype=torch.int32, device=dev) if rank == 0 else None
     kernel_ms = []
+    step_no = [0]
 
     def step():
+        b = step_no[0] & 1
+        step_no[0] += 1
+        out = outs[b]
+        if done[b] is not None:
+            done[b].synchronize()
+        score, endq, endt = out[:npad], (out[npad:2 * npad] if want_end else None), (out[2 * npad:] if want_end else None)
         rc, kms = pdb.search_device(query, args.gap_open, args.gap_ext, matrix, args.search_type, mode, score.data_ptr(),
                                     endq.data_ptr() if want_end else 0, endt.data_ptr() if want_end else 0)
         if rc != 0:
@@ -267,6 +277,8 @@ def main():
         elif rank == 0:
             for k in range(nres):
                 glob[k * total:(k + 1) * total][owned_dev[0]] = out[k * npad:k * npad + n]
+        done[b] = torch.cuda.Event()
+        done[b].record()
 
     def fence():
         if world > 1:
@@ -368,7 +380,7 @@ def main():
             other = 3 if args.gap_open == 11 else 11
             ks = []
             for _ in range(10):
-                rc, k = pdb.search_device(query, other, args.gap_ext, matrix, 0, mode, score.data_ptr())
+                rc, k = pdb.search_device(query, other, args.gap_ext, matrix, 0, mode, outs[0].data_ptr())
                 ks.append(k)
             res_line["also"] = {f"kernel_gcups_gaps_{other}_{args.gap_ext}": round(cells / (float(np.median(ks)) * 1e-3) / 1e9, 1)}
         if not args.no_cpu_baseline and world == 1:

@@ -177,6 +177,9 @@ struct OpalxDb {
     bool seqItemValid = false;
     DevBuf<int> revFlags;
     DevBuf<int> redo;
+    // launch plans of this database, keyed by what they depend on (cleared when the database is refilled): a search
+    // with the same query length, alphabet and mode re-uses the class split instead of recomputing it with the GPU idle
+    std::map<std::string, std::vector<int>> planCache;
     // staging used while (re)filling the database
     DevBuf<unsigned char> raw;
     DevBuf<uint64_t> rawOff;
@@ -262,6 +265,7 @@ static bool db_fill(OpalxDb* db, HostPack& hp, RawKind kind, const std::function
     db->emptySeqs.swap(hp.emptySeqs);
     db->numTokens = hp.numTokens + 8;
     db->seqItemValid = false;
+    db->planCache.clear();
     const double slack = db->cached ? 1.15 : 1.0;
     void* st = db->main();
     bool ok = st && db->tokens.ensure(db->numTokens, slack) && db->pairOff.ensure(P, slack) && db->dPairLen.ensure(2 * P, slack) &&
@@ -616,8 +620,28 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
         return std::min<long long>(c.Q, L0) * c.maxScore + (OPAL_HIP_MAX_ROWS + L0 + 64 + 4) * (long long)c.Ge < 32000;
     };
     const bool maySkew = width == 17 && c.mode != OPAL_MODE_SW && !work && !getenv("OPAL_HIP_NO_SKEW");
-    std::vector<LaunchClass> classes = plan_classes(width, c.mode, swEndPass, maySkew && skew_ok(firstItem + numItems - 1), c.Q, c.A,
-                                                    lenOf, firstItem, numItems);
+    std::vector<LaunchClass> classes;
+    std::string key;
+    if (!work) {  // (re-run lists differ from search to search: planned every time)
+        char buf[160];
+        const char* e1 = getenv("OPAL_HIP_LANES_PER_SEQ"); const char* e2 = getenv("OPAL_HIP_TAIL_FRACTION"); const char* e3 = getenv("OPAL_HIP_TAIL_MODEL");
+        snprintf(buf, sizeof buf, "%d/%d/%d/%d/%d/%d/%d/%lld/%d/%d|%s|%s|%s", width, c.mode, swEndPass, c.Q, c.A, c.Go, c.Ge, c.maxScore, firstItem, numItems,
+                 e1 ? e1 : "", e2 ? e2 : "", e3 ? e3 : "");
+        key = buf;
+        auto it = db->planCache.find(key);
+        if (it != db->planCache.end()) {
+            const std::vector<int>& v = it->second;
+            for (size_t i = 0; i + 6 <= v.size(); i += 6) classes.push_back({v[i], v[i + 1], v[i + 2], v[i + 3], v[i + 4], v[i + 5]});
+        }
+    }
+    if (classes.empty()) {
+        classes = plan_classes(width, c.mode, swEndPass, maySkew && skew_ok(firstItem + numItems - 1), c.Q, c.A, lenOf, firstItem, numItems);
+        if (!work && !classes.empty() && !getenv("OPAL_HIP_DEBUG")) {
+            std::vector<int>& v = db->planCache[key];
+            v.clear();
+            for (const LaunchClass& k : classes) v.insert(v.end(), {k.first, k.count, k.G, k.rows, k.wpb, k.ldsPad});
+        }
+    }
     if (classes.empty() || getenv("OPAL_HIP_FORCE_CHUNKS"))
         return launch_chunked(c, width, swEndPass, detectWrap, work, firstItem, numItems, ovfCounter);
     // The last class (the bulk of the database) runs on the main stream; the classes of long
