@@ -112,6 +112,7 @@ int opal_hip_memset32(void* dst, int value, size_t count, void* stream);   /* `c
 int opal_hip_scatter_results(const int* quads, int count, int* score, int* end_query, int* end_target, void* stream);
 int opal_hip_stream_sync(void* stream);
 void* opal_hip_stream_create(void);       /* non-blocking stream: ordered only through events */
+void* opal_hip_stream_create_high(void);  /* the same at the device's highest stream priority */
 void opal_hip_stream_destroy(void* stream);
 int opal_hip_stream_wait_event(void* stream, void* event);
 /* Interleave raw residues into the packed token streams on the device: for every pair p and column c,

@@ -187,7 +187,7 @@ struct OpalxDb {
     PinBuf<int> hResults;
     // Streams: everything of one search runs on `main` (a non-blocking stream: no implicit ordering
     // against the legacy null stream or against other contexts); long-sequence classes run on up to three
-    // side streams, forked from and joined back into `main` with events.
+    // HIGH-priority side streams (hardware queues of their own), forked from and joined back into `main` with events.
     void* mainStream = nullptr;
     void* streams[3] = {nullptr, nullptr, nullptr};
     void* events[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // 0 fork, 1-3 joins, 4-5 timing
@@ -196,7 +196,7 @@ struct OpalxDb {
         return mainStream;
     }
     void* stream(int i) {
-        if (!streams[i]) streams[i] = opal_hip_stream_create();
+        if (!streams[i]) { const char* e = getenv("OPAL_HIP_SIDE_STREAM_PRIO"); streams[i] = (e && *e == '0') ? opal_hip_stream_create() : opal_hip_stream_create_high(); }
         return streams[i];
     }
     void* event(int i) {
@@ -532,10 +532,14 @@ static std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass,
         i += 64 / cands[ci].G;
     }
     out.push_back(cls(start, first + count - start, ci));
-    // At most TWO side streams: HIP multiplexes streams onto 4 hardware queues and the caller's own streams (torch's,
-    // the null stream) take part of them; with three side streams plus the main one, two launches of a search ended up
-    // on one queue and ran one after the other (round 2 kernel trace).
-    while (out.size() > 3) {  // fold the two longest classes together
+    // Two side streams by default (three classes). HIP multiplexes normal-priority streams onto 4 hardware queues
+    // shared with the caller's own streams: with normal-priority side streams two launches of one search could land on
+    // the same queue and run one after the other (2.3 ms instead of 1.6 ms on C2, depending on how many streams the
+    // process had created: scripts/gpu_queue_test.py). The side streams are therefore HIGH-priority streams, which
+    // get queues of their own; with them three side streams work too but measure 1-3 % slower than two.
+    const char* nsEnv = getenv("OPAL_HIP_SIDE_STREAMS");  // tuning hook: 3 side streams
+    const size_t maxClasses = (nsEnv && atoi(nsEnv) == 3) ? 4 : 3;
+    while (out.size() > maxClasses) {  // fold the two longest classes together
         out[1].count += out[0].count;
         out[1].first = out[0].first;
         out[1].G = out[0].G; out[1].rows = out[0].rows; out[1].wpb = out[0].wpb; out[1].ldsPad = out[0].ldsPad;
@@ -636,7 +640,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
     }
     if (classes.empty()) {
         classes = plan_classes(width, c.mode, swEndPass, maySkew && skew_ok(firstItem + numItems - 1), c.Q, c.A, lenOf, firstItem, numItems);
-        if (!work && !classes.empty() && !getenv("OPAL_HIP_DEBUG")) {
+        if (!work && !classes.empty()) {
             std::vector<int>& v = db->planCache[key];
             v.clear();
             for (const LaunchClass& k : classes) v.insert(v.end(), {k.first, k.count, k.G, k.rows, k.wpb, k.ldsPad});
@@ -647,7 +651,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
     // The last class (the bulk of the database) runs on the main stream; the classes of long
     // sequences run beside it on up to three side streams (one hardware queue each), forked from and
     // joined back into the main stream with events, longest sequences enqueued first.
-    const int nside = std::min<int>((int)classes.size() - 1, 2);
+    const int nside = std::min<int>((int)classes.size() - 1, 3);
     void* fork = nullptr;
     if (nside > 0) {
         fork = db->event(0);

@@ -96,6 +96,15 @@ extern "C" void* opal_hip_stream_create(void) {
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
     return (void*)st;
 }
+// A stream of the highest priority the device offers (side launches of long sequences: dispatched ahead of the bulk
+// launch, and on hardware queues of their own priority class).
+extern "C" void* opal_hip_stream_create_high(void) {
+    int least = 0, greatest = 0;
+    hipStream_t st;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return opal_hip_stream_create();
+    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest) != hipSuccess) return opal_hip_stream_create();
+    return (void*)st;
+}
 extern "C" int opal_hip_stream_wait_event(void* stream, void* event) {
     hipError_t e = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0);
     return e == hipSuccess ? 0 : fail("hipStreamWaitEvent", e);
