@@ -91,6 +91,20 @@ typedef struct OpalHipLaunch {
     int lds_bytes_min;
 } OpalHipLaunch;
 
+/* ONE launch for up to three length classes of a search (plain 16-bit kernels): the bulk of the database on
+   base.lanes_per_seq (G0) lanes x base.rows_per_lane (S0) rows [items base.first_item .. +base.num_items), long
+   sequences on 2*G0 lanes x ceil(S0/2) rows, the longest on 4*G0 x ceil(S0/4). The workgroups of the longest class
+   come first in the grid. No side streams, events or extra hardware queues are involved. */
+typedef struct OpalHipUberLaunch {
+    OpalHipLaunch base;
+    int long_first_item, long_num_items;
+    int longest_first_item, longest_num_items;
+    int long_priority, longest_priority;   /* s_setprio of those classes' waves (0: none) */
+} OpalHipUberLaunch;
+/* 1 if a one-launch kernel exists for this variant (width 17, single launch) and bulk rows-per-lane value */
+int opal_hip_uber_supported(int mode, int want_end, int skew, int rows_per_lane);
+int opal_hip_launch_uber(const OpalHipUberLaunch* args);
+
 #define OPAL_HIP_MAX_ROWS 40
 
 int opal_hip_device_count(void);

@@ -74,6 +74,11 @@ struct KParams {
     int satLimit, negPad;  // width 17 only
 };
 
+// What differs between the length classes of one search (the rest of KParams is shared).
+struct KClass {
+    int log2G, firstItem, numItems, prio;
+};
+
 typedef void (*KernelFn)(const KParams);
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -310,7 +315,7 @@ __host__ __device__ inline int opal_profile_stride(int es, int G, int S, int pad
 // (the second launch bound asks the register allocator for 4 waves per SIMD, i.e. at most 128 VGPRs, on the single-launch
 // plain-16-bit kernels: OV at 38-39 rows per lane compiled to 129-131 registers without it, one wave per SIMD less)
 template <int WIDTH, int MODE, int FLAGS, int S>
-__global__ void __launch_bounds__(opal_max_waves_per_block(WIDTH) * 64, (WIDTH == 17 && !(FLAGS & FLAG_MULTI)) ? 4 : 1) opal_dp_kernel(const KParams p) {
+__device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls, const int blockId) {
     using V = Vec<WIDTH>;
     using reg = typename V::reg;
     using elem = typename V::elem;
@@ -326,7 +331,7 @@ __global__ void __launch_bounds__(opal_max_waves_per_block(WIDTH) * 64, (WIDTH =
     constexpr bool SKEW = (FLAGS & FLAG_SKEW) != 0 && WIDTH == 17 && MODE != MODE_SW && !MULTI;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
-    const int log2G = p.log2G;
+    const int log2G = cls.log2G;
     const int G = 1 << log2G;
     const int stride = opal_profile_stride(ES, G, S, WIDTH == 18);
     const int Q = p.Q, A = p.A;
@@ -389,16 +394,16 @@ __global__ void __launch_bounds__(opal_max_waves_per_block(WIDTH) * 64, (WIDTH =
     __syncthreads();
 
     // waves of the long-sequence classes take issue priority over co-resident waves of other launches
-    if (p.prio > 0) __builtin_amdgcn_s_setprio(2);
+    if (cls.prio > 0) __builtin_amdgcn_s_setprio(2);
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int slots = 64 >> log2G;
-    const int job = (int)blockIdx.x * (int)(blockDim.x >> 6) + wave;
+    const int job = blockId * (int)(blockDim.x >> 6) + wave;
     const int k = lane & (G - 1);
     const int slot = lane >> log2G;
     const int itemIdx = job * slots + slot;
-    const bool valid = itemIdx < p.numItems;
+    const bool valid = itemIdx < cls.numItems;
     // (idle slots and whole idle waves run the loop below with no columns of their own)
 
     int len[NH], seq[NH];
@@ -407,7 +412,7 @@ __global__ void __launch_bounds__(opal_max_waves_per_block(WIDTH) * 64, (WIDTH =
 #pragma unroll
     for (int h = 0; h < NH; h++) { len[h] = 0; seq[h] = -1; }
     if (valid) {
-        const int w = p.firstItem + itemIdx;
+        const int w = cls.firstItem + itemIdx;
         const int item = p.work ? p.work[w] : w;
         pairIdx = (NH == 2) ? item : (item >> 1);
         half0 = (NH == 2) ? 0 : (item & 1);
@@ -827,12 +832,41 @@ __global__ void __launch_bounds__(opal_max_waves_per_block(WIDTH) * 64, (WIDTH =
     }
 }
 
+template <int WIDTH, int MODE, int FLAGS, int S>
+__global__ void __launch_bounds__(opal_max_waves_per_block(WIDTH) * 64, (WIDTH == 17 && !(FLAGS & FLAG_MULTI)) ? 4 : 1) opal_dp_kernel(const KParams p) {
+    opal_dp_body<WIDTH, MODE, FLAGS, S>(p, KClass{p.log2G, p.firstItem, p.numItems, p.prio}, (int)blockIdx.x);
+}
+
+// ------------------------------------------------------------------ one launch for all length classes of a search
+// The host splits a database into up to three length classes: the bulk on G0 lanes x S0 rows, long sequences on 2*G0 x
+// ceil(S0/2) and the longest on 4*G0 x ceil(S0/4) (a 5000-residue sequence must not pin one wave for the whole launch).
+// As separate launches they need a stream each, fork/join events (~35 us of host calls before the bulk launch is even
+// submitted) and hardware queues that nothing else is using. Here they are ONE grid: the workgroups of the longest
+// class come first in the grid (dispatch order = longest first), every workgroup runs the body of its class, and the
+// register budget is the bulk body's. Plain-16-bit kernels, single-launch variants only.
+struct UberParams {
+    KParams base;
+    KClass cls[3];      // [0] longest sequences (4*G0 lanes), [1] long (2*G0), [2] the bulk (G0); empty classes have numItems 0
+    int firstBlock[3];  // first workgroup of each class in the grid
+};
+typedef void (*UberFn)(const UberParams);
+
+template <int MODE, int FLAGS, int S0>
+__global__ void __launch_bounds__(WAVES_PER_BLOCK * 64, 4) opal_dp_uber(const UberParams u) {
+    const int b = (int)blockIdx.x;
+    if (b >= u.firstBlock[2]) opal_dp_body<17, MODE, FLAGS, S0>(u.base, u.cls[2], b - u.firstBlock[2]);
+    else if (b >= u.firstBlock[1]) opal_dp_body<17, MODE, FLAGS, (S0 + 1) / 2>(u.base, u.cls[1], b - u.firstBlock[1]);
+    else opal_dp_body<17, MODE, FLAGS, (S0 + 3) / 4>(u.base, u.cls[0], b - u.firstBlock[0]);
+}
+
 // Kernel tables, one per translation unit (inst_*.hip); nullptr = shape not instantiated.
 KernelFn opal_kernel_sw16(int rows);                      // width 16, SW, score only: rows 1..40
 KernelFn opal_kernel_w16(int mode, int flags, int rows);  // width 16, the other variants: rows 4,8,..,40
 KernelFn opal_kernel_w32(int mode, int flags, int rows);  // width 32: rows 8,16,24,32,40
 KernelFn opal_kernel_s16sw(int rows);                     // width 17, SW, score only: rows 1..40
 KernelFn opal_kernel_s16swend(int rows);                  // width 17, SW, score + end location: rows 1..40
+UberFn opal_uber_sw(int flags, int rows);                // one-launch kernels: SW score / SW end, bulk rows 1..40
+UberFn opal_uber_skew(int mode, int rows);               // NW/HW/OV, FLAG_SKEW
 KernelFn opal_kernel_s18(int mode, int flags, int rows);   // width 18 (2-byte profile entries): rows 8,16,..,40
 KernelFn opal_kernel_s16skew(int mode, int rows);           // width 17, NW/HW/OV, FLAG_SKEW: rows 1..40
 KernelFn opal_kernel_s16(int mode, int flags, int rows);  // width 17, other variants incl. FLAG_MULTI: rows 4,8,..,40

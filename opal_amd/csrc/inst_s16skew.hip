@@ -18,3 +18,16 @@ KernelFn opal_kernel_s16skew(int mode, int rows) {
     }
     return nullptr;
 }
+
+// one-launch variants live in inst_uber_{nw,hw,ov}.hip
+UberFn opal_uber_skew_nw(int rows);
+UberFn opal_uber_skew_hw(int rows);
+UberFn opal_uber_skew_ov(int rows);
+UberFn opal_uber_skew(int mode, int rows) {
+    switch (mode) {
+    case MODE_NW: return opal_uber_skew_nw(rows);
+    case MODE_HW: return opal_uber_skew_hw(rows);
+    case MODE_OV: return opal_uber_skew_ov(rows);
+    }
+    return nullptr;
+}

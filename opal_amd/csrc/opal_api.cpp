@@ -457,7 +457,7 @@ static int pick_occupancy(int vgprs, size_t ldsBytes, int* wpbOut, int* ldsPadOu
  */
 template <typename LenOf>
 static std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass, int skew, int Q, int A, LenOf lenOf, int first,
-                                             int count) {
+                                             int count, int maxGFactor = 0) {
     std::vector<LaunchClass> out;
     if (count <= 0) return out;
     struct Cand { int G, rows, wpb, ldsPad; double eff; };
@@ -497,6 +497,9 @@ static std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass,
     size_t base = 0;
     for (size_t i = 1; i < cands.size(); i++)
         if (cands[i].eff > cands[base].eff * 1.02) base = i;
+    // one-launch kernels hold the bodies for G0, 2*G0 and 4*G0 lanes per sequence: keep the classes inside that chain
+    if (maxGFactor > 0)
+        while (cands.size() > base + 1 && cands.back().G > maxGFactor * cands[base].G) cands.pop_back();
     // time of the whole range at the base geometry if the machine were perfectly filled
     const double simds = 1024.0;
     const int slotsBase = 64 / cands[base].G;
@@ -624,13 +627,15 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
         return std::min<long long>(c.Q, L0) * c.maxScore + (OPAL_HIP_MAX_ROWS + L0 + 64 + 4) * (long long)c.Ge < 32000;
     };
     const bool maySkew = width == 17 && c.mode != OPAL_MODE_SW && !work && !getenv("OPAL_HIP_NO_SKEW");
+    // One launch for all classes where a one-launch kernel exists (plain 16-bit, no re-run list): see dp_kernel.hpp.
+    const bool uberEligible = width == 17 && !work && !getenv("OPAL_HIP_NO_UBER") && !getenv("OPAL_HIP_LANES_PER_SEQ");
     std::vector<LaunchClass> classes;
     std::string key;
     if (!work) {  // (re-run lists differ from search to search: planned every time)
         char buf[160];
         const char* e1 = getenv("OPAL_HIP_LANES_PER_SEQ"); const char* e2 = getenv("OPAL_HIP_TAIL_FRACTION"); const char* e3 = getenv("OPAL_HIP_TAIL_MODEL");
-        snprintf(buf, sizeof buf, "%d/%d/%d/%d/%d/%d/%d/%lld/%d/%d|%s|%s|%s", width, c.mode, swEndPass, c.Q, c.A, c.Go, c.Ge, c.maxScore, firstItem, numItems,
-                 e1 ? e1 : "", e2 ? e2 : "", e3 ? e3 : "");
+        snprintf(buf, sizeof buf, "%d/%d/%d/%d/%d/%d/%d/%lld/%d/%d/%d|%s|%s|%s", width, c.mode, swEndPass, c.Q, c.A, c.Go, c.Ge, c.maxScore, firstItem, numItems,
+                 (int)uberEligible, e1 ? e1 : "", e2 ? e2 : "", e3 ? e3 : "");
         key = buf;
         auto it = db->planCache.find(key);
         if (it != db->planCache.end()) {
@@ -639,7 +644,8 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
         }
     }
     if (classes.empty()) {
-        classes = plan_classes(width, c.mode, swEndPass, maySkew && skew_ok(firstItem + numItems - 1), c.Q, c.A, lenOf, firstItem, numItems);
+        classes = plan_classes(width, c.mode, swEndPass, maySkew && skew_ok(firstItem + numItems - 1), c.Q, c.A, lenOf, firstItem, numItems,
+                               uberEligible ? 4 : 0);
         if (!work && !classes.empty()) {
             std::vector<int>& v = db->planCache[key];
             v.clear();
@@ -648,6 +654,31 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
     }
     if (classes.empty() || getenv("OPAL_HIP_FORCE_CHUNKS"))
         return launch_chunked(c, width, swEndPass, detectWrap, work, firstItem, numItems, ovfCounter);
+    if (uberEligible && classes.size() >= 2 && classes.size() <= 3) {
+        const LaunchClass& bulk = classes.back();
+        const int skewBulk = maySkew && skew_ok(bulk.first);
+        bool ok = bulk.wpb == 4 && bulk.ldsPad == 0 && opal_hip_uber_supported(c.mode, swEndPass, skewBulk, bulk.rows);
+        OpalHipUberLaunch u;
+        memset(&u, 0, sizeof u);
+        for (size_t ki = 0; ok && ki + 1 < classes.size(); ki++) {
+            const LaunchClass& k = classes[ki];
+            if ((maySkew && skew_ok(k.first)) != skewBulk) ok = false;  // a class that cannot use the skewed kernels: separate launches
+            else if (k.G == 2 * bulk.G) { u.long_first_item = k.first; u.long_num_items = k.count; u.long_priority = 1; }
+            else if (k.G == 4 * bulk.G) { u.longest_first_item = k.first; u.longest_num_items = k.count; u.longest_priority = 1; }
+            else ok = false;
+        }
+        if (ok) {
+            fill_launch(u.base, c, width, swEndPass, detectWrap, nullptr, ovfCounter);
+            u.base.lanes_per_seq = bulk.G; u.base.rows_per_lane = bulk.rows; u.base.waves_per_block = 4;
+            u.base.first_item = bulk.first; u.base.num_items = bulk.count; u.base.skew = skewBulk;
+            if (debug_on())
+                fprintf(stderr, "[opal] one launch width=%d mode=%d end=%d G0=%d rows=%d%s: bulk [%d,+%d) long [%d,+%d) longest [%d,+%d)\n", width,
+                        c.mode, swEndPass, bulk.G, bulk.rows, skewBulk ? " skew" : "", bulk.first, bulk.count, u.long_first_item,
+                        u.long_num_items, u.longest_first_item, u.longest_num_items);
+            if (opal_hip_launch_uber(&u)) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
+            return 0;
+        }
+    }
     // The last class (the bulk of the database) runs on the main stream; the classes of long
     // sequences run beside it on up to three side streams (one hardware queue each), forked from and
     // joined back into the main stream with events, longest sequences enqueued first.

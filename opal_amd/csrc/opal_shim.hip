@@ -236,6 +236,78 @@ extern "C" int opal_hip_kernel_vgprs(const OpalHipLaunch* a) {
 
 extern "C" int opal_hip_max_waves_per_block(int width) { return opal_max_waves_per_block(width); }
 
+static UberFn pick_uber(int mode, int flags, int rows) {
+    if (flags & FLAG_MULTI) return nullptr;
+    if (mode == MODE_SW) return opal_uber_sw(flags, rows);
+    if (flags == FLAG_SKEW) return opal_uber_skew(mode, rows);
+    return nullptr;
+}
+
+extern "C" int opal_hip_uber_supported(int mode, int want_end, int skew, int rows_per_lane) {
+    OpalHipLaunch a;
+    memset(&a, 0, sizeof a);
+    a.width = 17; a.mode = mode; a.want_end = want_end & 1; a.skew = skew;
+    return pick_uber(mode, launch_flags(&a), rows_per_lane) != nullptr;
+}
+
+extern "C" int opal_hip_launch_uber(const OpalHipUberLaunch* u) {
+    const OpalHipLaunch* a = &u->base;
+    const int G0 = a->lanes_per_seq, S0 = a->rows_per_lane;
+    int log2G0 = 0;
+    while ((1 << log2G0) < G0) log2G0++;
+    UberFn fn = nullptr;
+    if (a->width == 17 && !a->chunk_flags && !a->work && (1 << log2G0) == G0 && S0 >= 1 && S0 <= OPAL_HIP_MAX_ROWS &&
+        (long long)G0 * S0 >= a->query_length && a->query_length >= 1 && a->mode >= 0 && a->mode <= 3)
+        fn = pick_uber(a->mode, launch_flags(a), S0);
+    const int items[3] = {u->longest_num_items, u->long_num_items, a->num_items};
+    const int firsts[3] = {u->longest_first_item, u->long_first_item, a->first_item};
+    const int prios[3] = {u->longest_priority, u->long_priority, a->priority};
+    const int lanes[3] = {4 * G0, 2 * G0, G0};
+    const int rows[3] = {(S0 + 3) / 4, (S0 + 1) / 2, S0};
+    for (int k = 0; k < 3; k++)
+        if (items[k] > 0 && lanes[k] > 64) fn = nullptr;
+    if (!fn) {
+        snprintf(g_err, sizeof g_err, "unlaunchable one-launch shape: mode=%d G0=%d rows=%d Q=%d", a->mode, G0, S0, a->query_length);
+        fprintf(stderr, "[opal-hip] %s\n", g_err);
+        return 2;
+    }
+    UberParams p;
+    memset(&p, 0, sizeof p);
+    KParams& b = p.base;
+    b.query = a->query; b.matrix = a->score_matrix; b.Q = a->query_length; b.A = a->alphabet_length;
+    b.Go = a->gap_open; b.Ge = a->gap_ext;
+    b.tokens = a->tokens; b.pairOff = a->pair_token_offset; b.pairLen = a->pair_len; b.pairSeq = a->pair_seq;
+    b.work = nullptr;
+    b.outScore = a->out_score; b.outEndQ = a->out_end_query; b.outEndT = a->out_end_target;
+    b.ovfCount = a->overflow_count; b.ovfItems = a->overflow_items;
+    b.chunkRows = a->query_length;
+    b.satLimit = a->sat_limit; b.negPad = a->neg_pad;
+    size_t lds = 0;
+    int blocks = 0;
+    for (int k = 0; k < 3; k++) {
+        p.firstBlock[k] = blocks;
+        int lg = 0;
+        while ((1 << lg) < lanes[k]) lg++;
+        p.cls[k] = KClass{lg, firsts[k], items[k] > 0 ? items[k] : 0, prios[k]};
+        if (items[k] <= 0) continue;
+        const int slots = 64 / lanes[k];
+        const int jobs = (items[k] + slots - 1) / slots;
+        blocks += (jobs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+        const size_t need = lds_bytes(17, lanes[k], rows[k], a->alphabet_length);
+        if (need > lds) lds = need;
+    }
+    if (blocks == 0) return 0;
+    if (a->lds_bytes_min > 0 && (size_t)a->lds_bytes_min > lds && a->lds_bytes_min <= 160 * 1024) lds = (size_t)a->lds_bytes_min;
+    if (lds > 160 * 1024) { snprintf(g_err, sizeof g_err, "query profile needs %zu bytes of LDS (>160 KiB)", lds); return 2; }
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail("hipFuncSetAttribute", e);
+    }
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(WAVES_PER_BLOCK * 64), lds, (hipStream_t)a->stream, p);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("one-launch kernel launch", e);
+}
+
 extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
     const int G = a->lanes_per_seq;
     int log2G = 0;

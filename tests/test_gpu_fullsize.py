@@ -259,3 +259,31 @@ def test_api_context_reuse_and_multi_device(oracle):
                 np.testing.assert_array_equal(a, b)
     finally:
         del os.environ["OPAL_HIP_DEVICES"]
+
+
+@pytest.mark.parametrize("mode", ["SW", "NW", "HW", "OV"])
+def test_one_launch_kernels_equal_separate_launches(mode, c2, oracle, monkeypatch):
+    """The one-launch ("uber") kernels -- all length classes of a search as ONE grid -- against the same search as
+    separate launches on forked streams (OPAL_HIP_NO_UBER=1): identical scores and end cells on 30 000 sequences of the
+    C2 database (three classes: the 5000-residue tail, the long ones, the bulk), score only and with end locations."""
+    from opal_amd.api import PreparedDb
+    n = 30000
+    pdb = PreparedDb(c2["res"][: c2["offs"][n]], c2["offs"][: n + 1])
+    q, m = c2["q"], c2["m"]
+    for st in (0, 1):
+        for go in (11, 3):
+            monkeypatch.delenv("OPAL_HIP_NO_UBER", raising=False)
+            a = pdb.search(q, go, 1, m, st, oracle_lib.MODES[mode])
+            monkeypatch.setenv("OPAL_HIP_NO_UBER", "1")
+            b = pdb.search(q, go, 1, m, st, oracle_lib.MODES[mode])
+            assert a[0] == b[0] == 0
+            for x, y in zip(a[1:], b[1:]):
+                np.testing.assert_array_equal(x, y)
+    monkeypatch.delenv("OPAL_HIP_NO_UBER", raising=False)
+    pick = _sample(c2["lens"][:n], 120, seed=9, n_edge=25)
+    db = [c2["res"][c2["offs"][i]:c2["offs"][i + 1]] for i in pick]
+    rc, s, eq, et = pdb.search(q, 3, 1, m, 1, oracle_lib.MODES[mode])
+    orc, so, oq, ot = oracle.search(q, db, 3, 1, m, 1, oracle_lib.MODES[mode])
+    np.testing.assert_array_equal(s[pick], so)
+    np.testing.assert_array_equal(eq[pick], oq)
+    np.testing.assert_array_equal(et[pick], ot)
