@@ -505,7 +505,7 @@ static std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass,
     const int slotsBase = 64 / cands[base].G;
     const double totalClocks = lenSum * sample / slotsBase * step_clocks(width, cands[base].rows) / simds;
     const char* budEnv = getenv("OPAL_HIP_TAIL_FRACTION");
-    const double budget = std::max(totalClocks * (budEnv && *budEnv ? atof(budEnv) : 0.5), 20000.0);
+    const double budget = std::max(totalClocks * (budEnv && *budEnv ? atof(budEnv) : 0.7), 20000.0);
     // walk from the longest item: the smallest geometry (>= base) whose lone-wave time fits the budget
     size_t ci = cands.size() - 1;
     int start = first;
