@@ -105,6 +105,14 @@ typedef struct OpalHipUberLaunch {
 int opal_hip_uber_supported(int mode, int want_end, int skew, int rows_per_lane);
 int opal_hip_launch_uber(const OpalHipUberLaunch* args);
 
+/* Streaming SW score search for long queries (stream_kernel.hpp): persistent workgroups, every group of
+   `lanes_per_seq` lanes works through a stream of sequences handed out by `next_counter` (a device int, zero before
+   the launch), the next sequence entering while the previous one drains. width 17 or 18, mode SW, score only, no work
+   list; results and the overflow list as for opal_hip_launch. */
+int opal_hip_stream_rows_supported(int width, int min_rows);   /* smallest instantiated rows_per_lane >= min_rows (0: none) */
+size_t opal_hip_stream_lds_bytes(int width, int lanes_per_seq, int rows_per_lane, int alphabet_length);
+int opal_hip_launch_stream(const OpalHipLaunch* args, int* next_counter);
+
 #define OPAL_HIP_MAX_ROWS 40
 
 int opal_hip_device_count(void);
@@ -188,6 +196,8 @@ OpalxDb* opalx_db_create_flat_device(const unsigned char* d_residues, const int6
 /* opalSearchDatabase keeps its device buffers, pinned staging memory and streams in cached contexts between
    calls; this frees them (optional: call it when no search is running, e.g. before unloading the library). */
 void opalx_release_cached(void);
+/* Number of searches of this process that ran on the streaming SW kernel (diagnostics and tests). */
+long long opalx_stream_launch_count(void);
 void opalx_db_destroy(OpalxDb* db);
 int opalx_db_num_sequences(const OpalxDb* db);
 int64_t opalx_db_num_residues(const OpalxDb* db);

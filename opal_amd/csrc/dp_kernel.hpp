@@ -329,6 +329,10 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
     constexpr bool MULTI = (FLAGS & FLAG_MULTI) != 0;
     constexpr bool PLAIN = WIDTH == 17 || WIDTH == 18;  // one sequence per lane, plain 16-bit instructions
     constexpr bool SKEW = (FLAGS & FLAG_SKEW) != 0 && WIDTH == 17 && MODE != MODE_SW && !MULTI;
+    // NW and OV read the first row block of the NEXT step's profile column at the top of the current step (measured on
+    // the C3 workload: NW 1.183 -> 1.117 ms, OV 1.266 -> 1.248 ms; HW and SW gain nothing from it and the 4 extra live
+    // registers push their 39/40-row shapes over 128, so they read it at the start of their own step)
+    constexpr bool PF_TOP = PLAIN && (MODE == MODE_NW || (MODE == MODE_OV && S <= 38));
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int log2G = cls.log2G;
@@ -501,18 +505,13 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
     uint2 bndNext = make_uint2(0u, 0u);
     if (hasPrev && 0 < slotLen) bndNext = p.bnd[bndIdx(0)];
 
-    int slotMax = 0;                         // SW end location: slot-wide running maximum (see the scan filter)
-    int topHv = V::clampv(-(long long)Go);  // NW: H[-1][0]
-    reg sRv = 0;                             // SKEW: s*Ge as a 16-bit value
-    for (int s = 0; s < nsteps; s++) {
-        if (MODE == MODE_SW && SWEND && NH == 1 && (s & 7) == 0) {
-            int v = V::half(mx, 0);
-            for (int d = 1; d < G; d <<= 1) { const int o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
-            slotMax = v;
-        }
-        if ((s & (G - 1)) == 0) {  // wave-uniform: refill the queue with columns s .. s+G-1
+    // The profile address of a step is formed ONE STEP AHEAD (it depends on tokens only, not on DP values), and the
+    // PF_TOP kernels also issue the LDS read of the next step's first row block then: such a wave no longer begins
+    // every step by waiting out an LDS round trip (DPP shift -> address -> ds_read -> first row).
+    auto advance = [&](const int sn) {  // offv <- profile address of step sn (my column sn - k)
+        if ((sn & (G - 1)) == 0) {  // wave-uniform: refill the queue with columns sn .. sn+G-1
             const unsigned tok = tokNext;
-            const int col = s + k;
+            const int col = sn + k;
             if (col + G < slotLen) tokNext = p.tokens[tokBase + (uint64_t)(col + G)];
 #pragma unroll
             for (int h = 0; h < NH; h++) {
@@ -521,6 +520,31 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
                 else mine = half0 ? ((tok >> 8) & 0xffu) : (tok & 0xffu);
                 tokq[h] = (col < len[h]) ? ldsBase + mine * (unsigned)stride : padOff;
             }
+        }
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            const unsigned shifted = shr1(offv[h]) + (unsigned)LANE_BYTES;
+            offv[h] = (k == 0) ? tokq[h] : shifted;
+            tokq[h] = shl1(tokq[h]);
+        }
+    };
+    int4 pfirst = make_int4(0, 0, 0, 0);  // PF_TOP: first row block of the profile column of the coming step
+    if constexpr (PF_TOP) { advance(0); pfirst = lds_ld16(offv[0]); }
+
+    int slotMax = 0;                         // SW end location: slot-wide running maximum (see the scan filter)
+    int topHv = V::clampv(-(long long)Go);  // NW: H[-1][0]
+    reg sRv = 0;                             // SKEW: s*Ge as a 16-bit value
+    for (int s = 0; s < nsteps; s++) {
+        if constexpr (!PF_TOP) advance(s);
+        unsigned offc[NH];  // this step's profile address
+#pragma unroll
+        for (int h = 0; h < NH; h++) offc[h] = offv[h];
+        const int4 pcur = pfirst;
+        if constexpr (PF_TOP) { advance(s + 1); pfirst = lds_ld16(offv[0]); }
+        if (MODE == MODE_SW && SWEND && NH == 1 && (s & 7) == 0) {
+            int v = V::half(mx, 0);
+            for (int d = 1; d < G; d <<= 1) { const int o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+            slotMax = v;
         }
         const uint2 bndCur = bndNext;
         if (hasPrev && s + 1 < slotLen) bndNext = p.bnd[bndIdx(s + 1)];
@@ -556,12 +580,6 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
                 inF = (MODE == MODE_SW) ? V::subu(topH, Qv) : V::subs(topH, Qv);
             }
         }
-#pragma unroll
-        for (int h = 0; h < NH; h++) {
-            const unsigned shifted = shr1(offv[h]) + (unsigned)LANE_BYTES;
-            offv[h] = (k == 0) ? tokq[h] : shifted;
-            tokq[h] = shl1(tokq[h]);
-        }
         const int c = s - k;  // my column
 
         if (MODE == MODE_SW || c >= 0) {
@@ -575,12 +593,13 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
                 // diagonal add of row j+1 comes before row j's recurrence, so H[j][c-1]'s register is free for H[j][c].
                 constexpr int KIND = MODE == MODE_SW ? ROWS_SW : (SKEW ? ROWS_SKEW : ROWS_GLOBAL);
                 constexpr int NBLK = SPAD / RB;   // LDS reads per column (RB rows each: 4 with 4-byte entries, 8 with 2-byte ones)
-                int4 pc = lds_ld16(offv[0]);
+                int4 pc = pcur;
+                if constexpr (!PF_TOP) pc = lds_ld16(offc[0]);
                 reg d = V::adds(diag, (reg)pc.x), t = 0;  // (a 16-bit add reads the low half only)
                 static_for<NBLK>([&](auto rbc) {
                     constexpr int rb = decltype(rbc)::value;
                     int4 pn = pc;
-                    if constexpr (rb + 1 < NBLK) pn = lds_ld16(offv[0] + (rb + 1) * RB * ES);
+                    if constexpr (rb + 1 < NBLK) pn = lds_ld16(offc[0] + (rb + 1) * RB * ES);
                     reg Pv[RB + 1];  // profile values of this block's rows, then of the next block's first row
                     if constexpr (ES == 4) {
                         Pv[0] = (reg)pc.x; Pv[1] = (reg)pc.y; Pv[2] = (reg)pc.z; Pv[3] = (reg)pc.w;
@@ -607,7 +626,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
             for (int rb = 0; rb < SPAD / RB; rb++) {
                 reg P[RB];
                 if constexpr (WIDTH == 16) {
-                    const int4 ai = lds_ld16(offv[0] + rb * RB * ES), bi = lds_ld16(offv[1] + rb * RB * ES);
+                    const int4 ai = lds_ld16(offc[0] + rb * RB * ES), bi = lds_ld16(offc[1] + rb * RB * ES);
                     const uint4 a = make_uint4((unsigned)ai.x, (unsigned)ai.y, (unsigned)ai.z, (unsigned)ai.w);
                     const uint4 b = make_uint4((unsigned)bi.x, (unsigned)bi.y, (unsigned)bi.z, (unsigned)bi.w);
                     P[0] = __builtin_amdgcn_perm(b.x, a.x, 0x05040100u);
@@ -619,7 +638,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
                     P[6] = __builtin_amdgcn_perm(b.w, a.w, 0x05040100u);
                     P[7] = __builtin_amdgcn_perm(b.w, a.w, 0x07060302u);
                 } else {
-                    const int4 a = lds_ld16(offv[0] + rb * RB * ES);
+                    const int4 a = lds_ld16(offc[0] + rb * RB * ES);
                     P[0] = a.x; P[1] = a.y; P[2] = a.z; P[3] = a.w;
                 }
 #pragma unroll

@@ -47,6 +47,7 @@ namespace {
 static double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+static std::atomic<long long> g_streamLaunches{0};  // searches that took the streaming SW kernel (tests ask)
 static bool debug_on() {
     static const int on = [] { const char* e = getenv("OPAL_HIP_DEBUG"); return (e && *e && *e != '0') ? 1 : 0; }();
     return on != 0;
@@ -781,6 +782,45 @@ static int write_degenerate(OpalxDb* db, const std::vector<int>& quads, int* dSc
     return opal_hip_stream_sync(db->main());  // `quads` is pageable host memory of the caller's frame
 }
 
+// Streaming SW score search (stream_kernel.hpp): which geometry, if any. Long queries need 32 or 64 lanes per sequence,
+// where the class kernels lose (G-1)/(L+G-1) of their steps to pipeline fill and drain; the streaming kernel has no
+// such loss, so it is chosen by the cost of a column step per useful query row alone.
+struct StreamPlan { int width = 0, G = 0, rows = 0; };
+static StreamPlan plan_stream(int Q, int A, long long residues, int longest) {
+    StreamPlan best;
+    const char* en = getenv("OPAL_HIP_STREAM");          // "0": never, "1": whenever a geometry exists (tests), unset: long queries
+    if (en && *en == '0') return best;
+    const bool force = en && *en == '1';
+    const char* forceG = getenv("OPAL_HIP_LANES_PER_SEQ");
+    const char* forceW = getenv("OPAL_HIP_NARROW");
+    if (!force && Q <= 16 * OPAL_HIP_MAX_ROWS) return best;  // 16 lanes per sequence or fewer: the class kernels' fill/drain is small
+    double bestCost = 1e30;
+    for (int width : {17, 18}) {
+        if (forceW && *forceW && atoi(forceW) != width && (atoi(forceW) == 17 || atoi(forceW) == 18)) continue;
+        for (int G = 1; G <= 64; G *= 2) {
+            if (forceG && *forceG && atoi(forceG) != G) continue;
+            const int need = (Q + G - 1) / G;
+            if (need > OPAL_HIP_MAX_ROWS) continue;
+            const int rows = opal_hip_stream_rows_supported(width, need);
+            if (!rows || opal_hip_stream_lds_bytes(width, G, rows, A) > 160 * 1024) continue;
+            const double cost = ((width == 18 ? 9.5 : 9.0) * rows + 30.0) * G / Q;
+            if (cost < bestCost) { bestCost = cost; best.width = width; best.G = G; best.rows = rows; }
+        }
+    }
+    if (best.G && !force) {
+        // A sequence stays on its G lanes from its first column to its last: the longest one (handed out first) sets a
+        // floor of (longest + G) steps at the rate of a wave that ends up alone on its SIMD (~3.5 clk per instruction).
+        // On a small database that floor exceeds the time of the whole search and the class kernels (4*G lanes for
+        // the longest sequences) win: measured with 20 000 sequences, 1000-aa query 2.6 ms against 1.7 ms; with 100 000
+        // sequences 4.9 ms against 7.0 ms.
+        const double stepInstr = (best.width == 18 ? 9.5 : 9.0) * best.rows + 30.0;
+        const double total = (double)residues * best.G / 64.0 * stepInstr * 2.15 / 1024.0;
+        const double crit = ((double)longest + best.G) * stepInstr * 3.5;
+        if (crit > 1.5 * total) best = StreamPlan();
+    }
+    return best;
+}
+
 /*
  * The scheduler. Plays the role of the reference's precision ladder (opal.cpp:496-535, :983-1021)
  * with the rungs gfx950 has: 16-bit first, 32-bit for whatever saturates or cannot be
@@ -849,7 +889,10 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
         if (narrow == 17 && !fits(17) && !(force && atoi(force) == 17)) narrow = 16;
         if (narrow == 18 && !fits(18)) narrow = 16;
     }
-    const bool plain = narrow != 16;
+    // SW score-only searches with long queries stream their sequences through persistent waves (plain 16-bit arithmetic)
+    StreamPlan splan;
+    if (mode == OPAL_MODE_SW && !wantEnd && fits16) splan = plan_stream(Q, A, db->residues, db->pairLen.empty() ? 0 : db->pairLen[0]);
+    const bool plain = narrow != 16 || splan.G;
     const int satLimit = plain ? (int)(32767 - maxS) : 32767;
     SearchCtx c{db, Q, A, Go, Ge, mode, wantEnd, dScore, dEndQ, dEndT, satLimit, mode == OPAL_MODE_SW ? -satLimit : 0, maxS};
     const int nNarrow = narrow == 16 ? P : 2 * P;  // items of the narrow rung: pairs or sequences
@@ -867,7 +910,17 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
         const int* work32 = nullptr;
         std::vector<int> rerun;  // the re-run list, longest sequence first
         if (fits16) {
-            if (narrow == 16) rc = launch_range(c, 16, wantEnd, 0, nullptr, 0, nNarrow, pairLenOf, db->ovfCount.p);
+            if (splan.G) {
+                OpalHipLaunch a;
+                fill_launch(a, c, splan.width, 0, 0, nullptr, db->ovfCount.p);
+                a.lanes_per_seq = splan.G; a.rows_per_lane = splan.rows;
+                a.first_item = 0; a.num_items = 2 * P;
+                if (debug_on())
+                    fprintf(stderr, "[opal] streaming launch width=%d G=%d rows=%d items=%d\n", splan.width, splan.G, splan.rows, 2 * P);
+                rc = opal_hip_launch_stream(&a, db->ovfCount.p + 2) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
+                g_streamLaunches.fetch_add(1);
+            }
+            else if (narrow == 16) rc = launch_range(c, 16, wantEnd, 0, nullptr, 0, nNarrow, pairLenOf, db->ovfCount.p);
             else rc = launch_range(c, narrow, wantEnd, 0, nullptr, 0, nNarrow, seqLenOf, db->ovfCount.p);
             if (rc) return rc;
             int cnt = 0;
@@ -1166,6 +1219,8 @@ extern "C" void opalx_db_destroy(OpalxDb* db) {
     db_release(db);
     delete db;
 }
+
+extern "C" long long opalx_stream_launch_count(void) { return g_streamLaunches.load(); }
 
 extern "C" void opalx_release_cached(void) {
     ContextCache& c = ContextCache::get();

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include "dp_kernel.hpp"
+#include "stream_kernel.hpp"
 #include "opal_hip.h"
 
 static thread_local char g_err[512] = "";
@@ -370,4 +371,69 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(wpb * 64), lds, (hipStream_t)a->stream, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("kernel launch", e);
+}
+
+// ------------------------------------------------------------------ streaming SW score search (stream_kernel.hpp)
+static StreamFn pick_stream(int width, int rows) {
+    if (width == 17) return opal_stream_s17(rows);
+    if (width == 18) return opal_stream_s18(rows);
+    return nullptr;
+}
+static size_t stream_lds_bytes(int width, int G, int rows, int A) {
+    return width == 18 ? opal_stream_lds_bytes<18>(G, rows, A) : opal_stream_lds_bytes<17>(G, rows, A);
+}
+extern "C" int opal_hip_stream_rows_supported(int width, int min_rows) {
+    for (int r = min_rows < 1 ? 1 : min_rows; r <= OPAL_HIP_MAX_ROWS; r++)
+        if (pick_stream(width, r)) return r;
+    return 0;
+}
+extern "C" size_t opal_hip_stream_lds_bytes(int width, int lanes_per_seq, int rows_per_lane, int alphabet_length) {
+    return stream_lds_bytes(width, lanes_per_seq, rows_per_lane, alphabet_length);
+}
+extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter) {
+    const int G = a->lanes_per_seq;
+    int log2G = 0;
+    while ((1 << log2G) < G) log2G++;
+    StreamFn fn = nullptr;
+    if ((1 << log2G) == G && G <= 64 && a->mode == MODE_SW && !a->want_end && !a->work && !a->chunk_flags && next_counter &&
+        a->query_length >= 1 && (long long)G * a->rows_per_lane >= a->query_length)
+        fn = pick_stream(a->width, a->rows_per_lane);
+    if (!fn) {
+        snprintf(g_err, sizeof g_err, "unlaunchable streaming shape: width=%d G=%d rows=%d Q=%d", a->width, G, a->rows_per_lane, a->query_length);
+        fprintf(stderr, "[opal-hip] %s\n", g_err);
+        return 2;
+    }
+    if (a->num_items <= 0) return 0;
+    const size_t lds = stream_lds_bytes(a->width, G, a->rows_per_lane, a->alphabet_length);
+    if (lds > 160 * 1024) { snprintf(g_err, sizeof g_err, "query profile needs %zu bytes of LDS (>160 KiB)", lds); return 2; }
+    static thread_local int cus = 0, cusDevice = -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail("hipGetDevice", hipGetLastError());
+    if (cusDevice != dev) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cusDevice = dev;
+    }
+    StreamParams sp;
+    memset(&sp, 0, sizeof sp);
+    KParams& p = sp.base;
+    p.query = a->query; p.matrix = a->score_matrix; p.Q = a->query_length; p.A = a->alphabet_length;
+    p.Go = a->gap_open; p.Ge = a->gap_ext;
+    p.tokens = a->tokens; p.pairOff = a->pair_token_offset; p.pairLen = a->pair_len; p.pairSeq = a->pair_seq;
+    p.firstItem = a->first_item; p.numItems = a->num_items; p.log2G = log2G;
+    p.outScore = a->out_score; p.ovfCount = a->overflow_count; p.ovfItems = a->overflow_items;
+    p.chunkRows = a->query_length;
+    p.satLimit = a->sat_limit; p.negPad = a->neg_pad;
+    sp.next = next_counter;
+    // persistent workgroups: one per CU (16 waves = 4 per SIMD), fewer when there are not enough sequences to go round
+    const int perBlock = STREAM_WAVES * (64 / G);
+    int blocks = (a->num_items + perBlock - 1) / perBlock;
+    if (blocks > cus) blocks = cus;
+    if (const char* e = getenv("OPAL_HIP_STREAM_BLOCKS")) { const int b = atoi(e); if (b >= 1) blocks = b; }  // test hook
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail("hipFuncSetAttribute", e);
+    }
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(STREAM_WAVES * 64), lds, (hipStream_t)a->stream, sp);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("streaming kernel launch", e);
 }

@@ -1,0 +1,267 @@
+// stream_kernel.hpp -- gfx950: Smith-Waterman score search for LONG queries as a streaming systolic array.
+//
+// Role: the same as dp_kernel.hpp's SW kernels (reference src/opal.cpp:164-470 searchDatabaseSW_ with
+// loadNextSequence :472-490), for queries that need 32 or 64 lanes per sequence. There the class kernels lose
+// (G-1)/(L+G-1) of their steps to filling and draining the lane pipeline for every sequence (18 % at G = 64 on a
+// 350-residue database) and restage a ~100 KB query profile for every 16 sequences with nothing else resident on
+// the CU. Here
+//   * workgroups are PERSISTENT: one per CU, 16 waves, the profile is staged once;
+//   * every slot (G lanes) works through a STREAM of sequences handed out by a device-wide counter (longest
+//     first, so the slots finish together), the next sequence entering lane 0 while the previous one is still
+//     draining through the upper lanes: no fill/drain between sequences, no tail of half-empty workgroups;
+//   * sequences are separated by two separator columns whose "letters" carry gap penalties of 0xFFFF: the unsigned
+//     saturating subtractions of the SW row block (E = max(E -sat Ge, H -sat Go)) then zero E and F in the first
+//     column and H in the second (profile value -32768), which is exactly the state a new sequence starts from --
+//     no register is reset by hand and no step is special-cased. The gap operands therefore live in VGPRs, loaded
+//     per step from a 16-byte info block that sits behind each letter's profile row in LDS;
+//   * a slot's score is the maximum over its lanes' running maxima, collected at the second separator column as
+//     it passes down the lanes (one DPP move per separator step) and written by the last lane.
+// Plain 16-bit arithmetic (Vec<17>: 4-byte profile entries, Vec<18>: 2-byte entries for queries beyond ~1400
+// residues), scores at the saturation limit go to the 32-bit re-run list like everywhere else.
+#pragma once
+#include "dp_kernel.hpp"
+
+struct StreamParams {
+    KParams base;  // work == nullptr; firstItem/numItems: the item range (pair*2+half); log2G: lanes per sequence
+    int* next;     // device counter (zeroed before the launch): next item of the range to hand out
+};
+typedef void (*StreamFn)(const StreamParams);
+
+#define STREAM_WAVES 16          // waves per (persistent) workgroup: 4 per SIMD at <= 128 registers
+#define STREAM_RING 4            // descriptors kept per slot (the newest two can be referenced by a refill, the
+                                 // last lane may still be flushing the one before)
+#define STREAM_DESC_BYTES 32
+
+// one letter's profile row: G lane segments, then the 16-byte info block {Go, Ge, flush flag, 0}
+template <int WIDTH>
+__host__ __device__ inline int opal_stream_stride(int G, int S) {
+    constexpr int ES = WIDTH == 18 ? 2 : 4;
+    int stride = G * opal_lane_bytes(ES, S, WIDTH == 18) + 16;
+    if (((stride / 16) & 1) == 0) stride += 16;
+    return stride;
+}
+template <int WIDTH>
+__host__ __device__ inline size_t opal_stream_lds_bytes(int G, int S, int A) {
+    return (size_t)(A + 3) * (size_t)opal_stream_stride<WIDTH>(G, S) + (size_t)STREAM_WAVES * (64 / G) * STREAM_RING * STREAM_DESC_BYTES;
+}
+
+template <int WIDTH, int S>
+__global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const StreamParams sp) {
+    using V = Vec<WIDTH>;
+    using reg = typename V::reg;
+    using elem = typename V::elem;
+    constexpr int ES = (int)sizeof(elem);
+    constexpr int RB = 16 / ES;
+    constexpr int SPAD = (S + RB - 1) / RB * RB;
+    constexpr int LANE_BYTES = opal_lane_bytes(ES, S, WIDTH == 18);
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const KParams& p = sp.base;
+
+    const int log2G = p.log2G;
+    const int G = 1 << log2G;
+    const int stride = opal_stream_stride<WIDTH>(G, S);
+    const int Q = p.Q, A = p.A;
+    const int padTop = G * S - Q;  // virtual rows above the query (profile 0: H, E, F stay 0 there)
+    const int PAD = A, SEP1 = A + 1, SEP2 = A + 2;
+
+    // ---- stage the profile: QP[letter][k][j]; letters A (beyond a slot's last sequence), A+1, A+2 (separators)
+    {
+        const int perLetter = G * SPAD;
+        for (int rem = threadIdx.x; rem < perLetter; rem += blockDim.x) {
+            const int k = rem / SPAD;
+            const int j = rem - k * SPAD;
+            const int lr = k * S + j - padTop;
+            const bool real = lr >= 0 && j < S;
+            unsigned char* dst = lds + k * LANE_BYTES + j * ES;
+            if (real) {
+                const int* mrow = p.matrix + (int)p.query[lr] * A;
+                for (int letter = 0; letter < A; letter += 2) {
+                    const int l1 = min(letter + 1, A - 1);
+                    const int v0 = mrow[letter], v1 = mrow[l1];
+                    *reinterpret_cast<elem*>(dst + letter * stride) = (elem)v0;
+                    *reinterpret_cast<elem*>(dst + l1 * stride) = (elem)v1;
+                }
+            } else {
+                for (int letter = 0; letter < A; letter++) *reinterpret_cast<elem*>(dst + letter * stride) = (elem)(lr < 0 ? 0 : p.negPad);
+            }
+            // H is in [0, 32767] at all times, so H - 32768 < 0: a separator column cannot extend anything
+            const int sepv = lr < 0 ? 0 : -32768;
+            *reinterpret_cast<elem*>(dst + PAD * stride) = (elem)(lr < 0 ? 0 : p.negPad);
+            *reinterpret_cast<elem*>(dst + SEP1 * stride) = (elem)sepv;
+            *reinterpret_cast<elem*>(dst + SEP2 * stride) = (elem)sepv;
+        }
+        for (int letter = threadIdx.x; letter < A + 3; letter += blockDim.x) {
+            int4 info;
+            const bool sep = letter > A;
+            info.x = sep ? 0xffff : (p.Go & 0xffff);
+            info.y = sep ? 0xffff : (p.Ge & 0xffff);
+            info.z = letter == SEP2 ? 1 : 0;
+            info.w = 0;
+            *reinterpret_cast<int4*>(lds + letter * stride + G * LANE_BYTES) = info;
+        }
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int k = lane & (G - 1);
+    const int slot = lane >> log2G;
+    const int slots = 64 >> log2G;
+    // this slot's descriptor ring: {start, len, caller index, byte shift, token offset lo, hi, item, -}
+    int* const ring = reinterpret_cast<int*>(lds + (size_t)(A + 3) * stride + (size_t)((wave * slots + slot) * STREAM_RING) * STREAM_DESC_BYTES);
+    const int slotLane0 = lane & ~(G - 1);
+
+    reg Hp[S], En[S];
+#pragma unroll
+    for (int j = 0; j < S; j++) { Hp[j] = 0; En[j] = 0; }
+    reg outH = 0, outF = 0, diagIn = 0, mx = 0;
+    int outM = 0;
+    const unsigned ldsBase = (unsigned)(uintptr_t)(opal_lds_u8*)lds;
+    const unsigned padOff = ldsBase + (unsigned)(PAD * stride);
+    const unsigned infoOff = (unsigned)((G - k) * LANE_BYTES);  // from my profile address to my letter's info block
+    unsigned offv = padOff + (unsigned)(k * LANE_BYTES);
+    unsigned tokq = padOff;
+
+    // ---- the stream of this slot (slot-uniform values, kept by every lane)
+    int nEntries = 0;          // descriptors appended so far
+    int curStart = 0;          // stream position where the newest entry starts
+    int coveredEnd = 0;        // stream position where it ends (INT_MAX once the item range is exhausted)
+    int lastEnd = 0;           // end of the last real entry
+    bool done = false;
+    int flushCount = 0;        // last lane: entries whose score has been written
+
+    // token of stream position x (x - k is a multiple of G): descriptor lookup, then a load that is consumed a batch later
+    unsigned tokNext = 0, shiftNext = 0;
+    auto fetch = [&](const int x) {
+        const int base = x - k;
+        const bool need = !done && coveredEnd <= base + G - 1;  // slot-uniform
+        if (__ballot(need) != 0ull) {  // (wave-uniform branch, every lane inside: the broadcast below reads lane 0 of the slot)
+            int idx = 0;
+            if (need && k == 0) idx = atomicAdd(sp.next, 1);
+            idx = __shfl(idx, slotLane0, 64);
+            if (need) {
+                if (idx < p.numItems) {
+                    const int item = p.firstItem + idx;
+                    const int pairIdx = item >> 1, half = item & 1;
+                    int len = p.pairLen[item];
+                    const int seq = p.pairSeq[item];
+                    if (seq < 0) len = 0;
+                    const uint64_t tb = p.pairOff[pairIdx];
+                    const int span = max(len + 2, 2 * G);  // >= 2G: a refill never looks beyond the newest two entries
+                    if (k == 0) {
+                        int* e = ring + (nEntries & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4);
+                        e[0] = coveredEnd; e[1] = len; e[2] = seq; e[3] = half * 8;
+                        e[4] = (int)(unsigned)(tb & 0xffffffffu); e[5] = (int)(unsigned)(tb >> 32); e[6] = item;
+                    }
+                    curStart = coveredEnd;
+                    coveredEnd += span;
+                    lastEnd = coveredEnd;
+                    nEntries++;
+                } else {
+                    done = true;
+                    coveredEnd = INT_MAX;
+                }
+            }
+            // ring writes by lane 0 of a slot are read by its other lanes below (same wave: LDS keeps program order)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        unsigned tok = (unsigned)PAD, sh = 0;
+        if (nEntries > 0 && x < lastEnd) {
+            const int e = (x >= curStart) ? (nEntries - 1) : (nEntries - 2);
+            const int* d = ring + (e & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4);
+            const int4 d0 = *reinterpret_cast<const int4*>(d);
+            const int col = x - d0.x;
+            if (col < d0.y) {
+                const uint64_t tb = (uint64_t)(unsigned)d[4] | ((uint64_t)(unsigned)d[5] << 32);
+                tok = p.tokens[tb + (uint64_t)col];
+                sh = (unsigned)d0.w;
+            } else if (col == d0.y) tok = (unsigned)SEP1;
+            else if (col == d0.y + 1) tok = (unsigned)SEP2;
+        }
+        tokNext = tok;
+        shiftNext = sh;
+    };
+    fetch(k);
+
+    for (int s = 0;; s++) {
+        if ((s & (G - 1)) == 0) {  // wave-uniform: refill the queue with columns s .. s+G-1, fetch those of the next batch
+            const unsigned letter = (tokNext >> shiftNext) & 0xffu;
+            fetch(s + G + k);
+            tokq = ldsBase + letter * (unsigned)stride;
+            // every slot has run dry and its last separator has left the last lane
+            if (__ballot(!(done && s >= lastEnd + G)) == 0ull) break;
+        }
+        reg inH = (reg)shr1((unsigned)outH);
+        reg inF = (reg)shr1((unsigned)outF);
+        inH = (k == 0) ? (reg)0 : inH;  // top boundary of local alignment
+        inF = (k == 0) ? (reg)0 : inF;
+        {
+            const unsigned shifted = shr1(offv) + (unsigned)LANE_BYTES;
+            offv = (k == 0) ? tokq : shifted;
+            tokq = shl1(tokq);
+        }
+        const int4 info = lds_ld16(offv + infoOff);
+        const reg Qv = (reg)info.x, Rv = (reg)info.y;
+
+        reg f = inF;
+        {
+            constexpr int NBLK = SPAD / RB;
+            int4 pc = lds_ld16(offv);
+            reg d = V::adds(diagIn, (reg)pc.x), t = 0;
+            static_for<NBLK>([&](auto rbc) {
+                constexpr int rb = decltype(rbc)::value;
+                int4 pn = pc;
+                if constexpr (rb + 1 < NBLK) pn = lds_ld16(offv + (rb + 1) * RB * ES);
+                reg Pv[RB + 1];
+                if constexpr (ES == 4) {
+                    Pv[0] = (reg)pc.x; Pv[1] = (reg)pc.y; Pv[2] = (reg)pc.z; Pv[3] = (reg)pc.w;
+                } else {
+                    Pv[0] = (reg)pc.x; Pv[1] = (reg)pc.x >> 16; Pv[2] = (reg)pc.y; Pv[3] = (reg)pc.y >> 16;
+                    Pv[4] = (reg)pc.z; Pv[5] = (reg)pc.z >> 16; Pv[6] = (reg)pc.w; Pv[7] = (reg)pc.w >> 16;
+                }
+                Pv[RB] = (reg)pn.x;
+                static_for<RB / 4>([&](auto subc) {
+                    constexpr int j0 = rb * RB + decltype(subc)::value * 4;
+                    if constexpr (j0 < S) {
+                        constexpr int n = (S - j0) < 4 ? (S - j0) : 4;
+                        constexpr bool last = j0 + n == S;
+                        V::template rows<ROWS_SWV, n, last>(&Hp[j0], &En[j0], &Pv[j0 - rb * RB + 1], f, mx, d, t, Qv, Rv);
+                    }
+                });
+                pc = pn;
+            });
+        }
+        outH = Hp[S - 1];
+        outF = f;
+        diagIn = inH;
+
+        // ---- second separator column: hand the slot's maximum down the lanes, the last lane writes it
+        if (__ballot(info.z != 0) != 0ull) {
+            int inM = (int)shr1((unsigned)outM);
+            inM = (k == 0) ? 0 : inM;
+            if (info.z != 0) {
+                const int mine = V::half(mx, 0);
+                outM = mine > inM ? mine : inM;
+                mx = 0;
+                if (k == G - 1) {
+                    const int* d = ring + (flushCount & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4);
+                    const int seq = d[2];
+                    flushCount++;
+                    if (seq >= 0) {
+                        if (outM >= p.satLimit) {  // (opal.cpp:364-370): hand over to width 32
+                            const int at = atomicAdd(p.ovfCount, 1);
+                            p.ovfItems[at] = d[6];
+                        } else {
+                            p.outScore[seq] = outM;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+StreamFn opal_stream_s17(int rows);  // width 17 (4-byte profile entries): rows 1..40
+StreamFn opal_stream_s18(int rows);  // width 18 (2-byte entries): rows 8,12,...,40

@@ -467,3 +467,87 @@ def test_unskewed_16bit_kernels_still_match(mode, ours, oracle, monkeypatch):
     m4 = cases.simple_matrix(4, 5, -4)
     got = ours.search(q4, dbl, 12, 9, m4, 1, MODES[mode])[:4]
     _check(got, oracle.search(q4, dbl, 12, 9, m4, 1, MODES[mode]), mode, f"mixed skew {mode}")
+
+
+def _stream_db(qlen, n=500):
+    """Synthetic sequences plus what a stream of sequences has to get right: single residues, sequences shorter than
+    the lane pipeline, a 5000-residue one, near copies of the query, an odd count (a pair with an absent half)."""
+    from opal_amd import synth
+    res, offs, lens = synth.database(n, seed=42, first=31000 + qlen)
+    q = synth.query(qlen, seed=7)
+    db = [res[offs[i]:offs[i + 1]] for i in range(n)]
+    rng = np.random.RandomState(qlen)
+    for L in (1, 1, 2, 3, 5, 17, 33, 63, 64, 65, 127, 128, 129):
+        db.append(rng.randint(0, 20, size=L).astype(np.uint8))
+    db.append(synth.database(1, seed=9, first=5)[0][:30])
+    db.append(rng.randint(0, 20, size=5000).astype(np.uint8))
+    db.append(q.copy())
+    db.append(q[: max(1, qlen - 7)].copy())
+    db.append(np.concatenate([q[qlen // 3:], q[: qlen // 5]]))
+    if len(db) % 2 == 0:
+        db.append(q[: max(1, qlen // 2)].copy())
+    order = rng.permutation(len(db))
+    return q, [db[i] for i in order]
+
+
+@pytest.mark.parametrize("qlen,lanes,narrow", [(100, "4", "17"), (300, "8", "17"), (513, "16", "17"), (1000, "32", "17"), (1280, "32", "17"),
+                                               (1330, "64", "17"), (1100, "64", "18"), (2000, "64", "18"), (2500, "64", "18")])
+def test_streaming_sw_score_kernels(qlen, lanes, narrow, ours, oracle, monkeypatch):
+    """The streaming SW score kernels (persistent workgroups, sequences handed out by a device counter and separated by
+    two separator columns), forced for every lanes-per-sequence value and both profile widths; once more with a single
+    workgroup, so that every slot works through many sequences."""
+    from opal_amd.score_matrix import blosum50
+    q, db = _stream_db(qlen)
+    m = blosum50()[1]
+    monkeypatch.setenv("OPAL_HIP_STREAM", "1")
+    monkeypatch.setenv("OPAL_HIP_LANES_PER_SEQ", lanes)
+    monkeypatch.setenv("OPAL_HIP_NARROW", narrow)
+    for blocks in ("", "1"):
+        if blocks:
+            monkeypatch.setenv("OPAL_HIP_STREAM_BLOCKS", blocks)
+        for go, ge in ((11, 1), (3, 1)):
+            got = ours.search(q, db, go, ge, m, 0, MODES["SW"])[:4]
+            want = oracle.search(q, db, go, ge, m, 0, MODES["SW"])
+            assert got[0] == want[0] == 0
+            np.testing.assert_array_equal(got[1], want[1], err_msg=f"stream q{qlen} G={lanes} w{narrow} gaps {go}/{ge} blocks={blocks or 'auto'}")
+
+
+def test_streaming_is_what_long_queries_run_on(ours):
+    """Without any forcing, a long query on a database large enough for the longest sequence not to dominate takes the
+    streaming path; a short query, a search with end locations and a small database do not."""
+    from opal_amd import synth
+    from opal_amd.score_matrix import blosum50
+    res, offs, lens = synth.database(30000, seed=42)
+    db = [res[offs[i]:offs[i + 1]] for i in range(30000)]
+    m = blosum50()[1]
+    count = ours.lib.opalx_stream_launch_count
+    count.restype = C.c_longlong
+    for qlen, st, n, expect in ((2000, 0, 30000, 1), (300, 0, 30000, 0), (2000, 1, 30000, 0), (2000, 0, 300, 0)):
+        before = count()
+        rc = ours.search(synth.query(qlen, seed=7), db[:n], 11, 1, m, st, MODES["SW"])[0]
+        assert rc == 0
+        assert count() - before == expect, (qlen, st, n)
+
+
+@pytest.mark.parametrize("narrow", ["17", "18"])
+def test_streaming_saturated_scores_rerun(narrow, ours, oracle, monkeypatch):
+    """Scores at the 16-bit limit leave the streaming kernel through the re-run list (one atomic per sequence, written by
+    the last lane of the slot) and come back from the 32-bit kernels; the others stay."""
+    monkeypatch.setenv("OPAL_HIP_STREAM", "1")
+    monkeypatch.setenv("OPAL_HIP_NARROW", narrow)
+    rng = np.random.RandomState(5)
+    q = rng.randint(0, 4, size=1400).astype(np.uint8)
+    m = cases.simple_matrix(4, 60, -40)
+    db = []
+    for i in range(151):
+        if i % 3 == 0:
+            db.append(rng.randint(0, 4, size=int(rng.randint(20, 900))).astype(np.uint8))
+        else:
+            t = q[: int(rng.randint(600, 1400))].copy()
+            t[rng.randint(0, len(t), size=5)] = rng.randint(0, 4, size=5)
+            db.append(t)
+    got = ours.search(q, db, 30, 5, m, 0, MODES["SW"])[:4]
+    want = oracle.search(q, db, 30, 5, m, 0, MODES["SW"])
+    assert (want[1] > 32767).sum() > 80 and (want[1] < 20000).sum() > 20
+    assert got[0] == 0
+    np.testing.assert_array_equal(got[1], want[1])
