@@ -786,14 +786,13 @@ static int write_degenerate(OpalxDb* db, const std::vector<int>& quads, int* dSc
 // where the class kernels lose (G-1)/(L+G-1) of their steps to pipeline fill and drain; the streaming kernel has no
 // such loss, so it is chosen by the cost of a column step per useful query row alone.
 struct StreamPlan { int width = 0, G = 0, rows = 0; };
-static StreamPlan plan_stream(int Q, int A, long long residues, int longest) {
+static StreamPlan plan_stream(int Q, int A, long long residues, int longest, int numSeqs) {
     StreamPlan best;
     const char* en = getenv("OPAL_HIP_STREAM");          // "0": never, "1": whenever a geometry exists (tests), unset: long queries
     if (en && *en == '0') return best;
     const bool force = en && *en == '1';
     const char* forceG = getenv("OPAL_HIP_LANES_PER_SEQ");
     const char* forceW = getenv("OPAL_HIP_NARROW");
-    if (!force && Q <= 16 * OPAL_HIP_MAX_ROWS) return best;  // 16 lanes per sequence or fewer: the class kernels' fill/drain is small
     double bestCost = 1e30;
     for (int width : {17, 18}) {
         if (forceW && *forceW && atoi(forceW) != width && (atoi(forceW) == 17 || atoi(forceW) == 18)) continue;
@@ -816,7 +815,15 @@ static StreamPlan plan_stream(int Q, int A, long long residues, int longest) {
         const double stepInstr = (best.width == 18 ? 9.5 : 9.0) * best.rows + 30.0;
         const double total = (double)residues * best.G / 64.0 * stepInstr * 2.15 / 1024.0;
         const double crit = ((double)longest + best.G) * stepInstr * 3.5;
-        if (crit > 1.5 * total) best = StreamPlan();
+        if (best.G >= 32) {
+            if (crit > 1.5 * total) best = StreamPlan();
+        } else {
+            // 16 lanes per sequence or fewer: the class kernels lose little to fill and drain, and streaming only wins
+            // (2-4 %: 513-aa query x 625 000 sequences 6 790 -> 7 050 GCUPS, 300-aa x 1 000 000 7 230 -> 7 390) when every
+            // slot works through many sequences; with ~3 per slot (300-aa x 100 000) it is 14 % slower.
+            const double perSlot = (double)numSeqs / (4096.0 * (64 / best.G));
+            if (crit > 0.5 * total || perSlot < 12.0) best = StreamPlan();
+        }
     }
     return best;
 }
@@ -891,7 +898,7 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
     }
     // SW score-only searches with long queries stream their sequences through persistent waves (plain 16-bit arithmetic)
     StreamPlan splan;
-    if (mode == OPAL_MODE_SW && !wantEnd && fits16) splan = plan_stream(Q, A, db->residues, db->pairLen.empty() ? 0 : db->pairLen[0]);
+    if (mode == OPAL_MODE_SW && !wantEnd && fits16) splan = plan_stream(Q, A, db->residues, db->pairLen.empty() ? 0 : db->pairLen[0], db->numSeqs);
     const bool plain = narrow != 16 || splan.G;
     const int satLimit = plain ? (int)(32767 - maxS) : 32767;
     SearchCtx c{db, Q, A, Go, Ge, mode, wantEnd, dScore, dEndQ, dEndT, satLimit, mode == OPAL_MODE_SW ? -satLimit : 0, maxS};
