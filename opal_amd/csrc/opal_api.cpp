@@ -786,7 +786,7 @@ static int write_degenerate(OpalxDb* db, const std::vector<int>& quads, int* dSc
 // where the class kernels lose (G-1)/(L+G-1) of their steps to pipeline fill and drain; the streaming kernel has no
 // such loss, so it is chosen by the cost of a column step per useful query row alone.
 struct StreamPlan { int width = 0, G = 0, rows = 0; };
-static StreamPlan plan_stream(int Q, int A, long long residues, int longest, int numSeqs) {
+static StreamPlan plan_stream(int Q, int A, int wantEnd, long long residues, int longest, int numSeqs) {
     StreamPlan best;
     const char* en = getenv("OPAL_HIP_STREAM");          // "0": never, "1": whenever a geometry exists (tests), unset: long queries
     if (en && *en == '0') return best;
@@ -800,12 +800,13 @@ static StreamPlan plan_stream(int Q, int A, long long residues, int longest, int
             if (forceG && *forceG && atoi(forceG) != G) continue;
             const int need = (Q + G - 1) / G;
             if (need > OPAL_HIP_MAX_ROWS) continue;
-            const int rows = opal_hip_stream_rows_supported(width, need);
+            const int rows = opal_hip_stream_rows_supported(width, wantEnd, need);
             if (!rows || opal_hip_stream_lds_bytes(width, G, rows, A) > 160 * 1024) continue;
-            const double cost = ((width == 18 ? 9.5 : 9.0) * rows + 30.0) * G / Q;
+            const double cost = ((width == 18 ? 9.5 : 9.0) * rows + (wantEnd ? 1.5 * rows : 0.0) + 30.0) * G / Q;
             if (cost < bestCost) { bestCost = cost; best.width = width; best.G = G; best.rows = rows; }
         }
     }
+    if (best.G && !force && wantEnd && best.G < 32) best = StreamPlan();  // (end locations at 16 lanes or fewer: class kernels, unmeasured otherwise)
     if (best.G && !force) {
         // A sequence stays on its G lanes from its first column to its last: the longest one (handed out first) sets a
         // floor of (longest + G) steps at the rate of a wave that ends up alone on its SIMD (~3.5 clk per instruction).
@@ -898,7 +899,7 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
     }
     // SW score-only searches with long queries stream their sequences through persistent waves (plain 16-bit arithmetic)
     StreamPlan splan;
-    if (mode == OPAL_MODE_SW && !wantEnd && fits16) splan = plan_stream(Q, A, db->residues, db->pairLen.empty() ? 0 : db->pairLen[0], db->numSeqs);
+    if (mode == OPAL_MODE_SW && fits16) splan = plan_stream(Q, A, wantEnd, db->residues, db->pairLen.empty() ? 0 : db->pairLen[0], db->numSeqs);
     const bool plain = narrow != 16 || splan.G;
     const int satLimit = plain ? (int)(32767 - maxS) : 32767;
     SearchCtx c{db, Q, A, Go, Ge, mode, wantEnd, dScore, dEndQ, dEndT, satLimit, mode == OPAL_MODE_SW ? -satLimit : 0, maxS};
@@ -919,11 +920,11 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
         if (fits16) {
             if (splan.G) {
                 OpalHipLaunch a;
-                fill_launch(a, c, splan.width, 0, 0, nullptr, db->ovfCount.p);
+                fill_launch(a, c, splan.width, wantEnd, 0, nullptr, db->ovfCount.p);
                 a.lanes_per_seq = splan.G; a.rows_per_lane = splan.rows;
                 a.first_item = 0; a.num_items = 2 * P;
                 if (debug_on())
-                    fprintf(stderr, "[opal] streaming launch width=%d G=%d rows=%d items=%d\n", splan.width, splan.G, splan.rows, 2 * P);
+                    fprintf(stderr, "[opal] streaming launch width=%d G=%d rows=%d end=%d items=%d\n", splan.width, splan.G, splan.rows, wantEnd, 2 * P);
                 rc = opal_hip_launch_stream(&a, db->ovfCount.p + 2) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
                 g_streamLaunches.fetch_add(1);
             }

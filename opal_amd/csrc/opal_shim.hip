@@ -374,17 +374,17 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
 }
 
 // ------------------------------------------------------------------ streaming SW score search (stream_kernel.hpp)
-static StreamFn pick_stream(int width, int rows) {
-    if (width == 17) return opal_stream_s17(rows);
-    if (width == 18) return opal_stream_s18(rows);
+static StreamFn pick_stream(int width, int want_end, int rows) {
+    if (width == 17) return want_end ? opal_stream_s17end(rows) : opal_stream_s17(rows);
+    if (width == 18) return want_end ? opal_stream_s18end(rows) : opal_stream_s18(rows);
     return nullptr;
 }
 static size_t stream_lds_bytes(int width, int G, int rows, int A) {
     return width == 18 ? opal_stream_lds_bytes<18>(G, rows, A) : opal_stream_lds_bytes<17>(G, rows, A);
 }
-extern "C" int opal_hip_stream_rows_supported(int width, int min_rows) {
+extern "C" int opal_hip_stream_rows_supported(int width, int want_end, int min_rows) {
     for (int r = min_rows < 1 ? 1 : min_rows; r <= OPAL_HIP_MAX_ROWS; r++)
-        if (pick_stream(width, r)) return r;
+        if (pick_stream(width, want_end, r)) return r;
     return 0;
 }
 extern "C" size_t opal_hip_stream_lds_bytes(int width, int lanes_per_seq, int rows_per_lane, int alphabet_length) {
@@ -395,9 +395,10 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
     int log2G = 0;
     while ((1 << log2G) < G) log2G++;
     StreamFn fn = nullptr;
-    if ((1 << log2G) == G && G <= 64 && a->mode == MODE_SW && !a->want_end && !a->work && !a->chunk_flags && next_counter &&
+    if ((1 << log2G) == G && G <= 64 && a->mode == MODE_SW && !a->work && !a->chunk_flags && next_counter &&
+        (!a->want_end || (a->out_end_query && a->out_end_target)) &&
         a->query_length >= 1 && (long long)G * a->rows_per_lane >= a->query_length)
-        fn = pick_stream(a->width, a->rows_per_lane);
+        fn = pick_stream(a->width, a->want_end, a->rows_per_lane);
     if (!fn) {
         snprintf(g_err, sizeof g_err, "unlaunchable streaming shape: width=%d G=%d rows=%d Q=%d", a->width, G, a->rows_per_lane, a->query_length);
         fprintf(stderr, "[opal-hip] %s\n", g_err);
@@ -420,7 +421,8 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
     p.Go = a->gap_open; p.Ge = a->gap_ext;
     p.tokens = a->tokens; p.pairOff = a->pair_token_offset; p.pairLen = a->pair_len; p.pairSeq = a->pair_seq;
     p.firstItem = a->first_item; p.numItems = a->num_items; p.log2G = log2G;
-    p.outScore = a->out_score; p.ovfCount = a->overflow_count; p.ovfItems = a->overflow_items;
+    p.outScore = a->out_score; p.outEndQ = a->want_end ? a->out_end_query : nullptr; p.outEndT = a->want_end ? a->out_end_target : nullptr;
+    p.ovfCount = a->overflow_count; p.ovfItems = a->overflow_items;
     p.chunkRows = a->query_length;
     p.satLimit = a->sat_limit; p.negPad = a->neg_pad;
     sp.next = next_counter;

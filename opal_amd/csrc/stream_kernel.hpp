@@ -45,7 +45,7 @@ __host__ __device__ inline size_t opal_stream_lds_bytes(int G, int S, int A) {
     return (size_t)(A + 3) * (size_t)opal_stream_stride<WIDTH>(G, S) + (size_t)STREAM_WAVES * (64 / G) * STREAM_RING * STREAM_DESC_BYTES;
 }
 
-template <int WIDTH, int S>
+template <int WIDTH, int S, bool SWEND = false>
 __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const StreamParams sp) {
     using V = Vec<WIDTH>;
     using reg = typename V::reg;
@@ -128,7 +128,13 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     int coveredEnd = 0;        // stream position where it ends (INT_MAX once the item range is exhausted)
     int lastEnd = 0;           // end of the last real entry
     bool done = false;
-    int flushCount = 0;        // last lane: entries whose score has been written
+    int flushCount = 0;        // entries this lane has seen the end of (the last lane: whose score has been written)
+    // SWEND: where my running maximum was first reached (column within the sequence, query row), the stream position at
+    // which my current sequence starts, and what the lane below reads: the maximum over the lanes above and me for the
+    // column I just finished (scan filter), and at the second separator the best cell so far (score, column, row)
+    int endCol = INT_MAX, endRow = -1, myStart = 0;
+    int pmOut = 0, outCol = INT_MAX, outRow = -1;
+    const int r0 = k * S - padTop;  // query row held in register 0
 
     // token of stream position x (x - k is a multiple of G): descriptor lookup, then a load that is consumed a batch later
     unsigned tokNext = 0, shiftNext = 0;
@@ -206,6 +212,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
         const reg Qv = (reg)info.x, Rv = (reg)info.y;
 
         reg f = inF;
+        reg cm = 0;  // SWEND: this column's maximum over my rows
         {
             constexpr int NBLK = SPAD / RB;
             int4 pc = lds_ld16(offv);
@@ -227,7 +234,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
                     if constexpr (j0 < S) {
                         constexpr int n = (S - j0) < 4 ? (S - j0) : 4;
                         constexpr bool last = j0 + n == S;
-                        V::template rows<ROWS_SWV, n, last>(&Hp[j0], &En[j0], &Pv[j0 - rb * RB + 1], f, mx, d, t, Qv, Rv);
+                        V::template rows<ROWS_SWV, n, last>(&Hp[j0], &En[j0], &Pv[j0 - rb * RB + 1], f, SWEND ? cm : mx, d, t, Qv, Rv);
                     }
                 });
                 pc = pn;
@@ -237,24 +244,73 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
         outF = f;
         diagIn = inH;
 
+        if constexpr (SWEND) {
+            // End location in the same pass, as in the class kernels: only a STRICT improvement of my running maximum
+            // can be the first cell holding the final score, and it is worth a row scan only if it also reaches the
+            // maximum the lanes ABOVE me had reached when they finished this very column (a lower bound of the final
+            // score that belongs to this sequence by construction: it travels down the lanes with the column).
+            int pmIn = (int)shr1((unsigned)pmOut);
+            pmIn = (k == 0) ? 0 : pmIn;
+            const int cv = V::half(cm, 0), mv = V::half(mx, 0);
+            if (cv > mv && cv >= pmIn) {
+                int r = 0;
+                constexpr int NBLK4 = (S + 3) / 4;
+                static_for<NBLK4>([&](auto bc) {  // highest block first: the smallest row holding it wins
+                    constexpr int b = NBLK4 - 1 - decltype(bc)::value;
+                    constexpr int n = (S - 4 * b) < 4 ? (S - 4 * b) : 4;
+                    V::template scan_rows<n, 4 * b>(&Hp[4 * b], cm, r);
+                });
+                endRow = r0 + r;
+                endCol = s - k - myStart;
+            }
+            mx = V::maxs(mx, cm);
+            const int mv2 = V::half(mx, 0);
+            pmOut = mv2 > pmIn ? mv2 : pmIn;
+        }
+
         // ---- second separator column: hand the slot's maximum down the lanes, the last lane writes it
         if (__ballot(info.z != 0) != 0ull) {
             int inM = (int)shr1((unsigned)outM);
             inM = (k == 0) ? 0 : inM;
+            int inCol = INT_MAX, inRow = -1;
+            if constexpr (SWEND) {
+                inCol = (int)shr1((unsigned)outCol);
+                inRow = (int)shr1((unsigned)outRow);
+                if (k == 0) { inCol = INT_MAX; inRow = -1; }
+            }
             if (info.z != 0) {
                 const int mine = V::half(mx, 0);
-                outM = mine > inM ? mine : inM;
+                if constexpr (SWEND) {
+                    // best cell: highest score, then smallest column, then smallest row (= the lanes above me)
+                    const bool take = mine > inM || (mine == inM && endCol < inCol);
+                    outM = take ? mine : inM;
+                    outCol = take ? endCol : inCol;
+                    outRow = take ? endRow : inRow;
+                    endCol = INT_MAX; endRow = -1;
+                } else {
+                    outM = mine > inM ? mine : inM;
+                }
                 mx = 0;
-                if (k == G - 1) {
-                    const int* d = ring + (flushCount & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4);
-                    const int seq = d[2];
+                const int* d = ring + (flushCount & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4);
+                if constexpr (SWEND) {  // my next sequence starts where this entry's span ends
+                    const int4 d0 = *reinterpret_cast<const int4*>(d);
+                    myStart = d0.x + max(d0.y + 2, 2 * G);
                     flushCount++;
+                }
+                if (k == G - 1) {
+                    const int seq = d[2];
+                    if constexpr (!SWEND) flushCount++;
                     if (seq >= 0) {
                         if (outM >= p.satLimit) {  // (opal.cpp:364-370): hand over to width 32
                             const int at = atomicAdd(p.ovfCount, 1);
                             p.ovfItems[at] = d[6];
                         } else {
                             p.outScore[seq] = outM;
+                            if constexpr (SWEND) {
+                                const bool none = outM <= 0 || outCol == INT_MAX;  // score 0: no cell (test.cpp:242-243)
+                                p.outEndQ[seq] = none ? -1 : outRow;
+                                p.outEndT[seq] = none ? -1 : outCol;
+                            }
                         }
                     }
                 }
@@ -263,5 +319,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     }
 }
 
-StreamFn opal_stream_s17(int rows);  // width 17 (4-byte profile entries): rows 1..40
-StreamFn opal_stream_s18(int rows);  // width 18 (2-byte entries): rows 8,12,...,40
+StreamFn opal_stream_s17(int rows);     // width 17 (4-byte profile entries), score only: rows 1..40
+StreamFn opal_stream_s18(int rows);     // width 18 (2-byte entries), score only: rows 20..40
+StreamFn opal_stream_s17end(int rows);  // with end locations: rows 1..36
+StreamFn opal_stream_s18end(int rows);  // rows 20..36

@@ -19,6 +19,9 @@ sample = np.random.RandomState(5).choice(n, size=min(n, 120), replace=False)
 sdb = [res[offs[i]:offs[i + 1]] for i in sample]
 a = torch.zeros(n, dtype=torch.int32, device="cuda")
 b = torch.zeros(n, dtype=torch.int32, device="cuda")
+e1 = torch.zeros(n, dtype=torch.int32, device="cuda")
+e2 = torch.zeros(n, dtype=torch.int32, device="cuda")
+ST = int(os.environ.get("ST", "0"))  # 1: with end locations
 
 def run(q, go, ge, env, out, iters):
     for k in ("OPAL_HIP_STREAM", "OPAL_HIP_LANES_PER_SEQ", "OPAL_HIP_NARROW"):
@@ -27,7 +30,7 @@ def run(q, go, ge, env, out, iters):
     ks = []
     out.fill_(-7)
     for _ in range(iters):
-        rc, kms = pdb.search_device(q, go, ge, m, 0, 3, out.data_ptr(), 0, 0)
+        rc, kms = pdb.search_device(q, go, ge, m, ST, 3, out.data_ptr(), e1.data_ptr() if ST else 0, e2.data_ptr() if ST else 0)
         assert rc == 0, rc
         ks.append(kms)
     return min(ks)
@@ -44,7 +47,7 @@ for qlen, extra in cases:
         t0 = run(q, go, ge, {"OPAL_HIP_STREAM": "0"}, a, iters)
         t1 = run(q, go, ge, dict(extra, OPAL_HIP_STREAM="1"), b, iters)
         same = bool((a == b).all().item())
-        rc, os_, _, _ = orc.search(q, sdb, go, ge, m, 0, 3)
+        rc, os_, _, _ = orc.search(q, sdb, go, ge, m, ST, 3)
         got = b.cpu().numpy()[sample]
         ok = bool((got == os_).all())
         cells = float(qlen) * float(offs[-1])

@@ -510,11 +510,14 @@ def test_streaming_sw_score_kernels(qlen, lanes, narrow, ours, oracle, monkeypat
             want = oracle.search(q, db, go, ge, m, 0, MODES["SW"])
             assert got[0] == want[0] == 0
             np.testing.assert_array_equal(got[1], want[1], err_msg=f"stream q{qlen} G={lanes} w{narrow} gaps {go}/{ge} blocks={blocks or 'auto'}")
+            # with end locations (the streaming kernels exist up to 36 rows per lane; beyond that the class kernels answer)
+            got = ours.search(q, db, go, ge, m, 1, MODES["SW"])[:4]
+            _check(got, oracle.search(q, db, go, ge, m, 1, MODES["SW"]), "SW", f"stream+end q{qlen} G={lanes} w{narrow} gaps {go}/{ge} blocks={blocks or 'auto'}")
 
 
 def test_streaming_is_what_long_queries_run_on(ours):
     """Without any forcing, a long query on a database large enough for the longest sequence not to dominate takes the
-    streaming path; a short query, a search with end locations and a small database do not."""
+    streaming path (with or without end locations); a short query and a small database do not."""
     from opal_amd import synth
     from opal_amd.score_matrix import blosum50
     res, offs, lens = synth.database(30000, seed=42)
@@ -522,7 +525,7 @@ def test_streaming_is_what_long_queries_run_on(ours):
     m = blosum50()[1]
     count = ours.lib.opalx_stream_launch_count
     count.restype = C.c_longlong
-    for qlen, st, n, expect in ((2000, 0, 30000, 1), (300, 0, 30000, 0), (2000, 1, 30000, 0), (2000, 0, 300, 0)):
+    for qlen, st, n, expect in ((2000, 0, 30000, 1), (300, 0, 30000, 0), (2000, 1, 30000, 1), (2000, 0, 300, 0)):
         before = count()
         rc = ours.search(synth.query(qlen, seed=7), db[:n], 11, 1, m, st, MODES["SW"])[0]
         assert rc == 0
@@ -551,3 +554,5 @@ def test_streaming_saturated_scores_rerun(narrow, ours, oracle, monkeypatch):
     assert (want[1] > 32767).sum() > 80 and (want[1] < 20000).sum() > 20
     assert got[0] == 0
     np.testing.assert_array_equal(got[1], want[1])
+    got = ours.search(q, db, 30, 5, m, 1, MODES["SW"])[:4]
+    _check(got, oracle.search(q, db, 30, 5, m, 1, MODES["SW"]), "SW", f"stream+end overflows narrow={narrow}")
