@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     const int k = lane & (G - 1);
     const int slot = lane >> log2G;
     const int slots = 64 >> log2G;
-    // this slot's descriptor ring: {start, len, caller index, byte shift, token offset lo, hi, item, -}
+    // this slot's descriptor ring: {start, len, caller index, byte shift, token offset lo, hi, item, running maximum (SWEND)}
     int* const ring = reinterpret_cast<int*>(lds + (size_t)(A + 3) * stride + (size_t)((wave * slots + slot) * STREAM_RING) * STREAM_DESC_BYTES);
     const int slotLane0 = lane & ~(G - 1);
 
@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     // which my current sequence starts, and what the lane below reads: the maximum over the lanes above and me for the
     // column I just finished (scan filter), and at the second separator the best cell so far (score, column, row)
     int endCol = INT_MAX, endRow = -1, myStart = 0;
-    int pmOut = 0, outCol = INT_MAX, outRow = -1;
+    int pmOut = 0, outCol = INT_MAX, outRow = -1, seqMax = 0;
     const int r0 = k * S - padTop;  // query row held in register 0
 
     // token of stream position x (x - k is a multiple of G): descriptor lookup, then a load that is consumed a batch later
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
                     if (k == 0) {
                         int* e = ring + (nEntries & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4);
                         e[0] = coveredEnd; e[1] = len; e[2] = seq; e[3] = half * 8;
-                        e[4] = (int)(unsigned)(tb & 0xffffffffu); e[5] = (int)(unsigned)(tb >> 32); e[6] = item;
+                        e[4] = (int)(unsigned)(tb & 0xffffffffu); e[5] = (int)(unsigned)(tb >> 32); e[6] = item; e[7] = 0;
                     }
                     curStart = coveredEnd;
                     coveredEnd += span;
@@ -252,7 +252,13 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
             int pmIn = (int)shr1((unsigned)pmOut);
             pmIn = (k == 0) ? 0 : pmIn;
             const int cv = V::half(cm, 0), mv = V::half(mx, 0);
-            if (cv > mv && cv >= pmIn) {
+            // ... and the maximum ALL lanes of my sequence had reached a few steps ago: one LDS atomic per 8 steps on the
+            // sequence's descriptor (word 7), which also covers the lanes below me
+            if ((s & 7) == 0) {
+                const int old = atomicMax(ring + (flushCount & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4) + 7, mv);
+                seqMax = old > mv ? old : mv;
+            }
+            if (cv > mv && cv >= pmIn && cv >= seqMax) {
                 int r = 0;
                 constexpr int NBLK4 = (S + 3) / 4;
                 static_for<NBLK4>([&](auto bc) {  // highest block first: the smallest row holding it wins
@@ -286,7 +292,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
                     outM = take ? mine : inM;
                     outCol = take ? endCol : inCol;
                     outRow = take ? endRow : inRow;
-                    endCol = INT_MAX; endRow = -1;
+                    endCol = INT_MAX; endRow = -1; seqMax = 0;
                 } else {
                     outM = mine > inM ? mine : inM;
                 }
