@@ -894,7 +894,15 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
         const char* force = getenv("OPAL_HIP_NARROW_FORCE");  // "17": run width 17 in row chunks rather than switching width
         // (width 18 measured SLOWER than the packed pairs on the 2000-aa workload, 15.1 vs 14.8 ms, so it is never
         // chosen automatically: OPAL_HIP_NARROW=18 selects it for experiments)
-        if (narrow == 17 && !fits(17) && !(force && atoi(force) == 17)) narrow = 16;
+        if (narrow == 17 && !fits(17) && !(force && atoi(force) == 17)) {
+            narrow = 16;
+            // ... except where the plain kernels with 2-byte profile entries measure faster (2000-aa query, class kernels,
+            // 100 000 / 20 000 sequences: SW + end 4 150 against 3 350 / 3 720 against 2 970 GCUPS, OV 4 270 : 4 130 / 3 810 : 3 660,
+            // NW and HW 4 970 : 5 100 / 4 400 : 4 040)
+            if (!getenv("OPAL_HIP_NARROW") && fits(18) &&
+                ((mode == OPAL_MODE_SW && wantEnd) || mode == OPAL_MODE_OV || (mode != OPAL_MODE_SW && db->numSeqs < 50000)))
+                narrow = 18;
+        }
         if (narrow == 18 && !fits(18)) narrow = 16;
     }
     // SW score-only searches with long queries stream their sequences through persistent waves (plain 16-bit arithmetic)
