@@ -133,7 +133,8 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     // which my current sequence starts, and what the lane below reads: the maximum over the lanes above and me for the
     // column I just finished (scan filter), and at the second separator the best cell so far (score, column, row)
     int endCol = INT_MAX, endRow = -1, myStart = 0;
-    int pmOut = 0, outCol = INT_MAX, outRow = -1, seqMax = 0;
+    reg pmOut = V::splat(-1), seqM1 = V::splat(-1);
+    int outCol = INT_MAX, outRow = -1;
     const int r0 = k * S - padTop;  // query row held in register 0
 
     // token of stream position x (x - k is a multiple of G): descriptor lookup, then a load that is consumed a batch later
@@ -249,16 +250,20 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
             // can be the first cell holding the final score, and it is worth a row scan only if it also reaches the
             // maximum the lanes ABOVE me had reached when they finished this very column (a lower bound of the final
             // score that belongs to this sequence by construction: it travels down the lanes with the column).
-            int pmIn = (int)shr1((unsigned)pmOut);
-            pmIn = (k == 0) ? 0 : pmIn;
-            const int cv = V::half(cm, 0), mv = V::half(mx, 0);
-            // ... and the maximum ALL lanes of my sequence had reached a few steps ago: one LDS atomic per 8 steps on the
-            // sequence's descriptor (word 7), which also covers the lanes below me
+            reg pmIn = (reg)shr1((unsigned)pmOut);
+            pmIn = (k == 0) ? V::splat(-1) : pmIn;
+            // ... and (minus one: ties with it may still be mine) the maximum ALL lanes of my sequence had reached a few steps
+            // ago: one LDS atomic per 8 steps on the sequence's descriptor (word 7), which also covers the lanes below me.
+            // Both bounds are kept MINUS ONE: a value equal to them may still be the first cell of the final score, and a
+            // lane that skipped a scan must end below the final score (its end cell is stale). Everything stays in 16-bit
+            // values and full-rate instructions: max, max, compare.
             if ((s & 7) == 0) {
+                const int mv = V::half(mx, 0);
                 const int old = atomicMax(ring + (flushCount & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4) + 7, mv);
-                seqMax = old > mv ? old : mv;
+                seqM1 = V::splat((old > mv ? old : mv) - 1);
             }
-            if (cv > mv && cv >= pmIn && cv >= seqMax) {
+            const reg bar = V::maxs(V::maxs(mx, seqM1), pmIn);
+            if ((short)cm > (short)bar) {
                 int r = 0;
                 constexpr int NBLK4 = (S + 3) / 4;
                 static_for<NBLK4>([&](auto bc) {  // highest block first: the smallest row holding it wins
@@ -270,8 +275,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
                 endCol = s - k - myStart;
             }
             mx = V::maxs(mx, cm);
-            const int mv2 = V::half(mx, 0);
-            pmOut = mv2 > pmIn ? mv2 : pmIn;
+            pmOut = V::maxs(pmIn, V::subs(mx, V::splat(1)));
         }
 
         // ---- second separator column: hand the slot's maximum down the lanes, the last lane writes it
@@ -292,7 +296,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
                     outM = take ? mine : inM;
                     outCol = take ? endCol : inCol;
                     outRow = take ? endRow : inRow;
-                    endCol = INT_MAX; endRow = -1; seqMax = 0;
+                    endCol = INT_MAX; endRow = -1; seqM1 = V::splat(-1);
                 } else {
                     outM = mine > inM ? mine : inM;
                 }
