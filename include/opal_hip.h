@@ -105,12 +105,13 @@ typedef struct OpalHipUberLaunch {
 int opal_hip_uber_supported(int mode, int want_end, int skew, int rows_per_lane);
 int opal_hip_launch_uber(const OpalHipUberLaunch* args);
 
-/* Streaming SW score search for long queries (stream_kernel.hpp): persistent workgroups, every group of
-   `lanes_per_seq` lanes works through a stream of sequences handed out by `next_counter` (a device int, zero before
-   the launch), the next sequence entering while the previous one drains. width 17 or 18, mode SW (score only or with end
-   locations: want_end), no work list; results and the overflow list as for opal_hip_launch. */
-int opal_hip_stream_rows_supported(int width, int want_end, int min_rows);   /* smallest instantiated rows_per_lane >= min_rows (0: none) */
-size_t opal_hip_stream_lds_bytes(int width, int lanes_per_seq, int rows_per_lane, int alphabet_length);
+/* Streaming searches (stream_kernel.hpp): persistent workgroups, every group of `lanes_per_seq` lanes works through a
+   stream of sequences handed out by `next_counter` (a device int, zero before the launch), the next sequence entering
+   while the previous one drains. width 17 or 18; SW (score only or with end locations: want_end) or NW/HW/OV (the
+   diagonal-skewed kernels: the caller guarantees the 16-bit range as for `skew`); no work list; results and, for SW, the
+   overflow list as for opal_hip_launch. */
+int opal_hip_stream_rows_supported(int width, int mode, int want_end, int min_rows);   /* smallest instantiated rows_per_lane >= min_rows (0: none) */
+size_t opal_hip_stream_lds_bytes(int width, int mode, int lanes_per_seq, int rows_per_lane, int alphabet_length);
 int opal_hip_launch_stream(const OpalHipLaunch* args, int* next_counter);
 
 #define OPAL_HIP_MAX_ROWS 40

@@ -1,0 +1,20 @@
+// Streaming NW/HW/OV kernels (diagonal-skewed), width 18 (2-byte profile entries): rows per lane 20..40.
+#include "stream_kernel.hpp"
+
+// (OV with 40 rows per lane: the one shape that does not fit 128 registers)
+template <int MODE, int ROWS> struct GlFn { static constexpr StreamFn fn = opal_gl_stream<18, MODE, ROWS>; };
+template <> struct GlFn<MODE_OV, 40> { static constexpr StreamFn fn = nullptr; };
+
+template <int MODE, int... R>
+static StreamFn pick(int rows, std::integer_sequence<int, R...>) {
+    static const StreamFn table[] = {GlFn<MODE, R + 20>::fn...};
+    return (rows >= 20 && rows < 20 + (int)sizeof...(R)) ? table[rows - 20] : nullptr;
+}
+
+StreamFn opal_stream_gl18(int mode, int rows) {
+    using Seq = std::make_integer_sequence<int, 21>;
+    if (mode == MODE_NW) return pick<MODE_NW>(rows, Seq{});
+    if (mode == MODE_HW) return pick<MODE_HW>(rows, Seq{});
+    if (mode == MODE_OV) return pick<MODE_OV>(rows, Seq{});
+    return nullptr;
+}

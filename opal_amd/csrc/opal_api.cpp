@@ -786,7 +786,7 @@ static int write_degenerate(OpalxDb* db, const std::vector<int>& quads, int* dSc
 // where the class kernels lose (G-1)/(L+G-1) of their steps to pipeline fill and drain; the streaming kernel has no
 // such loss, so it is chosen by the cost of a column step per useful query row alone.
 struct StreamPlan { int width = 0, G = 0, rows = 0; };
-static StreamPlan plan_stream(int Q, int A, int wantEnd, long long residues, int longest, int numSeqs) {
+static StreamPlan plan_stream(int Q, int A, int mode, int wantEnd, long long residues, int longest, int numSeqs) {
     StreamPlan best;
     const char* en = getenv("OPAL_HIP_STREAM");          // "0": never, "1": whenever a geometry exists (tests), unset: long queries
     if (en && *en == '0') return best;
@@ -800,13 +800,14 @@ static StreamPlan plan_stream(int Q, int A, int wantEnd, long long residues, int
             if (forceG && *forceG && atoi(forceG) != G) continue;
             const int need = (Q + G - 1) / G;
             if (need > OPAL_HIP_MAX_ROWS) continue;
-            const int rows = opal_hip_stream_rows_supported(width, wantEnd, need);
-            if (!rows || opal_hip_stream_lds_bytes(width, G, rows, A) > 160 * 1024) continue;
-            const double cost = ((width == 18 ? 9.5 : 9.0) * rows + (wantEnd ? 1.5 * rows : 0.0) + 30.0) * G / Q;
+            const int rows = opal_hip_stream_rows_supported(width, mode, wantEnd, need);
+            if (!rows || opal_hip_stream_lds_bytes(width, mode, G, rows, A) > 160 * 1024) continue;
+            const double perRow = (mode == OPAL_MODE_SW ? 9.0 + (wantEnd ? 1.5 : 0.0) : 6.0) + (width == 18 ? 0.5 : 0.0);
+            const double cost = (perRow * rows + 30.0) * G / Q;
             if (cost < bestCost) { bestCost = cost; best.width = width; best.G = G; best.rows = rows; }
         }
     }
-    if (best.G && !force && wantEnd && best.G < 32) best = StreamPlan();  // (end locations at 16 lanes or fewer: class kernels, unmeasured otherwise)
+    if (best.G && !force && (wantEnd || mode != OPAL_MODE_SW) && best.G < 32) best = StreamPlan();  // (end locations, NW/HW/OV at 16 lanes or fewer: class kernels, unmeasured otherwise)
     if (best.G && !force) {
         // A sequence stays on its G lanes from its first column to its last: the longest one (handed out first) sets a
         // floor of (longest + G) steps at the rate of a wave that ends up alone on its SIMD (~3.5 clk per instruction).
@@ -907,7 +908,7 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
     }
     // SW score-only searches with long queries stream their sequences through persistent waves (plain 16-bit arithmetic)
     StreamPlan splan;
-    if (mode == OPAL_MODE_SW && fits16) splan = plan_stream(Q, A, wantEnd, db->residues, db->pairLen.empty() ? 0 : db->pairLen[0], db->numSeqs);
+    if (mode == OPAL_MODE_SW && fits16) splan = plan_stream(Q, A, mode, wantEnd, db->residues, db->pairLen.empty() ? 0 : db->pairLen[0], db->numSeqs);
     const bool plain = narrow != 16 || splan.G;
     const int satLimit = plain ? (int)(32767 - maxS) : 32767;
     SearchCtx c{db, Q, A, Go, Ge, mode, wantEnd, dScore, dEndQ, dEndT, satLimit, mode == OPAL_MODE_SW ? -satLimit : 0, maxS};
@@ -996,6 +997,34 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
                 p32++;
             }
         }
+        // Long queries on large databases: the 16-bit part as a stream of sequences through persistent waves
+        // (stream_kernel.hpp, diagonal-skewed kernels). The few sequences whose skewed values could leave 16 bits join the
+        // 32-bit prefix (they are the longest ones); if they hold more than 2 % of the residues the class kernels run instead.
+        StreamPlan gplan;
+        if (fits16 && p32 < P) {
+            int q32 = p32;
+            long long moved = 0;
+            auto skew_safe = [&](long long L) {
+                return std::min<long long>(Q, L) * maxS + (OPAL_HIP_MAX_ROWS + L + 64 + 4) * (long long)Ge < 32000;
+            };
+            while (q32 < P && !skew_safe(db->pairLen[2 * (size_t)q32])) { moved += db->pairLen[2 * (size_t)q32] + db->pairLen[2 * (size_t)q32 + 1]; q32++; }
+            const char* sen = getenv("OPAL_HIP_STREAM");
+            if (q32 < P && (moved * 50 <= db->residues || (sen && *sen == '1')) && !getenv("OPAL_HIP_NO_SKEW")) {
+                gplan = plan_stream(Q, A, mode, wantEnd, db->residues - moved, db->pairLen[2 * (size_t)q32], db->numSeqs - 2 * q32);
+                if (gplan.G) p32 = q32;
+            }
+        }
+        auto launch_global_stream = [&]() -> int {
+            OpalHipLaunch a;
+            fill_launch(a, c, gplan.width, 0, 0, nullptr, db->ovfCount.p);
+            a.lanes_per_seq = gplan.G; a.rows_per_lane = gplan.rows; a.skew = 1;
+            a.first_item = 2 * p32; a.num_items = 2 * (P - p32);
+            if (debug_on())
+                fprintf(stderr, "[opal] streaming launch mode=%d width=%d G=%d rows=%d items=[%d,+%d)\n", mode, gplan.width, gplan.G, gplan.rows,
+                        a.first_item, a.num_items);
+            g_streamLaunches.fetch_add(1);
+            return opal_hip_launch_stream(&a, db->ovfCount.p + 2);
+        };
         // 32-bit safety (our definition where the reference is undefined, see oracle/opal_oracle.c):
         // sequences whose bound leaves [-2^30, 2^30] are not computed and the call returns OVERFLOW.
         // Width-32 items (pair*2+half) enumerate the sequences in descending length, so the unsafe
@@ -1013,7 +1042,8 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
             launch_range(c, 32, 0, 0, nullptr, nBad, 2 * p32 - nBad, seqLenOf, db->ovfCount.p + 1))
             return OPAL_ERR_NO_SIMD_SUPPORT;
         if (P > p32) {
-            const int e = narrow == 16 ? launch_range(c, 16, 0, 0, nullptr, p32, P - p32, pairLenOf, db->ovfCount.p)
+            const int e = gplan.G ? launch_global_stream()
+                        : narrow == 16 ? launch_range(c, 16, 0, 0, nullptr, p32, P - p32, pairLenOf, db->ovfCount.p)
                                        : launch_range(c, narrow, 0, 0, nullptr, 2 * p32, 2 * (P - p32), seqLenOf, db->ovfCount.p);
             if (e) return OPAL_ERR_NO_SIMD_SUPPORT;
         }

@@ -374,38 +374,44 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
 }
 
 // ------------------------------------------------------------------ streaming SW score search (stream_kernel.hpp)
-static StreamFn pick_stream(int width, int want_end, int rows) {
+static StreamFn pick_stream(int width, int mode, int want_end, int rows) {
+    if (mode != MODE_SW) {
+        if (width == 17) return opal_stream_gl17(mode, rows);
+        if (width == 18) return opal_stream_gl18(mode, rows);
+        return nullptr;
+    }
     if (width == 17) return want_end ? opal_stream_s17end(rows) : opal_stream_s17(rows);
     if (width == 18) return want_end ? opal_stream_s18end(rows) : opal_stream_s18(rows);
     return nullptr;
 }
-static size_t stream_lds_bytes(int width, int G, int rows, int A) {
+static size_t stream_lds_bytes(int width, int mode, int G, int rows, int A) {
+    if (mode != MODE_SW) return width == 18 ? opal_gl_stream_lds_bytes<18>(G, rows, A) : opal_gl_stream_lds_bytes<17>(G, rows, A);
     return width == 18 ? opal_stream_lds_bytes<18>(G, rows, A) : opal_stream_lds_bytes<17>(G, rows, A);
 }
-extern "C" int opal_hip_stream_rows_supported(int width, int want_end, int min_rows) {
+extern "C" int opal_hip_stream_rows_supported(int width, int mode, int want_end, int min_rows) {
     for (int r = min_rows < 1 ? 1 : min_rows; r <= OPAL_HIP_MAX_ROWS; r++)
-        if (pick_stream(width, want_end, r)) return r;
+        if (pick_stream(width, mode, want_end, r)) return r;
     return 0;
 }
-extern "C" size_t opal_hip_stream_lds_bytes(int width, int lanes_per_seq, int rows_per_lane, int alphabet_length) {
-    return stream_lds_bytes(width, lanes_per_seq, rows_per_lane, alphabet_length);
+extern "C" size_t opal_hip_stream_lds_bytes(int width, int mode, int lanes_per_seq, int rows_per_lane, int alphabet_length) {
+    return stream_lds_bytes(width, mode, lanes_per_seq, rows_per_lane, alphabet_length);
 }
 extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter) {
     const int G = a->lanes_per_seq;
     int log2G = 0;
     while ((1 << log2G) < G) log2G++;
     StreamFn fn = nullptr;
-    if ((1 << log2G) == G && G <= 64 && a->mode == MODE_SW && !a->work && !a->chunk_flags && next_counter &&
+    if ((1 << log2G) == G && G <= 64 && a->mode >= 0 && a->mode <= 3 && !a->work && !a->chunk_flags && next_counter &&
         (!a->want_end || (a->out_end_query && a->out_end_target)) &&
         a->query_length >= 1 && (long long)G * a->rows_per_lane >= a->query_length)
-        fn = pick_stream(a->width, a->want_end, a->rows_per_lane);
+        fn = pick_stream(a->width, a->mode, a->want_end, a->rows_per_lane);
     if (!fn) {
         snprintf(g_err, sizeof g_err, "unlaunchable streaming shape: width=%d G=%d rows=%d Q=%d", a->width, G, a->rows_per_lane, a->query_length);
         fprintf(stderr, "[opal-hip] %s\n", g_err);
         return 2;
     }
     if (a->num_items <= 0) return 0;
-    const size_t lds = stream_lds_bytes(a->width, G, a->rows_per_lane, a->alphabet_length);
+    const size_t lds = stream_lds_bytes(a->width, a->mode, G, a->rows_per_lane, a->alphabet_length);
     if (lds > 160 * 1024) { snprintf(g_err, sizeof g_err, "query profile needs %zu bytes of LDS (>160 KiB)", lds); return 2; }
     static thread_local int cus = 0, cusDevice = -1;
     int dev = 0;
@@ -421,7 +427,7 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
     p.Go = a->gap_open; p.Ge = a->gap_ext;
     p.tokens = a->tokens; p.pairOff = a->pair_token_offset; p.pairLen = a->pair_len; p.pairSeq = a->pair_seq;
     p.firstItem = a->first_item; p.numItems = a->num_items; p.log2G = log2G;
-    p.outScore = a->out_score; p.outEndQ = a->want_end ? a->out_end_query : nullptr; p.outEndT = a->want_end ? a->out_end_target : nullptr;
+    p.outScore = a->out_score; p.outEndQ = a->out_end_query; p.outEndT = a->out_end_target;  /* (SW score only: NULL) */
     p.ovfCount = a->overflow_count; p.ovfItems = a->overflow_items;
     p.chunkRows = a->query_length;
     p.satLimit = a->sat_limit; p.negPad = a->neg_pad;

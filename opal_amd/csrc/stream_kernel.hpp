@@ -329,7 +329,332 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     }
 }
 
+// ------------------------------------------------------------------ NW / HW / OV as a stream of sequences
+// The same persistent-workgroup scheme for the global modes (reference src/opal.cpp:594-977 searchDatabase_, with the
+// lane re-initialisation of :921-961), in the diagonal-skewed representation of dp_kernel.hpp (6 instructions per cell:
+// X' = X + (row register + local step) * Ge). There is no zero clamp to build a separator from, so a lane that reaches
+// the first column of its next sequence RELOADS its boundary column: H[r][-1] and E[r][0] of its rows (in its frame at
+// local step k) are per-lane constants, staged once per workgroup in LDS as 4-byte entries and fetched with
+// ds_read_b128 straight into the DP registers -- no arithmetic. The local step (column + lane) restarts with every
+// sequence, so the skew stays as small as in the class kernels; the host sends only sequences whose skewed values stay
+// inside 16 bits (the others take the 32-bit path with those that need it anyway).
+// Results: NW the final cell on the lane holding query row Q-1; HW the last-row maximum tracked by the last lane; OV
+// also the last-column maximum, handed down the lanes as each reaches its last column (value, then smallest row).
+template <int WIDTH>
+__host__ __device__ inline int opal_gl_stream_stride(int G, int S) {
+    constexpr int ES = WIDTH == 18 ? 2 : 4;
+    int stride = G * opal_lane_bytes(ES, S, WIDTH == 18);
+    if (((stride / 16) & 1) == 0) stride += 16;
+    return stride;
+}
+__host__ __device__ inline int opal_gl_init_entries(int S) { return 2 * ((S + 3) / 4 * 4) + 4; }  // Hp[], En[], diagonal input
+template <int WIDTH>
+__host__ __device__ inline size_t opal_gl_stream_lds_bytes(int G, int S, int A) {
+    return (size_t)(A + 1) * (size_t)opal_gl_stream_stride<WIDTH>(G, S) + (size_t)G * opal_gl_init_entries(S) * 4 +
+           (size_t)STREAM_WAVES * (64 / G) * STREAM_RING * STREAM_DESC_BYTES;
+}
+
+template <int WIDTH, int MODE, int S>
+__global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const StreamParams sp) {
+    using V = Vec<WIDTH>;
+    using reg = typename V::reg;
+    using elem = typename V::elem;
+    constexpr int ES = (int)sizeof(elem);
+    constexpr int RB = 16 / ES;
+    constexpr int SPAD = (S + RB - 1) / RB * RB;
+    constexpr int SP4 = (S + 3) / 4 * 4;
+    constexpr int INIT = 2 * SP4 + 4;  // entries of one lane's boundary block
+    constexpr int LANE_BYTES = opal_lane_bytes(ES, S, WIDTH == 18);
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const KParams& p = sp.base;
+
+    const int log2G = p.log2G;
+    const int G = 1 << log2G;
+    const int stride = opal_gl_stream_stride<WIDTH>(G, S);
+    const int Q = p.Q, A = p.A;
+    const int Go = p.Go, Ge = p.Ge;
+    const int padTop = (MODE == MODE_NW) ? 0 : (G * S - Q);  // NW pads below the query, HW/OV above (dp_kernel.hpp)
+    const int PAD = A;
+    const int sk = 2 * Ge;  // the skewed diagonal: H'(j,s) = H'(j-1,s-1) + P + 2*Ge
+    unsigned char* const initBase = lds + (size_t)(A + 1) * stride;
+
+    // ---- stage the profile (+2*Ge) and every lane's boundary block
+    {
+        const int perLetter = G * SPAD;
+        for (int rem = threadIdx.x; rem < perLetter; rem += blockDim.x) {
+            const int k = rem / SPAD;
+            const int j = rem - k * SPAD;
+            const int lr = k * S + j - padTop;
+            const bool real = lr >= 0 && j < S && lr < Q;
+            unsigned char* dst = lds + k * LANE_BYTES + j * ES;
+            if (real) {
+                const int* mrow = p.matrix + (int)p.query[lr] * A;
+                for (int letter = 0; letter < A; letter += 2) {
+                    const int l1 = min(letter + 1, A - 1);
+                    const int v0 = mrow[letter], v1 = mrow[l1];
+                    *reinterpret_cast<elem*>(dst + letter * stride) = (elem)(v0 + sk);
+                    *reinterpret_cast<elem*>(dst + l1 * stride) = (elem)(v1 + sk);
+                }
+                *reinterpret_cast<elem*>(dst + PAD * stride) = (elem)(p.negPad + sk);
+            } else {
+                const int fill = (lr < 0 ? 0 : p.negPad) + sk;
+                for (int letter = 0; letter <= A; letter++) *reinterpret_cast<elem*>(dst + letter * stride) = (elem)fill;
+            }
+        }
+        auto hbound = [&](int r) -> long long {  // H[r][-1] (opal.cpp:671-679); rows above the query: 0
+            return (MODE == MODE_OV || r < 0) ? 0LL : -(long long)Go - (long long)r * Ge;
+        };
+        for (int idx = threadIdx.x; idx < G * INIT; idx += blockDim.x) {
+            const int k = idx / INIT;
+            const int e = idx - k * INIT;
+            const int r0k = k * S - padTop;
+            int v = 0;
+            if (e < SP4) {  // H[r][-1] in the frame of my step before my first column
+                const int j = e;
+                v = V::clampv(hbound(r0k + j)) + (j + k - 1) * Ge;
+            } else if (e < 2 * SP4) {  // E[r][0] = H[r][-1] - Go in the frame of my first column
+                const int j = e - SP4;
+                v = V::clampv(hbound(r0k + j) - Go) + (j + k) * Ge;
+            } else if (e == 2 * SP4) {  // H[r0-1][-1] as the lane above would have handed it over
+                v = V::clampv(hbound(r0k - 1)) + (k - 2) * Ge;
+            }
+            reinterpret_cast<int*>(initBase)[idx] = v & 0xffff;
+        }
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int k = lane & (G - 1);
+    const int slot = lane >> log2G;
+    const int slots = 64 >> log2G;
+    int* const ring = reinterpret_cast<int*>(initBase + (size_t)G * INIT * 4 + (size_t)((wave * slots + slot) * STREAM_RING) * STREAM_DESC_BYTES);
+    const int slotLane0 = lane & ~(G - 1);
+    const unsigned myInit = (unsigned)(uintptr_t)(opal_lds_u8*)initBase + (unsigned)(k * INIT * 4);
+
+    reg Hp[S], En[S];
+#pragma unroll
+    for (int j = 0; j < S; j++) { Hp[j] = 0; En[j] = 0; }
+    reg outH = 0, outF = 0, diagIn = 0;
+    const reg Qv = V::splat(Go), Rv = V::splat(Ge);
+    const unsigned GQs = (unsigned)(Go - Ge) & 0xffffu;
+    const reg SR1v = V::splat((S - 1) * Ge);
+    reg sRv = 0;  // (my column + k) * Ge: the local step of my current sequence
+    const unsigned ldsBase = (unsigned)(uintptr_t)(opal_lds_u8*)lds;
+    const unsigned padOff = ldsBase + (unsigned)(PAD * stride);
+    unsigned offv = padOff + (unsigned)(k * LANE_BYTES);
+    unsigned tokq = padOff;
+
+    // where query row Q-1 lives: NW lane kLast, register jLast; HW/OV the last register of the last lane
+    const int kLast = (MODE == MODE_NW) ? (Q - 1) / S : G - 1;
+    const int jLast = (MODE == MODE_NW) ? (Q - 1) - kLast * S : S - 1;
+    const int r0 = k * S - padTop;
+    int jlo = padTop - k * S, jhi = Q + padTop - k * S;  // my registers [jlo, jhi) hold real query rows
+    jlo = jlo < 0 ? 0 : (jlo > S ? S : jlo);
+    jhi = jhi < 0 ? 0 : (jhi > S ? S : jhi);
+
+    // ---- the stream of this slot
+    int nEntries = 0, curStart = 0, coveredEnd = 0, lastEnd = 0;
+    bool done = false;
+    int started = 0;                    // entries this lane has begun
+    int myStart = 0, myLen = 0, myNext = 0;  // my current sequence: first stream position, length; where my next one begins
+    int best = INT_MIN, bestCol = -1, prevBest = INT_MIN;  // HW/OV (last lane): last-row maximum, its first column; OV: before the last column
+    int outLcV = INT_MIN, outLcRow = -1;                    // OV: last-column maximum handed down the lanes
+
+    unsigned tokNext = 0, shiftNext = 0;
+    auto fetch = [&](const int x) {
+        const int base = x - k;
+        const bool need = !done && coveredEnd <= base + G - 1;
+        if (__ballot(need) != 0ull) {
+            int idx = 0;
+            if (need && k == 0) idx = atomicAdd(sp.next, 1);
+            idx = __shfl(idx, slotLane0, 64);
+            if (need) {
+                if (idx < p.numItems) {
+                    const int item = p.firstItem + idx;
+                    const int pairIdx = item >> 1, half = item & 1;
+                    int len = p.pairLen[item];
+                    const int seq = p.pairSeq[item];
+                    if (seq < 0) len = 0;
+                    const uint64_t tb = p.pairOff[pairIdx];
+                    const int span = max(len, 2 * G);
+                    if (k == 0) {
+                        int* e = ring + (nEntries & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4);
+                        e[0] = coveredEnd; e[1] = len; e[2] = seq; e[3] = half * 8;
+                        e[4] = (int)(unsigned)(tb & 0xffffffffu); e[5] = (int)(unsigned)(tb >> 32); e[6] = item; e[7] = 0;
+                    }
+                    curStart = coveredEnd;
+                    coveredEnd += span;
+                    lastEnd = coveredEnd;
+                    nEntries++;
+                } else {
+                    done = true;
+                    coveredEnd = INT_MAX;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        unsigned tok = (unsigned)PAD, sh = 0;
+        if (nEntries > 0 && x < lastEnd) {
+            const int e = (x >= curStart) ? (nEntries - 1) : (nEntries - 2);
+            const int* d = ring + (e & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4);
+            const int4 d0 = *reinterpret_cast<const int4*>(d);
+            const int col = x - d0.x;
+            if (col < d0.y) {
+                const uint64_t tb = (uint64_t)(unsigned)d[4] | ((uint64_t)(unsigned)d[5] << 32);
+                tok = p.tokens[tb + (uint64_t)col];
+                sh = (unsigned)d0.w;
+            }
+        }
+        tokNext = tok;
+        shiftNext = sh;
+    };
+    fetch(k);
+
+    for (int s = 0;; s++) {
+        if ((s & (G - 1)) == 0) {
+            const unsigned letter = (tokNext >> shiftNext) & 0xffu;
+            fetch(s + G + k);
+            tokq = ldsBase + letter * (unsigned)stride;
+            if (__ballot(!(done && s >= lastEnd + G)) == 0ull) break;
+        }
+        const int x = s - k;  // my stream position
+        // ---- first column of my next sequence: reload the boundary column
+        if (__ballot(x == myNext) != 0ull) {
+            if (x == myNext) {
+                if (started < nEntries) {
+                    const int4 d0 = *reinterpret_cast<const int4*>(ring + (started & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4));
+                    myStart = d0.x;  // == myNext
+                    myLen = d0.y;
+                    myNext = d0.x + max(d0.y, 2 * G);
+                    started++;
+                } else {  // the stream has run dry: nothing of mine is a result any more
+                    myLen = 0;
+                    myNext = INT_MAX;
+                }
+                static_for<SP4 / 4>([&](auto bc) {
+                    constexpr int b = decltype(bc)::value;
+                    const int4 h4 = lds_ld16(myInit + b * 16);
+                    const int4 e4 = lds_ld16(myInit + (SP4 + b * 4) * 4);
+                    if constexpr (4 * b + 0 < S) { Hp[4 * b + 0] = (reg)h4.x; En[4 * b + 0] = (reg)e4.x; }
+                    if constexpr (4 * b + 1 < S) { Hp[4 * b + 1] = (reg)h4.y; En[4 * b + 1] = (reg)e4.y; }
+                    if constexpr (4 * b + 2 < S) { Hp[4 * b + 2] = (reg)h4.z; En[4 * b + 2] = (reg)e4.z; }
+                    if constexpr (4 * b + 3 < S) { Hp[4 * b + 3] = (reg)h4.w; En[4 * b + 3] = (reg)e4.w; }
+                });
+                diagIn = (reg)lds_ld16(myInit + 2 * SP4 * 4).x;
+                sRv = V::splat(k * Ge);
+                best = INT_MIN; bestCol = -1; prevBest = INT_MIN;
+            }
+        }
+        const int c = x - myStart;  // my column
+
+        // ---- inputs of this column: from the lane above (frame change of S-1 registers), or the top boundary
+        reg inH = V::subs((reg)shr1((unsigned)outH), SR1v);
+        reg inF = V::subs((reg)shr1((unsigned)outF), SR1v);
+        if (k == 0) {
+            // H[-1][c] + (s-1)*Ge and F[0][c] + s*Ge = H[-1][c] - Go + s*Ge; NW: H[-1][c] = -Go - c*Ge, HW/OV: 0
+            if (MODE == MODE_NW) { inH = V::splat(-Go - Ge); inF = V::splat(-2 * Go); }
+            else { inH = V::subs(sRv, Rv); inF = V::subs(sRv, Qv); }
+        }
+        {
+            const unsigned shifted = shr1(offv) + (unsigned)LANE_BYTES;
+            offv = (k == 0) ? tokq : shifted;
+            tokq = shl1(tokq);
+        }
+        reg f = inF;
+        reg unused = 0;
+        {
+            constexpr int NBLK = SPAD / RB;
+            int4 pc = lds_ld16(offv);
+            reg d = V::adds(diagIn, (reg)pc.x), t = 0;
+            static_for<NBLK>([&](auto rbc) {
+                constexpr int rb = decltype(rbc)::value;
+                int4 pn = pc;
+                if constexpr (rb + 1 < NBLK) pn = lds_ld16(offv + (rb + 1) * RB * ES);
+                reg Pv[RB + 1];
+                if constexpr (ES == 4) {
+                    Pv[0] = (reg)pc.x; Pv[1] = (reg)pc.y; Pv[2] = (reg)pc.z; Pv[3] = (reg)pc.w;
+                } else {
+                    Pv[0] = (reg)pc.x; Pv[1] = (reg)pc.x >> 16; Pv[2] = (reg)pc.y; Pv[3] = (reg)pc.y >> 16;
+                    Pv[4] = (reg)pc.z; Pv[5] = (reg)pc.z >> 16; Pv[6] = (reg)pc.w; Pv[7] = (reg)pc.w >> 16;
+                }
+                Pv[RB] = (reg)pn.x;
+                static_for<RB / 4>([&](auto subc) {
+                    constexpr int j0 = rb * RB + decltype(subc)::value * 4;
+                    if constexpr (j0 < S) {
+                        constexpr int n = (S - j0) < 4 ? (S - j0) : 4;
+                        constexpr bool last = j0 + n == S;
+                        V::template rows<ROWS_SKEW, n, last>(&Hp[j0], &En[j0], &Pv[j0 - rb * RB + 1], f, unused, d, t, GQs, 0u);
+                    }
+                });
+                pc = pn;
+            });
+        }
+        outH = Hp[S - 1];
+        outF = f;
+        diagIn = inH;
+
+        // ---- results (caller index and length of my sequence: descriptor started-1)
+        const int* desc = ring + ((started - 1) & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4);
+        if (MODE == MODE_NW) {
+            if (k == kLast && c == myLen - 1 && myLen > 0) {  // the final cell: once per sequence
+                const reg hl = SelectRow<reg, S, 0, S>::get(Hp, jLast);
+                const int v = V::half(V::subs(hl, V::adds(sRv, V::splat(jLast * Ge))), 0);
+                const int seq = desc[2];
+                if (seq >= 0) {
+                    p.outScore[seq] = v;
+                    if (p.outEndQ) { p.outEndQ[seq] = Q - 1; p.outEndT[seq] = myLen - 1; }
+                }
+            }
+        }
+        if (MODE == MODE_HW || MODE == MODE_OV) {
+            const bool lastc = c == myLen - 1 && myLen > 0;
+            int lcV = INT_MIN, lcRow = -1;
+            if (MODE == MODE_OV) {
+                // the last column: its maximum over the query rows (value, then smallest row), lane by lane as the column
+                // passes down (opal.cpp:881-904)
+                if (__ballot(lastc) != 0ull) {
+                    int inV = (int)shr1((unsigned)outLcV), inRow = (int)shr1((unsigned)outLcRow);
+                    if (k == 0) { inV = INT_MIN; inRow = -1; }
+                    if (lastc) {
+                        int bv = INT_MIN, bj = -1;
+#pragma unroll
+                        for (int j = S - 1; j >= 0; j--) {
+                            const int v = V::half(V::subs(Hp[j], V::adds(sRv, V::splat(j * Ge))), 0);
+                            if (j >= jlo && j < jhi && v >= bv) { bv = v; bj = j; }
+                            asm volatile("" : "+v"(bv), "+v"(bj));
+                        }
+                        lcV = inV; lcRow = inRow;
+                        if (bj >= 0 && bv > inV) { lcV = bv; lcRow = r0 + bj; }  // the lanes above hold smaller rows: they keep ties
+                        outLcV = lcV; outLcRow = lcRow;
+                    }
+                }
+            }
+            if (k == kLast && c >= 0 && c < myLen) {
+                // last query row = last register of the last lane = this column's outH
+                const int v = V::half(V::subs(outH, V::adds(sRv, SR1v)), 0);
+                if (lastc) prevBest = best;
+                if (v > best) { best = v; bestCol = c; }  // strict >: first column wins (opal.cpp:824-834)
+                if (lastc) {
+                    int sc = best, eq = Q - 1, et = bestCol;
+                    if (MODE == MODE_OV && lcV > prevBest) { sc = lcV; et = myLen - 1; eq = lcRow; }
+                    const int seq = desc[2];
+                    if (seq >= 0) {
+                        p.outScore[seq] = sc;
+                        if (p.outEndQ) { p.outEndQ[seq] = eq; p.outEndT[seq] = et; }
+                    }
+                }
+            }
+        }
+        sRv = V::adds(sRv, Rv);
+    }
+}
+
 StreamFn opal_stream_s17(int rows);     // width 17 (4-byte profile entries), score only: rows 1..40
 StreamFn opal_stream_s18(int rows);     // width 18 (2-byte entries), score only: rows 20..40
 StreamFn opal_stream_s17end(int rows);  // with end locations: rows 1..36
 StreamFn opal_stream_s18end(int rows);  // rows 20..36
+StreamFn opal_stream_gl17(int mode, int rows);  // NW/HW/OV, width 17: rows 1..40
+StreamFn opal_stream_gl18(int mode, int rows);  // width 18: rows 20..40

@@ -556,3 +556,28 @@ def test_streaming_saturated_scores_rerun(narrow, ours, oracle, monkeypatch):
     np.testing.assert_array_equal(got[1], want[1])
     got = ours.search(q, db, 30, 5, m, 1, MODES["SW"])[:4]
     _check(got, oracle.search(q, db, 30, 5, m, 1, MODES["SW"]), "SW", f"stream+end overflows narrow={narrow}")
+
+
+@pytest.mark.parametrize("mode", ["NW", "HW", "OV"])
+@pytest.mark.parametrize("qlen,lanes,narrow", [(100, "4", "17"), (300, "8", "17"), (513, "16", "17"), (1000, "32", "17"), (1200, "64", "17"),
+                                               (1330, "64", "18"), (2000, "64", "18"), (2490, "64", "18")])
+def test_streaming_global_kernels(mode, qlen, lanes, narrow, ours, oracle, monkeypatch):
+    """NW/HW/OV as a stream of sequences (boundary column reloaded from LDS at every sequence start, diagonal-skewed
+    arithmetic with a local step per sequence), forced for every lanes-per-sequence value and both profile widths, with
+    end locations and score only; once more with a single workgroup."""
+    from opal_amd.score_matrix import blosum50
+    q, db = _stream_db(qlen)
+    m = blosum50()[1]
+    monkeypatch.setenv("OPAL_HIP_STREAM", "1")
+    monkeypatch.setenv("OPAL_HIP_LANES_PER_SEQ", lanes)
+    monkeypatch.setenv("OPAL_HIP_NARROW", narrow)
+    count = ours.lib.opalx_stream_launch_count
+    count.restype = C.c_longlong
+    before = count()
+    for blocks in ("", "1"):
+        if blocks:
+            monkeypatch.setenv("OPAL_HIP_STREAM_BLOCKS", blocks)
+        for go, ge, st in ((11, 1, 1), (3, 1, 1), (3, 1, 0)):
+            got = ours.search(q, db, go, ge, m, st, MODES[mode])[:4]
+            _check(got, oracle.search(q, db, go, ge, m, st, MODES[mode]), mode, f"stream {mode} q{qlen} G={lanes} w{narrow} gaps {go}/{ge} st={st} blocks={blocks or 'auto'}")
+    assert count() - before == 6
