@@ -6,6 +6,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "dp_kernel.hpp"
 #include "stream_kernel.hpp"
 #include "opal_hip.h"
@@ -190,6 +194,22 @@ extern "C" int opal_hip_scatter_results(const int* quads, int count, int* score,
     return e == hipSuccess ? 0 : fail("scatter kernel launch", e);
 }
 
+
+// Kernels that need more than 64 KiB of dynamic LDS get the limit raised once per kernel and device (to the full 160 KiB):
+// hipFuncSetAttribute is not free while other kernels are running (it delayed a launch beside a running one by ~2 ms).
+static int raise_lds_limit(const void* fn) {
+    static std::mutex m;
+    static std::set<std::pair<int, const void*>> raised;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1;
+    std::lock_guard<std::mutex> lk(m);
+    if (raised.count({dev, fn})) return 0;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { fail("hipFuncSetAttribute", e); return 1; }
+    raised.insert({dev, fn});
+    return 0;
+}
+
 static size_t lds_bytes(int width, int G, int rows, int A) {
     const int es = (width == 16 || width == 18) ? 2 : 4;  // widths 17 and 32 keep 4-byte profile entries
     return (size_t)(A + 1) * (size_t)opal_profile_stride(es, G, rows, width == 18) + 16;
@@ -308,10 +328,7 @@ extern "C" int opal_hip_launch_uber(const OpalHipUberLaunch* u) {
     if (blocks == 0) return 0;
     if (a->lds_bytes_min > 0 && (size_t)a->lds_bytes_min > lds && a->lds_bytes_min <= 160 * 1024) lds = (size_t)a->lds_bytes_min;
     if (lds > 160 * 1024) { snprintf(g_err, sizeof g_err, "query profile needs %zu bytes of LDS (>160 KiB)", lds); return 2; }
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail("hipFuncSetAttribute", e);
-    }
+    if (lds > 64 * 1024 && raise_lds_limit((const void*)fn)) return 1;
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(WAVES_PER_BLOCK * 64), lds, (hipStream_t)a->stream, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("one-launch kernel launch", e);
@@ -364,10 +381,7 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
         fprintf(stderr, "[opal-hip] %s\n", g_err);
         return 2;
     }
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail("hipFuncSetAttribute", e);
-    }
+    if (lds > 64 * 1024 && raise_lds_limit((const void*)fn)) return 1;
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(wpb * 64), lds, (hipStream_t)a->stream, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("kernel launch", e);
@@ -435,12 +449,10 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
     // persistent workgroups: one per CU (16 waves = 4 per SIMD), fewer when there are not enough sequences to go round
     const int perBlock = STREAM_WAVES * (64 / G);
     int blocks = (a->num_items + perBlock - 1) / perBlock;
-    if (blocks > cus) blocks = cus;
+    const int avail = (a->stream_blocks_reserved > 0 && a->stream_blocks_reserved < cus) ? cus - a->stream_blocks_reserved : cus;
+    if (blocks > avail) blocks = avail;
     if (const char* e = getenv("OPAL_HIP_STREAM_BLOCKS")) { const int b = atoi(e); if (b >= 1) blocks = b; }  // test hook
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail("hipFuncSetAttribute", e);
-    }
+    if (lds > 64 * 1024 && raise_lds_limit((const void*)fn)) return 1;
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(STREAM_WAVES * 64), lds, (hipStream_t)a->stream, sp);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("streaming kernel launch", e);
