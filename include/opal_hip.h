@@ -89,9 +89,9 @@ typedef struct OpalHipLaunch {
     /* request at least this much LDS per workgroup (0: the query profile's own size): the scheduler pads the
        request to keep an odd number of workgroups from sharing a CU */
     int lds_bytes_min;
-    /* opal_hip_launch_stream only: start this many persistent workgroups fewer than the device has CUs (CUs left to a
-       class launch of long sequences running beside the stream on another hardware queue) */
-    int stream_blocks_reserved;
+    /* opal_hip_launch_stream, NW/HW/OV only: items [side_first_item, +side_num_items) (sequences too long for the skewed
+       arithmetic of the stream) run on the unskewed class body inside the same launch, ahead of the streaming workgroups */
+    int side_first_item, side_num_items;
 } OpalHipLaunch;
 
 /* ONE launch for up to three length classes of a search (plain 16-bit kernels): the bulk of the database on

@@ -315,7 +315,7 @@ __host__ __device__ inline int opal_profile_stride(int es, int G, int S, int pad
 // (the second launch bound asks the register allocator for 4 waves per SIMD, i.e. at most 128 VGPRs, on the single-launch
 // plain-16-bit kernels: OV at 38-39 rows per lane compiled to 129-131 registers without it, one wave per SIMD less)
 template <int WIDTH, int MODE, int FLAGS, int S>
-__device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls, const int blockId) {
+__device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls, const int blockId, const int activeWaves = 0) {
     using V = Vec<WIDTH>;
     using reg = typename V::reg;
     using elem = typename V::elem;
@@ -403,11 +403,14 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int slots = 64 >> log2G;
-    const int job = blockId * (int)(blockDim.x >> 6) + wave;
+    // (activeWaves: only the first few waves of a workgroup take work -- one per SIMD for the long sequences that run inside
+    // a streaming launch, stream_kernel.hpp; 0 = all of them)
+    const int wpbUsed = activeWaves ? activeWaves : (int)(blockDim.x >> 6);
+    const int job = blockId * wpbUsed + wave;
     const int k = lane & (G - 1);
     const int slot = lane >> log2G;
     const int itemIdx = job * slots + slot;
-    const bool valid = itemIdx < cls.numItems;
+    const bool valid = wave < wpbUsed && itemIdx < cls.numItems;
     // (idle slots and whole idle waves run the loop below with no columns of their own)
 
     int len[NH], seq[NH];

@@ -368,7 +368,6 @@ struct SearchCtx {
     int* dScore; int* dEndQ; int* dEndT;
     int satLimit, negPad;  // width 17 (plain 16-bit) parameters
     long long maxScore;    // largest matrix entry (>= 0)
-    void* onStream = nullptr;  // if set: every launch of this context goes to that stream, one after the other (no forking)
 };
 
 // Measured on MI355X (profiles/r01_ubench_*): packed-int16 and 32-bit max/min issue one wave
@@ -565,7 +564,7 @@ static void fill_launch(OpalHipLaunch& a, const SearchCtx& c, int width, int swE
     a.out_score = c.dScore; a.out_end_query = c.wantEnd ? c.dEndQ : nullptr; a.out_end_target = c.wantEnd ? c.dEndT : nullptr;
     a.overflow_count = ovfCounter; a.overflow_items = db->ovfItems.p;
     a.sat_limit = c.satLimit; a.neg_pad = c.negPad;
-    a.stream = c.onStream ? c.onStream : db->main();
+    a.stream = db->main();
 }
 
 // Queries that no single wave geometry can hold (more than 64 lanes x 40 rows, or a query profile
@@ -684,7 +683,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
     // The last class (the bulk of the database) runs on the main stream; the classes of long
     // sequences run beside it on up to three side streams (one hardware queue each), forked from and
     // joined back into the main stream with events, longest sequences enqueued first.
-    const int nside = c.onStream ? 0 : std::min<int>((int)classes.size() - 1, 3);
+    const int nside = std::min<int>((int)classes.size() - 1, 3);
     void* fork = nullptr;
     if (nside > 0) {
         fork = db->event(0);
@@ -1000,8 +999,8 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
         }
         // Long queries on large databases: the 16-bit part as a stream of sequences through persistent waves
         // (stream_kernel.hpp, diagonal-skewed kernels). The few sequences whose skewed values could leave 16 bits (the longest
-        // ones) run on the unskewed class kernels beside the stream; if they hold more than 2 % of the residues the class
-        // kernels run everything.
+        // ones) run on the unskewed class body in the first workgroups of the same launch; if they hold more than 2 % of the
+        // residues the class kernels run everything.
         StreamPlan gplan;
         int q32 = p32;  // pairs [p32, q32): 16-bit, but not safe for the skewed stream kernels -> class kernels beside the stream
         if (fits16 && p32 < P) {
@@ -1021,9 +1020,8 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
             fill_launch(a, c, gplan.width, 0, 0, nullptr, db->ovfCount.p);
             a.lanes_per_seq = gplan.G; a.rows_per_lane = gplan.rows; a.skew = 1;
             a.first_item = 2 * q32; a.num_items = 2 * (P - q32);
-            // leave CUs to the class launch of the skew-unsafe sequences (at most one wave each, 8 waves per workgroup): whichever
-            // of the two launches reaches the dispatcher first, both become resident
-            a.stream_blocks_reserved = std::min(64, (2 * (q32 - p32) + 7) / 8);
+            // the skew-unsafe sequences (the longest ones) ride along in the same launch on the unskewed class body
+            a.side_first_item = 2 * p32; a.side_num_items = 2 * (q32 - p32);
             if (debug_on())
                 fprintf(stderr, "[opal] streaming launch mode=%d width=%d G=%d rows=%d items=[%d,+%d)\n", mode, gplan.width, gplan.G, gplan.rows,
                         a.first_item, a.num_items);
@@ -1045,28 +1043,12 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
         if (nBad > 0) rc = OPAL_ERR_OVERFLOW;
         if (2 * p32 > nBad && launch_range(c, 32, 0, 0, nullptr, nBad, 2 * p32 - nBad, seqLenOf, db->ovfCount.p + 1))
             return OPAL_ERR_NO_SIMD_SUPPORT;
-        bool joinSide = false;
-        if (gplan.G && q32 > p32) {
-            // The skew-unsafe sequences (a handful of the longest ones, each a wave of its own for milliseconds) run BESIDE the
-            // streaming kernel, on a high-priority side stream and submitted first: they take ~3 ms of lone-wave time on a
-            // 2000-aa query, which one after the other would be a third of the search.
-            SearchCtx cs = c;
-            cs.onStream = db->stream(0);
-            void* fork = db->event(0);
-            if (!cs.onStream || !fork || opal_hip_event_record(fork, db->main()) || opal_hip_stream_wait_event(cs.onStream, fork))
-                return OPAL_ERR_NO_SIMD_SUPPORT;
-            const int e = narrow == 16 ? launch_range(cs, 16, 0, 0, nullptr, p32, q32 - p32, pairLenOf, db->ovfCount.p)
-                                       : launch_range(cs, narrow, 0, 0, nullptr, 2 * p32, 2 * (q32 - p32), seqLenOf, db->ovfCount.p);
-            if (e || opal_hip_event_record(db->event(1), cs.onStream)) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
-            joinSide = true;
-        }
         if (P > q32) {
             const int e = gplan.G ? launch_global_stream()
                         : narrow == 16 ? launch_range(c, 16, 0, 0, nullptr, p32, P - p32, pairLenOf, db->ovfCount.p)
                                        : launch_range(c, narrow, 0, 0, nullptr, 2 * p32, 2 * (P - p32), seqLenOf, db->ovfCount.p);
             if (e) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
         }
-        if (joinSide && opal_hip_stream_wait_event(db->main(), db->event(1))) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
     }
     if (evStop) opal_hip_event_record(evStop, st);
     if (opal_hip_stream_sync(st)) return OPAL_ERR_NO_SIMD_SUPPORT;

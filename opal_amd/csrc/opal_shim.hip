@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <set>
 #include <utility>
@@ -449,11 +450,16 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
     // persistent workgroups: one per CU (16 waves = 4 per SIMD), fewer when there are not enough sequences to go round
     const int perBlock = STREAM_WAVES * (64 / G);
     int blocks = (a->num_items + perBlock - 1) / perBlock;
-    const int avail = (a->stream_blocks_reserved > 0 && a->stream_blocks_reserved < cus) ? cus - a->stream_blocks_reserved : cus;
-    if (blocks > avail) blocks = avail;
+    if (blocks > cus) blocks = cus;
+    if (a->mode != MODE_SW && a->side_num_items > 0) {
+        const int perSide = STREAM_SIDE_WAVES * (64 / G);
+        sp.side = KClass{log2G, a->side_first_item, a->side_num_items, 0};
+        sp.sideBlocks = (a->side_num_items + perSide - 1) / perSide;
+        if (blocks + sp.sideBlocks > cus && blocks > 1) blocks = std::max(1, cus - sp.sideBlocks);  // every workgroup resident from the start
+    }
     if (const char* e = getenv("OPAL_HIP_STREAM_BLOCKS")) { const int b = atoi(e); if (b >= 1) blocks = b; }  // test hook
     if (lds > 64 * 1024 && raise_lds_limit((const void*)fn)) return 1;
-    hipLaunchKernelGGL(fn, dim3(blocks), dim3(STREAM_WAVES * 64), lds, (hipStream_t)a->stream, sp);
+    hipLaunchKernelGGL(fn, dim3(blocks + sp.sideBlocks), dim3(STREAM_WAVES * 64), lds, (hipStream_t)a->stream, sp);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("streaming kernel launch", e);
 }

@@ -24,7 +24,12 @@
 struct StreamParams {
     KParams base;  // work == nullptr; firstItem/numItems: the item range (pair*2+half); log2G: lanes per sequence
     int* next;     // device counter (zeroed before the launch): next item of the range to hand out
+    // NW/HW/OV only: the first `sideBlocks` workgroups of the grid run the UNSKEWED class body on the item range `side`
+    // (sequences too long for the skewed arithmetic), STREAM_SIDE_WAVES waves each; the streaming workgroups follow
+    KClass side;
+    int sideBlocks;
 };
+#define STREAM_SIDE_WAVES 4  // one wave per SIMD: these few sequences are the critical path, they run at the lone-wave rate
 typedef void (*StreamFn)(const StreamParams);
 
 #define STREAM_WAVES 16          // waves per (persistent) workgroup: 4 per SIMD at <= 128 registers
@@ -367,6 +372,16 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
     constexpr int LANE_BYTES = opal_lane_bytes(ES, S, WIDTH == 18);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const KParams& p = sp.base;
+    if ((int)blockIdx.x < sp.sideBlocks) {
+        // The sequences whose skewed values could leave 16 bits (the longest ones, a handful): the class body with plain
+        // arithmetic, in the same launch and ahead of the streaming workgroups in dispatch order. (As a separate launch on
+        // another stream they overlapped with the stream only when HIP happened to give the two streams different hardware
+        // queues: 9 ms or 13 ms per search from run to run.)
+        opal_dp_body<WIDTH, MODE, 0, S>(p, sp.side, (int)blockIdx.x, STREAM_SIDE_WAVES);
+        return;
+    }
+    const int streamBlock = (int)blockIdx.x - sp.sideBlocks;
+    (void)streamBlock;
 
     const int log2G = p.log2G;
     const int G = 1 << log2G;
@@ -620,11 +635,27 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
                     if (k == 0) { inV = INT_MIN; inRow = -1; }
                     if (lastc) {
                         int bv = INT_MIN, bj = -1;
+                        if (jlo == 0 && jhi == S) {
+                            // all my rows are query rows: compare in the skewed frame, moving the running best from the frame of
+                            // row j+1 to that of row j with one subtraction (4 full-rate instructions per row)
+                            reg bf = Hp[S - 1];
+                            bj = S - 1;
 #pragma unroll
-                        for (int j = S - 1; j >= 0; j--) {
-                            const int v = V::half(V::subs(Hp[j], V::adds(sRv, V::splat(j * Ge))), 0);
-                            if (j >= jlo && j < jhi && v >= bv) { bv = v; bj = j; }
-                            asm volatile("" : "+v"(bv), "+v"(bj));
+                            for (int j = S - 2; j >= 0; j--) {
+                                bf = V::subs(bf, Rv);
+                                const bool ge = (short)Hp[j] >= (short)bf;  // ties: the smaller row
+                                bf = ge ? Hp[j] : bf;
+                                bj = ge ? j : bj;
+                                asm volatile("" : "+v"(bf), "+v"(bj));
+                            }
+                            bv = V::half(V::subs(bf, sRv), 0);
+                        } else {
+#pragma unroll
+                            for (int j = S - 1; j >= 0; j--) {
+                                const int v = V::half(V::subs(Hp[j], V::adds(sRv, V::splat(j * Ge))), 0);
+                                if (j >= jlo && j < jhi && v >= bv) { bv = v; bj = j; }
+                                asm volatile("" : "+v"(bv), "+v"(bj));
+                            }
                         }
                         lcV = inV; lcRow = inRow;
                         if (bj >= 0 && bv > inV) { lcV = bv; lcRow = r0 + bj; }  // the lanes above hold smaller rows: they keep ties

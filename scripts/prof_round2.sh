@@ -3,7 +3,7 @@
 # Run on the GPU box from the repo root: scripts/prof_round2.sh <outdir-under-gpurun_out> [configs...]
 # The program goes directly after `--` (no env/bash hop: the profiler initialises the GPU before exec).
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
-CFGS=${@:-"c2 c2end c3nw c3hw c3ov c4 c5 w32"}
+CFGS=${@:-"c2 c2end c3nw c3hw c3ov c4 c5 c5end c5nw c5hw c5ov w32"}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B=$GRAFT_REPO_ROOT/bench.py
@@ -20,6 +20,10 @@ for c in $CFGS; do
     c3ov)  ARGS="--workload c3 --mode OV" ;;
     c4)    ARGS="--workload c4 --total-seqs 625000" ;;
     c5)    ARGS="--workload c5 --total-seqs 100000" ;;
+    c5end) ARGS="--workload c5 --total-seqs 100000 --search-type 1" ;;
+    c5nw)  ARGS="--workload c5 --total-seqs 100000 --search-type 1 --mode NW" ;;
+    c5hw)  ARGS="--workload c5 --total-seqs 100000 --search-type 1 --mode HW" ;;
+    c5ov)  ARGS="--workload c5 --total-seqs 100000 --search-type 1 --mode OV" ;;
     w32)   ARGS="--workload c2 --seqs 20000"; export OPAL_HIP_FORCE_WIDTH=32 ;;
   esac
   D=$OUT/$c; mkdir -p $D

@@ -559,8 +559,8 @@ def test_streaming_saturated_scores_rerun(narrow, ours, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("mode", ["NW", "HW", "OV"])
-@pytest.mark.parametrize("qlen,lanes,narrow", [(100, "4", "17"), (300, "8", "17"), (513, "16", "17"), (1000, "32", "17"), (1200, "64", "17"),
-                                               (1330, "64", "18"), (2000, "64", "18"), (2490, "64", "18")])
+@pytest.mark.parametrize("qlen,lanes,narrow", [(100, "4", "17"), (290, "8", "17"), (513, "16", "17"), (1000, "32", "17"), (1200, "64", "17"),
+                                               (1330, "64", "18"), (2000, "64", "18"), (2360, "64", "18")])
 def test_streaming_global_kernels(mode, qlen, lanes, narrow, ours, oracle, monkeypatch):
     """NW/HW/OV as a stream of sequences (boundary column reloaded from LDS at every sequence start, diagonal-skewed
     arithmetic with a local step per sequence), forced for every lanes-per-sequence value and both profile widths, with
@@ -577,7 +577,9 @@ def test_streaming_global_kernels(mode, qlen, lanes, narrow, ours, oracle, monke
     for blocks in ("", "1"):
         if blocks:
             monkeypatch.setenv("OPAL_HIP_STREAM_BLOCKS", blocks)
-        for go, ge, st in ((11, 1, 1), (3, 1, 1), (3, 1, 0)):
+        # (gaps 12/4: the 5000-residue sequence no longer fits the skewed arithmetic and runs on the unskewed class body inside
+        # the streaming launch, for the longer queries also at the smaller extension penalties)
+        for go, ge, st in ((11, 1, 1), (3, 1, 1), (3, 1, 0), (12, 4, 1)):
             got = ours.search(q, db, go, ge, m, st, MODES[mode])[:4]
             _check(got, oracle.search(q, db, go, ge, m, st, MODES[mode]), mode, f"stream {mode} q{qlen} G={lanes} w{narrow} gaps {go}/{ge} st={st} blocks={blocks or 'auto'}")
-    assert count() - before == 6
+    assert count() - before == 8
