@@ -50,6 +50,78 @@ __host__ __device__ inline size_t opal_stream_lds_bytes(int G, int S, int A) {
     return (size_t)(A + 3) * (size_t)opal_stream_stride<WIDTH>(G, S) + (size_t)STREAM_WAVES * (64 / G) * STREAM_RING * STREAM_DESC_BYTES;
 }
 
+
+// ---- the stream of one slot (slot-uniform values, kept by every lane of the slot) and its refill
+struct SlotStream {
+    int nEntries = 0;     // descriptors appended so far
+    int curStart = 0;     // stream position where the newest entry starts
+    int coveredEnd = 0;   // stream position where it ends (INT_MAX once the item range is exhausted)
+    int lastEnd = 0;      // end of the last real entry
+    bool done = false;
+    unsigned tokNext = 0, shiftNext = 0;  // token (or letter) of the position fetched last, and the shift that selects its byte
+};
+
+// Token of stream position x for lane k of a slot (x - k is a multiple of G; called by all lanes of the wave together):
+// appends the next item of the range to the slot's descriptor ring when the positions [x-k, x-k+G) are not covered yet
+// (one atomic on the device-wide counter per appended sequence), looks the position up in the newest two descriptors and
+// issues the token load, which is consumed a batch later. SEPS separator columns (letters PAD+1 .. PAD+SEPS) follow every
+// sequence; an entry spans at least 2G positions (pad columns after short sequences), which is what bounds the look-up
+// to two descriptors and the ring to four.
+// Descriptor: {start, len, caller index, byte shift, token offset lo, hi, item, running maximum (SW with end locations)}.
+template <int SEPS>
+__device__ __forceinline__ void stream_fetch(SlotStream& st, const KParams& p, int* next, int* ring, const int x, const int k,
+                                             const int G, const int slotLane0, const int PAD) {
+    const int base = x - k;
+    const bool need = !st.done && st.coveredEnd <= base + G - 1;  // slot-uniform
+    if (__ballot(need) != 0ull) {  // (wave-uniform branch, every lane inside: the broadcast below reads lane 0 of the slot)
+        int idx = 0;
+        if (need && k == 0) idx = atomicAdd(next, 1);
+        idx = __shfl(idx, slotLane0, 64);
+        if (need) {
+            if (idx < p.numItems) {
+                const int item = p.firstItem + idx;
+                const int pairIdx = item >> 1, half = item & 1;
+                int len = p.pairLen[item];
+                const int seq = p.pairSeq[item];
+                if (seq < 0) len = 0;
+                const uint64_t tb = p.pairOff[pairIdx];
+                const int span = max(len + SEPS, 2 * G);
+                if (k == 0) {
+                    int* e = ring + (st.nEntries & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4);
+                    e[0] = st.coveredEnd; e[1] = len; e[2] = seq; e[3] = half * 8;
+                    e[4] = (int)(unsigned)(tb & 0xffffffffu); e[5] = (int)(unsigned)(tb >> 32); e[6] = item; e[7] = 0;
+                }
+                st.curStart = st.coveredEnd;
+                st.coveredEnd += span;
+                st.lastEnd = st.coveredEnd;
+                st.nEntries++;
+            } else {
+                st.done = true;
+                st.coveredEnd = INT_MAX;
+            }
+        }
+        // ring writes by lane 0 of a slot are read by its other lanes below (same wave: LDS keeps program order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    unsigned tok = (unsigned)PAD, sh = 0;
+    if (st.nEntries > 0 && x < st.lastEnd) {
+        const int e = (x >= st.curStart) ? (st.nEntries - 1) : (st.nEntries - 2);
+        const int* d = ring + (e & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4);
+        const int4 d0 = *reinterpret_cast<const int4*>(d);
+        const int col = x - d0.x;
+        if (col < d0.y) {
+            const uint64_t tb = (uint64_t)(unsigned)d[4] | ((uint64_t)(unsigned)d[5] << 32);
+            tok = p.tokens[tb + (uint64_t)col];
+            sh = (unsigned)d0.w;
+        } else if (SEPS >= 1 && col == d0.y) tok = (unsigned)(PAD + 1);
+        else if (SEPS >= 2 && col == d0.y + 1) tok = (unsigned)(PAD + 2);
+    }
+    st.tokNext = tok;
+    st.shiftNext = sh;
+}
+
 template <int WIDTH, int S, bool SWEND = false>
 __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const StreamParams sp) {
     using V = Vec<WIDTH>;
@@ -127,12 +199,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     unsigned offv = padOff + (unsigned)(k * LANE_BYTES);
     unsigned tokq = padOff;
 
-    // ---- the stream of this slot (slot-uniform values, kept by every lane)
-    int nEntries = 0;          // descriptors appended so far
-    int curStart = 0;          // stream position where the newest entry starts
-    int coveredEnd = 0;        // stream position where it ends (INT_MAX once the item range is exhausted)
-    int lastEnd = 0;           // end of the last real entry
-    bool done = false;
+    SlotStream st;  // the stream of this slot
     int flushCount = 0;        // entries this lane has seen the end of (the last lane: whose score has been written)
     // SWEND: where my running maximum was first reached (column within the sequence, query row), the stream position at
     // which my current sequence starts, and what the lane below reads: the maximum over the lanes above and me for the
@@ -142,68 +209,16 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     int outCol = INT_MAX, outRow = -1;
     const int r0 = k * S - padTop;  // query row held in register 0
 
-    // token of stream position x (x - k is a multiple of G): descriptor lookup, then a load that is consumed a batch later
-    unsigned tokNext = 0, shiftNext = 0;
-    auto fetch = [&](const int x) {
-        const int base = x - k;
-        const bool need = !done && coveredEnd <= base + G - 1;  // slot-uniform
-        if (__ballot(need) != 0ull) {  // (wave-uniform branch, every lane inside: the broadcast below reads lane 0 of the slot)
-            int idx = 0;
-            if (need && k == 0) idx = atomicAdd(sp.next, 1);
-            idx = __shfl(idx, slotLane0, 64);
-            if (need) {
-                if (idx < p.numItems) {
-                    const int item = p.firstItem + idx;
-                    const int pairIdx = item >> 1, half = item & 1;
-                    int len = p.pairLen[item];
-                    const int seq = p.pairSeq[item];
-                    if (seq < 0) len = 0;
-                    const uint64_t tb = p.pairOff[pairIdx];
-                    const int span = max(len + 2, 2 * G);  // >= 2G: a refill never looks beyond the newest two entries
-                    if (k == 0) {
-                        int* e = ring + (nEntries & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4);
-                        e[0] = coveredEnd; e[1] = len; e[2] = seq; e[3] = half * 8;
-                        e[4] = (int)(unsigned)(tb & 0xffffffffu); e[5] = (int)(unsigned)(tb >> 32); e[6] = item; e[7] = 0;
-                    }
-                    curStart = coveredEnd;
-                    coveredEnd += span;
-                    lastEnd = coveredEnd;
-                    nEntries++;
-                } else {
-                    done = true;
-                    coveredEnd = INT_MAX;
-                }
-            }
-            // ring writes by lane 0 of a slot are read by its other lanes below (same wave: LDS keeps program order)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-        unsigned tok = (unsigned)PAD, sh = 0;
-        if (nEntries > 0 && x < lastEnd) {
-            const int e = (x >= curStart) ? (nEntries - 1) : (nEntries - 2);
-            const int* d = ring + (e & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4);
-            const int4 d0 = *reinterpret_cast<const int4*>(d);
-            const int col = x - d0.x;
-            if (col < d0.y) {
-                const uint64_t tb = (uint64_t)(unsigned)d[4] | ((uint64_t)(unsigned)d[5] << 32);
-                tok = p.tokens[tb + (uint64_t)col];
-                sh = (unsigned)d0.w;
-            } else if (col == d0.y) tok = (unsigned)SEP1;
-            else if (col == d0.y + 1) tok = (unsigned)SEP2;
-        }
-        tokNext = tok;
-        shiftNext = sh;
-    };
+    auto fetch = [&](const int x) { stream_fetch<2>(st, p, sp.next, ring, x, k, G, slotLane0, PAD); };
     fetch(k);
 
     for (int s = 0;; s++) {
         if ((s & (G - 1)) == 0) {  // wave-uniform: refill the queue with columns s .. s+G-1, fetch those of the next batch
-            const unsigned letter = (tokNext >> shiftNext) & 0xffu;
+            const unsigned letter = (st.tokNext >> st.shiftNext) & 0xffu;
             fetch(s + G + k);
             tokq = ldsBase + letter * (unsigned)stride;
             // every slot has run dry and its last separator has left the last lane
-            if (__ballot(!(done && s >= lastEnd + G)) == 0ull) break;
+            if (__ballot(!(st.done && s >= st.lastEnd + G)) == 0ull) break;
         }
         reg inH = (reg)shr1((unsigned)outH);
         reg inF = (reg)shr1((unsigned)outF);
@@ -468,78 +483,27 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
     jlo = jlo < 0 ? 0 : (jlo > S ? S : jlo);
     jhi = jhi < 0 ? 0 : (jhi > S ? S : jhi);
 
-    // ---- the stream of this slot
-    int nEntries = 0, curStart = 0, coveredEnd = 0, lastEnd = 0;
-    bool done = false;
+    SlotStream st;  // the stream of this slot
     int started = 0;                    // entries this lane has begun
     int myStart = 0, myLen = 0, myNext = 0;  // my current sequence: first stream position, length; where my next one begins
     int best = INT_MIN, bestCol = -1, prevBest = INT_MIN;  // HW/OV (last lane): last-row maximum, its first column; OV: before the last column
     int outLcV = INT_MIN, outLcRow = -1;                    // OV: last-column maximum handed down the lanes
 
-    unsigned tokNext = 0, shiftNext = 0;
-    auto fetch = [&](const int x) {
-        const int base = x - k;
-        const bool need = !done && coveredEnd <= base + G - 1;
-        if (__ballot(need) != 0ull) {
-            int idx = 0;
-            if (need && k == 0) idx = atomicAdd(sp.next, 1);
-            idx = __shfl(idx, slotLane0, 64);
-            if (need) {
-                if (idx < p.numItems) {
-                    const int item = p.firstItem + idx;
-                    const int pairIdx = item >> 1, half = item & 1;
-                    int len = p.pairLen[item];
-                    const int seq = p.pairSeq[item];
-                    if (seq < 0) len = 0;
-                    const uint64_t tb = p.pairOff[pairIdx];
-                    const int span = max(len, 2 * G);
-                    if (k == 0) {
-                        int* e = ring + (nEntries & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4);
-                        e[0] = coveredEnd; e[1] = len; e[2] = seq; e[3] = half * 8;
-                        e[4] = (int)(unsigned)(tb & 0xffffffffu); e[5] = (int)(unsigned)(tb >> 32); e[6] = item; e[7] = 0;
-                    }
-                    curStart = coveredEnd;
-                    coveredEnd += span;
-                    lastEnd = coveredEnd;
-                    nEntries++;
-                } else {
-                    done = true;
-                    coveredEnd = INT_MAX;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-        unsigned tok = (unsigned)PAD, sh = 0;
-        if (nEntries > 0 && x < lastEnd) {
-            const int e = (x >= curStart) ? (nEntries - 1) : (nEntries - 2);
-            const int* d = ring + (e & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4);
-            const int4 d0 = *reinterpret_cast<const int4*>(d);
-            const int col = x - d0.x;
-            if (col < d0.y) {
-                const uint64_t tb = (uint64_t)(unsigned)d[4] | ((uint64_t)(unsigned)d[5] << 32);
-                tok = p.tokens[tb + (uint64_t)col];
-                sh = (unsigned)d0.w;
-            }
-        }
-        tokNext = tok;
-        shiftNext = sh;
-    };
+    auto fetch = [&](const int x) { stream_fetch<0>(st, p, sp.next, ring, x, k, G, slotLane0, PAD); };
     fetch(k);
 
     for (int s = 0;; s++) {
         if ((s & (G - 1)) == 0) {
-            const unsigned letter = (tokNext >> shiftNext) & 0xffu;
+            const unsigned letter = (st.tokNext >> st.shiftNext) & 0xffu;
             fetch(s + G + k);
             tokq = ldsBase + letter * (unsigned)stride;
-            if (__ballot(!(done && s >= lastEnd + G)) == 0ull) break;
+            if (__ballot(!(st.done && s >= st.lastEnd + G)) == 0ull) break;
         }
         const int x = s - k;  // my stream position
         // ---- first column of my next sequence: reload the boundary column
         if (__ballot(x == myNext) != 0ull) {
             if (x == myNext) {
-                if (started < nEntries) {
+                if (started < st.nEntries) {
                     const int4 d0 = *reinterpret_cast<const int4*>(ring + (started & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4));
                     myStart = d0.x;  // == myNext
                     myLen = d0.y;
