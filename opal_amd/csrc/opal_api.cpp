@@ -594,6 +594,14 @@ static int launch_chunked(const SearchCtx& c, int width, int swEndPass, int dete
         return OPAL_ERR_NO_SIMD_SUPPORT;
     int wpb = 4, ldsPad = 0;
     pick_occupancy(kernel_vgprs(width, c.mode, swEndPass, 1, 0, bestS), opal_hip_lds_bytes(width, bestG, bestS, c.A), &wpb, &ldsPad);
+    // Equal chunks: with nchunks passes needed anyway, the smallest rows-per-lane value that still covers Q in that many
+    // passes (a 3000-aa query ran as 440 + 2560 rows at 40 rows per lane, 2 900 GCUPS; as 2 x 1500 at 24 rows per lane ...)
+    if (!getenv("OPAL_HIP_CHUNK_GEOMETRY")) {
+        const int passes = (c.Q + bestG * bestS - 1) / (bestG * bestS);
+        const int need = ((c.Q + passes - 1) / passes + bestG - 1) / bestG;  // rows per lane of a balanced chunk
+        const int rows = opal_hip_rows_supported(width, c.mode, swEndPass | 2, need);
+        if (rows && rows < bestS) bestS = rows;
+    }
     const int cap = bestG * bestS;
     const int nchunks = (c.Q + cap - 1) / cap;
     const int firstRows = c.Q - (nchunks - 1) * cap;  // SW/HW/OV: the partial chunk is the first one
