@@ -1,23 +1,29 @@
-// stream_kernel.hpp -- gfx950: Smith-Waterman score search for LONG queries as a streaming systolic array.
+// stream_kernel.hpp -- gfx950: the database search as a STREAM of sequences through persistent waves.
 //
-// Role: the same as dp_kernel.hpp's SW kernels (reference src/opal.cpp:164-470 searchDatabaseSW_ with
-// loadNextSequence :472-490), for queries that need 32 or 64 lanes per sequence. There the class kernels lose
+// Role: the same as dp_kernel.hpp's kernels (reference src/opal.cpp:164-470 searchDatabaseSW_, :594-977 searchDatabase_,
+// with loadNextSequence :472-490 -- the reference, too, hands a lane its next sequence as soon as the previous one ends),
+// for searches in which every group of lanes sees many sequences: long queries (32 or 64 lanes per sequence) in all four
+// modes, SW score searches of large databases at any query length. The class kernels of dp_kernel.hpp lose
 // (G-1)/(L+G-1) of their steps to filling and draining the lane pipeline for every sequence (18 % at G = 64 on a
 // 350-residue database) and restage a ~100 KB query profile for every 16 sequences with nothing else resident on
 // the CU. Here
 //   * workgroups are PERSISTENT: one per CU, 16 waves, the profile is staged once;
 //   * every slot (G lanes) works through a STREAM of sequences handed out by a device-wide counter (longest
 //     first, so the slots finish together), the next sequence entering lane 0 while the previous one is still
-//     draining through the upper lanes: no fill/drain between sequences, no tail of half-empty workgroups;
-//   * sequences are separated by two separator columns whose "letters" carry gap penalties of 0xFFFF: the unsigned
-//     saturating subtractions of the SW row block (E = max(E -sat Ge, H -sat Go)) then zero E and F in the first
-//     column and H in the second (profile value -32768), which is exactly the state a new sequence starts from --
-//     no register is reset by hand and no step is special-cased. The gap operands therefore live in VGPRs, loaded
-//     per step from a 16-byte info block that sits behind each letter's profile row in LDS;
-//   * a slot's score is the maximum over its lanes' running maxima, collected at the second separator column as
-//     it passes down the lanes (one DPP move per separator step) and written by the last lane.
+//     draining through the upper lanes: no fill/drain between sequences, no tail of half-empty workgroups
+//     (SlotStream / stream_fetch: the descriptor ring of a slot and its refill);
+//   * SW (opal_sw_stream): sequences are separated by two separator columns whose "letters" carry gap penalties of
+//     0xFFFF: the unsigned saturating subtractions of the SW row block (E = max(E -sat Ge, H -sat Go)) then zero E and F
+//     in the first column and H in the second (profile value -32768), which is exactly the state a new sequence starts
+//     from -- no register is reset by hand and no step is special-cased. The gap operands therefore live in VGPRs, loaded
+//     per step from a 16-byte info block that sits behind each letter's profile row in LDS. A slot's score is the
+//     maximum over its lanes' running maxima, collected at the second separator column as it passes down the lanes
+//     (one DPP move per separator step) and written by the last lane; with end locations the best cell travels the
+//     same way;
+//   * NW/HW/OV (opal_gl_stream, further down): diagonal-skewed arithmetic with a per-sequence local step, the boundary
+//     column reloaded from LDS at every sequence start.
 // Plain 16-bit arithmetic (Vec<17>: 4-byte profile entries, Vec<18>: 2-byte entries for queries beyond ~1400
-// residues), scores at the saturation limit go to the 32-bit re-run list like everywhere else.
+// residues); SW scores at the saturation limit go to the 32-bit re-run list like everywhere else.
 #pragma once
 #include "dp_kernel.hpp"
 
