@@ -185,6 +185,29 @@ typedef struct OpalHipRevLaunch {
 int opal_hip_rev_rows_supported(int query_length);
 int opal_hip_rev_launch(const OpalHipRevLaunch* args);
 
+/* Alignment operations on the device (trace_kernel.hip): for every listed sequence, the traceback of reference
+   src/opal.cpp:1369-1409 inside the box between its start and end cells. All pointers are device pointers. */
+typedef struct OpalHipTraceLaunch {
+    const unsigned char* query; int alphabet_length;
+    const int* score_matrix;
+    int gap_open, gap_ext;
+    const uint16_t* tokens; const uint64_t* pair_token_offset;
+    const int* seq_item;           /* [N] caller index -> pair*2 + half in the packed database */
+    const int* items; int num_items;    /* caller indices of this batch */
+    int max_rows;                  /* largest number of box rows (endQ - startQ + 1) in the batch */
+    const int* end_query; const int* end_target; const int* start_query; const int* start_target;   /* [N], caller order */
+    const uint64_t* dir_offset;    /* [num_items] start of each flag matrix in `dirs`: columns x (rows rounded up to 4) bytes */
+    unsigned char* dirs;
+    const uint64_t* ops_offset;    /* [num_items] start of each operation string in `ops` (capacity rows + columns) */
+    unsigned char* ops;
+    int* ops_length;               /* [num_items] out */
+    int* box_score;                /* [num_items] out: must equal the alignment's score */
+    void* stream;
+} OpalHipTraceLaunch;
+/* rows per lane the trace kernel would use for boxes of up to `rows` rows (0: more than 64 x 40, unsupported) */
+int opal_hip_trace_rows_supported(int rows);
+int opal_hip_trace_launch(const OpalHipTraceLaunch* args);
+
 /* ------------------------------------------------------------------ part 2 */
 
 typedef struct OpalxDb OpalxDb; /* opaque: packed database resident in device memory */
@@ -241,6 +264,11 @@ int opalx_find_alignments(unsigned char query[], int query_length, unsigned char
 int opalx_find_alignments_from(unsigned char query[], int query_length, unsigned char* db[], int db_length,
                                int db_seq_lengths[], int gap_open, int gap_ext, int* score_matrix, int alphabet_length,
                                struct OpalSearchResult* results[], int mode, const int* start_query, const int* start_target);
+/* The same, skipping the results i with skip[i] != 0 (e.g. already traced on the device); skip may be NULL. */
+int opalx_find_alignments_masked(unsigned char query[], int query_length, unsigned char* db[], int db_length,
+                                 int db_seq_lengths[], int gap_open, int gap_ext, int* score_matrix, int alphabet_length,
+                                 struct OpalSearchResult* results[], int mode, const int* start_query, const int* start_target,
+                                 const unsigned char* skip);
 
 /*
  * Start locations of alignments, computed on the device (rev_kernel.hip; reference src/opal.cpp:1475-1507):

@@ -178,6 +178,10 @@ struct OpalxDb {
     bool seqItemValid = false;
     DevBuf<int> revFlags;
     DevBuf<int> redo;
+    // alignment operations on the device (trace_kernel.hip): flag matrices, operation strings, per-batch lists and outputs
+    DevBuf<unsigned char> trDirs, trOps;
+    DevBuf<uint64_t> trOff;
+    DevBuf<int> trItems, trOut;
     // launch plans of this database, keyed by what they depend on (cleared when the database is refilled): a search
     // with the same query length, alphabet and mode re-uses the class split instead of recomputing it with the GPU idle
     std::map<std::string, std::vector<int>> planCache;
@@ -238,6 +242,7 @@ static void db_release(OpalxDb* db) {
     db->results.release(); db->quads.release();
     db->ovfCount.p = nullptr; db->matrix.p = nullptr; db->query.p = nullptr;
     db->seqItem.release(); db->revFlags.release(); db->redo.release();
+    db->trDirs.release(); db->trOps.release(); db->trOff.release(); db->trItems.release(); db->trOut.release();
     db->raw.release(); db->rawOff.release(); db->hRaw.release(); db->hResults.release();
     for (void*& st : db->streams) { opal_hip_stream_destroy(st); st = nullptr; }
     opal_hip_stream_destroy(db->mainStream); db->mainStream = nullptr;
@@ -1108,6 +1113,99 @@ static int search_starts(OpalxDb* db, const unsigned char* query, int Q, int Go,
     return 0;
 }
 
+// Operations traced on the device, by position in the shard: ops[off[i] .. +len[i]), or len[i] < 0 (not traced: the host does it).
+struct TraceOut {
+    std::vector<unsigned char> ops;
+    std::vector<uint64_t> off;
+    std::vector<int> len;
+};
+
+/*
+ * Alignment operations on the device (trace_kernel.hip) for every sequence of the shard whose score, end cell and start
+ * cell are known: the box between start and end is computed with one byte of flags per cell in HBM and walked back there;
+ * only the operation strings come to the host. Batches are bounded by OPAL_TRACEBACK_DEVICE_BYTES of flags (default
+ * 8 GiB). Whatever is left out (no start cell, SW score 0, boxes of more than 2560 rows, a box larger than the budget, any
+ * failure) keeps len < 0 and is traced by the host as before. `dEndQ` .. `dStartT` are the device arrays in caller
+ * (= shard) order the search and the start-location pass have filled; the host arrays hold the same values.
+ */
+static void device_traceback(OpalxDb* db, int Q, int Go, int Ge, int A, int mode, int n, const int* score, const int* endQ,
+                             const int* endT, const int* startQ, const int* startT, const int* dEndQ, const int* dEndT,
+                             const int* dStartQ, const int* dStartT, TraceOut& out) {
+    out.len.assign((size_t)n, -1);
+    out.off.assign((size_t)n, 0);
+    out.ops.clear();
+    if (getenv("OPAL_HIP_HOST_TRACEBACK") || !db->seqItemValid || n <= 0) return;
+    uint64_t budget = 8ull << 30;
+    if (const char* e = getenv("OPAL_TRACEBACK_DEVICE_BYTES")) { const long long v = atoll(e); if (v > 0) budget = (uint64_t)v; }
+    void* st = db->main();
+    std::vector<int> items;
+    std::vector<uint64_t> offs;  // [2 * batch]: flag-matrix offsets, then operation offsets
+    const double t0 = now_ms();
+    int traced = 0, batches = 0;
+    int i = 0;
+    while (i < n) {
+        items.clear(); offs.clear();
+        std::vector<uint64_t> dirOff, opsOff;
+        uint64_t dirBytes = 0, opsBytes = 0;
+        int maxRows = 0;
+        for (; i < n; i++) {
+            if (score[i] == INT_MIN || (mode == OPAL_MODE_SW && score[i] == 0)) continue;
+            if (endQ[i] < 0 || endT[i] < 0 || startQ[i] < 0 || startT[i] < 0 || startQ[i] > endQ[i] || startT[i] > endT[i]) continue;
+            const int bq = endQ[i] - startQ[i] + 1, bt = endT[i] - startT[i] + 1;
+            if (bq > Q || !opal_hip_trace_rows_supported(bq)) continue;
+            const uint64_t bytes = (uint64_t)((bq + 3) & ~3) * (uint64_t)bt;
+            if (bytes > budget) continue;                          // a box of its own: the host's job
+            if (dirBytes + bytes > budget && !items.empty()) break;  // next batch
+            items.push_back(i);
+            dirOff.push_back(dirBytes); opsOff.push_back(opsBytes);
+            dirBytes += (bytes + 15) & ~15ull;
+            opsBytes += (uint64_t)(bq + bt);
+            maxRows = std::max(maxRows, bq);
+        }
+        const size_t m = items.size();
+        if (!m) break;
+        offs = dirOff;
+        offs.insert(offs.end(), opsOff.begin(), opsOff.end());
+        bool ok = db->trDirs.ensure((size_t)dirBytes + 16) && db->trOps.ensure((size_t)opsBytes + 16) && db->trOff.ensure(2 * m, 1.25) &&
+                  db->trItems.ensure(m, 1.25) && db->trOut.ensure(2 * m, 1.25);
+        ok = ok && !opal_hip_memcpy_h2d(db->trItems.p, items.data(), m * sizeof(int), st) &&
+             !opal_hip_memcpy_h2d(db->trOff.p, offs.data(), 2 * m * sizeof(uint64_t), st);
+        std::vector<int> res(2 * m);
+        std::vector<unsigned char> ops((size_t)opsBytes);
+        if (ok) {
+            OpalHipTraceLaunch a;
+            memset(&a, 0, sizeof a);
+            a.query = db->query.p; a.alphabet_length = A; a.score_matrix = db->matrix.p; a.gap_open = Go; a.gap_ext = Ge;
+            a.tokens = db->tokens.p; a.pair_token_offset = db->pairOff.p; a.seq_item = db->seqItem.p;
+            a.items = db->trItems.p; a.num_items = (int)m; a.max_rows = maxRows;
+            a.end_query = dEndQ; a.end_target = dEndT; a.start_query = dStartQ; a.start_target = dStartT;
+            a.dir_offset = db->trOff.p; a.dirs = db->trDirs.p; a.ops_offset = db->trOff.p + m; a.ops = db->trOps.p;
+            a.ops_length = db->trOut.p; a.box_score = db->trOut.p + m;
+            a.stream = st;
+            ok = !opal_hip_memset32(db->trOut.p, INT_MIN, 2 * m, st) && !opal_hip_trace_launch(&a) &&
+                 !opal_hip_memcpy_d2h(res.data(), db->trOut.p, 2 * m * sizeof(int), st) &&
+                 !opal_hip_memcpy_d2h(ops.data(), db->trOps.p, (size_t)opsBytes, st) && !opal_hip_stream_sync(st);
+        }
+        if (!ok) {  // nothing of this batch is trusted; the host traces it
+            db->quiesce();
+            if (debug_on()) fprintf(stderr, "[opal] device traceback: batch of %zu failed (%s); host traceback instead\n", m, opal_hip_last_error());
+            continue;
+        }
+        batches++;
+        for (size_t b = 0; b < m; b++) {
+            const int idx = items[b];
+            const int len = res[b], bs = res[m + b];
+            const int cap = (endQ[idx] - startQ[idx] + 1) + (endT[idx] - startT[idx] + 1);
+            if (bs != score[idx] || len <= 0 || len > cap) continue;  // the box does not carry the score: the host's full pass decides
+            out.off[(size_t)idx] = out.ops.size();
+            out.len[(size_t)idx] = len;
+            out.ops.insert(out.ops.end(), ops.begin() + (size_t)opsOff[b], ops.begin() + (size_t)opsOff[b] + len);
+            traced++;
+        }
+    }
+    if (debug_on()) fprintf(stderr, "[opal] device traceback: %d of %d alignments in %d batches, %.2f ms\n", traced, n, batches, now_ms() - t0);
+}
+
 // ------------------------------------------------------------------------------------ devices of a call
 // OPAL_HIP_DEVICES = "all" | "0,1,2,..." makes opalSearchDatabase shard every call over those GPUs. A device
 // may be listed more than once (two contexts on one GPU): that is how the sharding is tested on a one-GPU box.
@@ -1173,7 +1271,7 @@ static std::vector<std::vector<int>> deal_groups(const int* lens, int n, int par
  */
 static int run_shard(int device, const unsigned char* query, int Q, unsigned char* const* db, const int* dbLens, const int* ids,
                      int n, int Go, int Ge, const int* M, int A, int searchType, int mode, int* score, int* endQ, int* endT,
-                     double* tms, int* startQ = nullptr, int* startT = nullptr) {
+                     double* tms, int* startQ = nullptr, int* startT = nullptr, TraceOut* trace = nullptr) {
     BorrowedContext ctx(device);
     OpalxDb* pdb = ctx.db;
     if (!pdb) return OPAL_ERR_NO_SIMD_SUPPORT;
@@ -1222,6 +1320,8 @@ static int run_shard(int device, const unsigned char* query, int Q, unsigned cha
         } else {
             for (int i = 0; i < n; i++) { startQ[i] = INT_MIN; startT[i] = INT_MIN; }
         }
+        // the operations themselves, while database, query and end/start cells are still on the device
+        if (trace && haveStarts) device_traceback(pdb, Q, Go, Ge, A, mode, n, score, endQ, endT, startQ, startT, dQ, dT, dS + 3 * nn, dS + 4 * nn, *trace);
     }
     if (tms) { tms[0] += t1 - t0; tms[1] += t2 - t1; tms[2] += t3 - t2; tms[3] += now_ms() - t3; }
     return rc;
@@ -1395,7 +1495,7 @@ static bool collect_todo(OpalSearchResult* results[], int n, int searchType, std
 // computed ({startQ[dbLength], startT[dbLength]}, INT_MIN = unknown).
 static int search_into_results(unsigned char query[], int Q, unsigned char* db[], int dbLength, int dbSeqLengths[], int Go, int Ge,
                                int* M, int A, OpalSearchResult* results[], int searchType, int mode, bool clearAlignment,
-                               int* starts) {
+                               int* starts, unsigned char* traced = nullptr) {
     const double tA = now_ms();
     std::vector<int> todo;
     const bool all = collect_todo(results, dbLength, searchType, todo);
@@ -1414,10 +1514,14 @@ static int search_into_results(unsigned char query[], int Q, unsigned char* db[]
         int* score = buf.get(); int* endQ = score + n; int* endT = score + 2 * (size_t)n;
         int* startQ = starts ? score + 3 * (size_t)n : nullptr; int* startT = starts ? score + 4 * (size_t)n : nullptr;
         std::vector<int> devices = call_devices();
+        // alignment search: operation strings traced on the device, per shard (positions of a shard in the to-do list: tracePos)
+        std::vector<TraceOut> traces(std::max<size_t>(devices.size(), 1));
+        std::vector<std::vector<int>> tracePos;
         if (devices.size() <= 1 || n < 2 * 64) {
             if (devices.size() == 1 && opal_hip_set_device(devices[0])) return OPAL_ERR_NO_SIMD_SUPPORT;
             rc = run_shard(opal_hip_get_device(), query, Q, db, dbSeqLengths, ids, n, Go, Ge, M, A, st, mode, score, endQ, endT, tms,
-                           startQ, startT);
+                           startQ, startT, traced ? &traces[0] : nullptr);
+            tracePos.resize(1);  // (identity: shard position = position in the to-do list)
         } else {
             // several GPUs: deal 64-sequence groups balancing the residue count, one host thread per GPU, each
             // running the single-GPU pipeline on its shard; the host is the gather root (results live in host structs)
@@ -1441,7 +1545,7 @@ static int search_into_results(unsigned char query[], int Q, unsigned char* db[]
                     int* s = out[k].data();
                     rcs[k] = run_shard(devices[k], query, Q, db, dbSeqLengths, sid.data(), m, Go, Ge, M, A, st, mode, s, s + m,
                                        s + 2 * (size_t)m, nullptr, starts ? s + 3 * (size_t)m : nullptr,
-                                       starts ? s + 4 * (size_t)m : nullptr);
+                                       starts ? s + 4 * (size_t)m : nullptr, traced ? &traces[k] : nullptr);
                 });
             }
             for (auto& th : threads) th.join();
@@ -1458,6 +1562,7 @@ static int search_into_results(unsigned char query[], int Q, unsigned char* db[]
                     if (starts) { startQ[p] = out[k][3 * (size_t)m + i]; startT[p] = out[k][4 * (size_t)m + i]; }
                 }
             }
+            tracePos = shard;
         }
         tC = now_ms();
         if (rc == OPAL_ERR_NO_SIMD_SUPPORT || rc == OPAL_ERR_INVALID_MODE) return rc;
@@ -1480,6 +1585,33 @@ static int search_into_results(unsigned char query[], int Q, unsigned char* db[]
                 if (starts) { starts[ids ? ids[i] : i] = startQ[i]; starts[(size_t)dbLength + (ids ? ids[i] : i)] = startT[i]; }
             }
         });
+        // alignments traced on the device: start cell and operations into the result structs (`alignment` is malloc()ed: the
+        // caller free()s it, opal.h); whatever is not marked in `traced` is left to the host traceback
+        if (traced && rc == 0) {
+            for (size_t k = 0; k < traces.size() && k < tracePos.size(); k++) {
+                const TraceOut& tr = traces[k];
+                const int m = (int)tr.len.size();
+                const std::vector<int>& pos = tracePos[k];
+                pool.parallel_for(std::max(1, std::min(pool.width(), m / 256)), [&](int t) {
+                    const int parts = std::max(1, std::min(pool.width(), m / 256));
+                    const int i0 = (int)((long long)m * t / parts), i1 = (int)((long long)m * (t + 1) / parts);
+                    for (int i = i0; i < i1; i++) {
+                        if (tr.len[(size_t)i] <= 0) continue;
+                        const int p = pos.empty() ? i : pos[(size_t)i];  // position in the to-do list
+                        const int caller = ids ? ids[p] : p;
+                        unsigned char* a = (unsigned char*)malloc((size_t)tr.len[(size_t)i]);
+                        if (!a) continue;  // the host traceback will try (and report) instead
+                        memcpy(a, tr.ops.data() + tr.off[(size_t)i], (size_t)tr.len[(size_t)i]);
+                        OpalSearchResult* r = results[caller];
+                        r->startLocationQuery = startQ[p];
+                        r->startLocationTarget = startT[p];
+                        r->alignment = a;
+                        r->alignmentLength = tr.len[(size_t)i];
+                        traced[caller] = 1;
+                    }
+                });
+            }
+        }
         if (debug_on())
             fprintf(stderr, "[opal] opalSearchDatabase: todo %.2f ms | order %.2f, gather+upload+pack %.2f, search %.2f, download %.2f | "
                     "scatter %.2f ms\n", tB - tA, tms[0], tms[1], tms[2], tms[3], now_ms() - tC);
@@ -1510,16 +1642,24 @@ extern "C" int opalSearchDatabase(unsigned char query[], int queryLength, unsign
     // traces the operations inside each (start..end) box. Sequences whose score/end the caller supplied (not
     // recomputed here, opal.h:118-122) have no device start: the host pass finds theirs.
     std::vector<int> starts;
-    if (searchType == OPAL_SEARCH_ALIGNMENT) starts.assign(2 * (size_t)std::max(dbLength, 1), INT_MIN);
+    std::vector<unsigned char> traced;  // alignments the device has already traced (trace_kernel.hip)
+    if (searchType == OPAL_SEARCH_ALIGNMENT) {
+        starts.assign(2 * (size_t)std::max(dbLength, 1), INT_MIN);
+        traced.assign((size_t)std::max(dbLength, 1), 0);
+    }
     const int rc = search_into_results(query, queryLength, db, dbLength, dbSeqLengths, gapOpen, gapExt, scoreMatrix,
                                        alphabetLength, results, searchType, mode, searchType != OPAL_SEARCH_ALIGNMENT,
-                                       searchType == OPAL_SEARCH_ALIGNMENT ? starts.data() : nullptr);
+                                       searchType == OPAL_SEARCH_ALIGNMENT ? starts.data() : nullptr,
+                                       searchType == OPAL_SEARCH_ALIGNMENT ? traced.data() : nullptr);
     if (rc) return rc;
     if (searchType == OPAL_SEARCH_ALIGNMENT) {
         const double t0 = now_ms();
-        const int arc = opalx_find_alignments_from(query, queryLength, db, dbLength, dbSeqLengths, gapOpen, gapExt, scoreMatrix,
-                                                   alphabetLength, results, mode, starts.data(), starts.data() + dbLength);
-        if (debug_on()) fprintf(stderr, "[opal] host traceback of %d alignments: %.2f ms\n", dbLength, now_ms() - t0);
+        int left = 0;
+        for (int i = 0; i < dbLength; i++) left += traced[(size_t)i] ? 0 : 1;
+        const int arc = left ? opalx_find_alignments_masked(query, queryLength, db, dbLength, dbSeqLengths, gapOpen, gapExt, scoreMatrix,
+                                                            alphabetLength, results, mode, starts.data(), starts.data() + dbLength, traced.data())
+                             : 0;
+        if (debug_on()) fprintf(stderr, "[opal] host traceback of %d of %d alignments: %.2f ms\n", left, dbLength, now_ms() - t0);
         return arc;
     }
     return 0;

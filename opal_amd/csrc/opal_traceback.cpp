@@ -214,9 +214,10 @@ static void align_one(const unsigned char* rQuery, int queryLength, const unsign
 
 }  // namespace
 
-extern "C" int opalx_find_alignments_from(unsigned char query[], int queryLength, unsigned char* db[], int dbLength,
-                                          int dbSeqLengths[], int gapOpen, int gapExt, int* scoreMatrix, int alphabetLength,
-                                          OpalSearchResult* results[], int mode, const int* startQuery, const int* startTarget) {
+extern "C" int opalx_find_alignments_masked(unsigned char query[], int queryLength, unsigned char* db[], int dbLength,
+                                            int dbSeqLengths[], int gapOpen, int gapExt, int* scoreMatrix, int alphabetLength,
+                                            OpalSearchResult* results[], int mode, const int* startQuery, const int* startTarget,
+                                            const unsigned char* skip) {
     (void)dbSeqLengths;
     std::vector<unsigned char> rQuery((size_t)std::max(queryLength, 1));
     for (int i = 0; i < queryLength; i++) rQuery[i] = query[queryLength - 1 - i];
@@ -238,6 +239,7 @@ extern "C" int opalx_find_alignments_from(unsigned char query[], int queryLength
         static thread_local Workspace ws;
         for (int i = t; i < dbLength; i += tasks) {
             if (failed.load(std::memory_order_relaxed)) return;
+            if (skip && skip[i]) continue;
             try {
                 align_one(rQuery.data(), queryLength, db[i], gapOpen, gapExt, profR.data(), results[i], mode, ws,
                           startQuery ? startQuery[i] : INT_MIN, startTarget ? startTarget[i] : INT_MIN, budget);
@@ -251,6 +253,13 @@ extern "C" int opalx_find_alignments_from(unsigned char query[], int queryLength
         return OPALX_ERR_NO_MEMORY;
     }
     return 0;
+}
+
+extern "C" int opalx_find_alignments_from(unsigned char query[], int queryLength, unsigned char* db[], int dbLength,
+                                          int dbSeqLengths[], int gapOpen, int gapExt, int* scoreMatrix, int alphabetLength,
+                                          OpalSearchResult* results[], int mode, const int* startQuery, const int* startTarget) {
+    return opalx_find_alignments_masked(query, queryLength, db, dbLength, dbSeqLengths, gapOpen, gapExt, scoreMatrix, alphabetLength,
+                                        results, mode, startQuery, startTarget, nullptr);
 }
 
 extern "C" int opalx_find_alignments(unsigned char query[], int queryLength, unsigned char* db[], int dbLength,
