@@ -1,5 +1,5 @@
-"""OPAL_SEARCH_ALIGNMENT: start cells on the device + box traceback against the host's full reverse pass
-(OPAL_HIP_HOST_STARTS=1). Same results; wall time of the opalSearchDatabase call alone (arrays prepared outside)."""
+"""OPAL_SEARCH_ALIGNMENT: start cells and traceback on the device, against the host traceback of the device's boxes
+(OPAL_HIP_HOST_TRACEBACK=1) and the host's full reverse pass (OPAL_HIP_HOST_STARTS=1). Same results; wall time of the opalSearchDatabase call alone (arrays prepared outside)."""
 import ctypes as C
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -44,15 +44,17 @@ def call(mode, level):
 for mode in ("SW", "OV", "HW", "NW"):
     t_end = min(call(mode, 1)[0] for _ in range(3))
     res_by = {}
-    for tag, env in (("device starts + box traceback", None), ("host full reverse pass", "1")):
-        if env: os.environ["OPAL_HIP_HOST_STARTS"] = env
-        else: os.environ.pop("OPAL_HIP_HOST_STARTS", None)
+    for tag, env in (("device starts + box traceback", None), ("device starts, host box traceback", "T"), ("host full reverse pass", "1")):
+        os.environ.pop("OPAL_HIP_HOST_STARTS", None); os.environ.pop("OPAL_HIP_HOST_TRACEBACK", None)
+        if env == "1": os.environ["OPAL_HIP_HOST_STARTS"] = "1"
+        if env == "T": os.environ["OPAL_HIP_HOST_TRACEBACK"] = "1"
         best, keep = None, None
         for rep in range(3):
             dt, out = call(mode, 2)
             best = dt if best is None else min(best, dt); keep = out
         res_by[tag] = keep
         print(f"{mode} {n} alignments, {tag:32s}: {best * 1e3:7.2f} ms   (score + end cells only: {t_end * 1e3:.2f} ms)", flush=True)
-    a, b = res_by["device starts + box traceback"], res_by["host full reverse pass"]
+    a, b, c = res_by["device starts + box traceback"], res_by["host full reverse pass"], res_by["device starts, host box traceback"]
     assert (a[0] == b[0]).all() and a[1] == b[1], mode
+    assert (a[0] == c[0]).all() and a[1] == c[1], mode
 print("identical start cells and operation strings")

@@ -583,3 +583,38 @@ def test_streaming_global_kernels(mode, qlen, lanes, narrow, ours, oracle, monke
             got = ours.search(q, db, go, ge, m, st, MODES[mode])[:4]
             _check(got, oracle.search(q, db, go, ge, m, st, MODES[mode]), mode, f"stream {mode} q{qlen} G={lanes} w{narrow} gaps {go}/{ge} st={st} blocks={blocks or 'auto'}")
     assert count() - before == 8
+
+
+@pytest.mark.parametrize("mode", ["SW", "NW", "HW", "OV"])
+@pytest.mark.parametrize("qlen,go,ge", [(60, 3, 1), (333, 11, 1), (333, 1, 1), (1000, 3, 1), (1700, 5, 2)])
+def test_device_traceback_equals_host_traceback(mode, qlen, go, ge, ours, oracle, monkeypatch):
+    """The operations traced on the device (trace_kernel.hip: box DP with one flag byte per cell in HBM, walk kernel) equal
+    the host traceback's, for every rows-per-lane shape of the kernel, cheap gaps (long indels), a flag budget so small
+    that the work is cut into many batches and the largest boxes are left to the host; every alignment re-scores."""
+    from opal_amd import synth
+    from opal_amd.score_matrix import blosum50
+    n = 260 if qlen < 1000 else 90
+    res, offs, lens = synth.database(n, seed=42, first=43000 + qlen)
+    q = synth.query(qlen, seed=9)
+    db = [res[offs[i]:offs[i + 1]] for i in range(n)] + [q[5:qlen - 3].copy(), np.concatenate([q[: qlen // 2], q[qlen // 2 + 7:]])]
+    m = blosum50()[1]
+    monkeypatch.setenv("OPAL_HIP_HOST_TRACEBACK", "1")
+    rc, s, eq, et, sset, (arr, _) = ours.search(q, db, go, ge, m, 2, MODES[mode])
+    assert rc == 0
+    sq, st, ops = ours.alignments(arr)
+    monkeypatch.delenv("OPAL_HIP_HOST_TRACEBACK")
+    for budget in ("", "300000"):
+        if budget:
+            monkeypatch.setenv("OPAL_TRACEBACK_DEVICE_BYTES", budget)
+        rc2, s2, eq2, et2, sset2, (arr2, _) = ours.search(q, db, go, ge, m, 2, MODES[mode])
+        assert rc2 == 0
+        sq2, st2, ops2 = ours.alignments(arr2)
+        np.testing.assert_array_equal(s, s2)
+        np.testing.assert_array_equal(sq, sq2)
+        np.testing.assert_array_equal(st, st2)
+        assert ops == ops2, f"{mode} q{qlen} gaps {go}/{ge} budget={budget or 'default'}"
+    for i in range(0, len(db), 7):
+        if mode == "SW" and s[i] == 0:
+            continue
+        o = np.frombuffer(ops[i], dtype=np.uint8)
+        assert oracle.check_alignment(q, db[i], go, ge, m, int(s[i]), int(sq[i]), int(st[i]), int(eq[i]), int(et[i]), o) == 0
