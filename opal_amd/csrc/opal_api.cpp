@@ -1113,11 +1113,13 @@ static int search_starts(OpalxDb* db, const unsigned char* query, int Q, int Go,
     return 0;
 }
 
-// Operations traced on the device, by position in the shard: ops[off[i] .. +len[i]), or len[i] < 0 (not traced: the host does it).
+// Operations traced on the device, by position in the shard: at(i)[0 .. len[i]), or len[i] < 0 (not traced: the host does it).
 struct TraceOut {
-    std::vector<unsigned char> ops;
+    std::vector<std::vector<unsigned char>> chunks;  // one buffer of operation strings per device batch, as downloaded
+    std::vector<int> chunk;                          // [n] which one
     std::vector<uint64_t> off;
     std::vector<int> len;
+    const unsigned char* at(size_t i) const { return chunks[(size_t)chunk[i]].data() + off[i]; }
 };
 
 /*
@@ -1133,7 +1135,8 @@ static void device_traceback(OpalxDb* db, int Q, int Go, int Ge, int A, int mode
                              const int* dStartQ, const int* dStartT, TraceOut& out) {
     out.len.assign((size_t)n, -1);
     out.off.assign((size_t)n, 0);
-    out.ops.clear();
+    out.chunk.assign((size_t)n, 0);
+    out.chunks.clear();
     if (getenv("OPAL_HIP_HOST_TRACEBACK") || !db->seqItemValid || n <= 0) return;
     uint64_t budget = 8ull << 30;
     if (const char* e = getenv("OPAL_TRACEBACK_DEVICE_BYTES")) { const long long v = atoll(e); if (v > 0) budget = (uint64_t)v; }
@@ -1141,6 +1144,7 @@ static void device_traceback(OpalxDb* db, int Q, int Go, int Ge, int A, int mode
     std::vector<int> items;
     std::vector<uint64_t> offs;  // [2 * batch]: flag-matrix offsets, then operation offsets
     const double t0 = now_ms();
+    double tDev = 0, tPack = 0;
     int traced = 0, batches = 0;
     int i = 0;
     while (i < n) {
@@ -1172,6 +1176,7 @@ static void device_traceback(OpalxDb* db, int Q, int Go, int Ge, int A, int mode
              !opal_hip_memcpy_h2d(db->trOff.p, offs.data(), 2 * m * sizeof(uint64_t), st);
         std::vector<int> res(2 * m);
         std::vector<unsigned char> ops((size_t)opsBytes);
+        const double tb0 = now_ms();
         if (ok) {
             OpalHipTraceLaunch a;
             memset(&a, 0, sizeof a);
@@ -1192,18 +1197,24 @@ static void device_traceback(OpalxDb* db, int Q, int Go, int Ge, int A, int mode
             continue;
         }
         batches++;
+        const double tb1 = now_ms();
+        tDev += tb1 - tb0;
         for (size_t b = 0; b < m; b++) {
             const int idx = items[b];
             const int len = res[b], bs = res[m + b];
             const int cap = (endQ[idx] - startQ[idx] + 1) + (endT[idx] - startT[idx] + 1);
             if (bs != score[idx] || len <= 0 || len > cap) continue;  // the box does not carry the score: the host's full pass decides
-            out.off[(size_t)idx] = out.ops.size();
+            out.chunk[(size_t)idx] = (int)out.chunks.size();
+            out.off[(size_t)idx] = opsOff[b];
             out.len[(size_t)idx] = len;
-            out.ops.insert(out.ops.end(), ops.begin() + (size_t)opsOff[b], ops.begin() + (size_t)opsOff[b] + len);
             traced++;
         }
+        out.chunks.push_back(std::move(ops));
+        tPack += now_ms() - tb1;
     }
-    if (debug_on()) fprintf(stderr, "[opal] device traceback: %d of %d alignments in %d batches, %.2f ms\n", traced, n, batches, now_ms() - t0);
+    if (debug_on())
+        fprintf(stderr, "[opal] device traceback: %d of %d alignments in %d batches, %.2f ms (kernels + copies %.2f, bookkeeping %.2f)\n", traced, n,
+                batches, now_ms() - t0, tDev, tPack);
 }
 
 // ------------------------------------------------------------------------------------ devices of a call
@@ -1601,7 +1612,7 @@ static int search_into_results(unsigned char query[], int Q, unsigned char* db[]
                         const int caller = ids ? ids[p] : p;
                         unsigned char* a = (unsigned char*)malloc((size_t)tr.len[(size_t)i]);
                         if (!a) continue;  // the host traceback will try (and report) instead
-                        memcpy(a, tr.ops.data() + tr.off[(size_t)i], (size_t)tr.len[(size_t)i]);
+                        memcpy(a, tr.at((size_t)i), (size_t)tr.len[(size_t)i]);
                         OpalSearchResult* r = results[caller];
                         r->startLocationQuery = startQ[p];
                         r->startLocationTarget = startT[p];
