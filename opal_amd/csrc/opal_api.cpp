@@ -837,7 +837,7 @@ static StreamPlan plan_stream(int Q, int A, int mode, int wantEnd, long long res
             // (2-4 %: 513-aa query x 625 000 sequences 6 790 -> 7 050 GCUPS, 300-aa x 1 000 000 7 230 -> 7 390) when every
             // slot works through many sequences; with ~3 per slot (300-aa x 100 000) it is 14 % slower.
             const double perSlot = (double)numSeqs / (4096.0 * (64 / best.G));
-            if (crit > 0.5 * total || perSlot < 12.0) best = StreamPlan();
+            if (crit > 0.5 * total || perSlot < 20.0) best = StreamPlan();  // (300-aa query: break-even at ~18 sequences per slot, 600 000 sequences)
         }
     }
     return best;
