@@ -618,3 +618,41 @@ def test_device_traceback_equals_host_traceback(mode, qlen, go, ge, ours, oracle
             continue
         o = np.frombuffer(ops[i], dtype=np.uint8)
         assert oracle.check_alignment(q, db[i], go, ge, m, int(s[i]), int(sq[i]), int(st[i]), int(eq[i]), int(et[i]), o) == 0
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_randomized_differential_streaming(seed, ours, oracle, monkeypatch):
+    """The randomized shapes once more with the streaming kernels forced wherever a geometry exists (other alphabets and
+    matrices than BLOSUM50, gap extension 0 or larger than the opening, queries from 1 to 2400 residues, every mode and
+    search type, alignment searches included)."""
+    monkeypatch.setenv("OPAL_HIP_STREAM", "1")
+    rng = np.random.RandomState(7000 + seed)
+    for _ in range(5):
+        A = int(rng.choice([2, 4, 5, 20, 24, 31]))
+        m = rng.randint(-9, 12, size=(A, A)).astype(np.int32)
+        if rng.rand() < 0.5:
+            m = ((m + m.T) // 2).astype(np.int32)
+            np.fill_diagonal(m, rng.randint(1, 14))
+        go = int(rng.randint(0, 16)); ge = int(rng.randint(0, go + 1)) if rng.rand() < 0.8 else int(rng.randint(0, 20))
+        qlen = int(rng.choice([1, 2, 7, 40, 41, 159, 333, 641, 900, 1281, 1500, 2047, 2400]))
+        n = int(rng.randint(1, 120))
+        lens = np.maximum(1, (rng.lognormal(4.5, 1.0, size=n)).astype(int)); lens = np.minimum(lens, 1500)
+        if rng.rand() < 0.3:
+            lens[rng.randint(0, n)] = int(rng.randint(1500, 4000))
+        q = rng.randint(0, A, size=qlen).astype(np.uint8)
+        db = [rng.randint(0, A, size=int(L)).astype(np.uint8) for L in lens]
+        if rng.rand() < 0.5:
+            for i in range(0, n, 3):
+                L = len(db[i]); k = min(L, qlen)
+                db[i][:k] = np.where(rng.rand(k) < 0.8, q[:k], db[i][:k])
+        mode = str(rng.choice(["SW", "NW", "HW", "OV"])); st = int(rng.randint(0, 2))
+        lanes = str(rng.choice(["", "", "16", "32", "64"]))
+        if lanes:
+            monkeypatch.setenv("OPAL_HIP_LANES_PER_SEQ", lanes)
+        else:
+            monkeypatch.delenv("OPAL_HIP_LANES_PER_SEQ", raising=False)
+        got = ours.search(q, db, go, ge, m, st, MODES[mode], int(rng.randint(0, 2)))[:4]
+        want = oracle.search(q, db, go, ge, m, st, MODES[mode])
+        what = f"stream seed {seed}: A={A} Q={qlen} n={n} gaps {go}/{ge} {mode} st={st} lanes={lanes or 'auto'}"
+        _check(got, want, mode, what)
+        assert (got[2] == want[2]).all() and (got[3] == want[3]).all(), what
