@@ -1212,6 +1212,7 @@ static void device_traceback(OpalxDb* db, int Q, int Go, int Ge, int A, int mode
         out.chunks.push_back(std::move(ops));
         tPack += now_ms() - tb1;
     }
+    if (db->trDirs.cap > (2ull << 30)) db->trDirs.release();  // a cached context does not sit on gigabytes of flags between calls
     if (debug_on())
         fprintf(stderr, "[opal] device traceback: %d of %d alignments in %d batches, %.2f ms (kernels + copies %.2f, bookkeeping %.2f)\n", traced, n,
                 batches, now_ms() - t0, tDev, tPack);
