@@ -656,3 +656,28 @@ def test_randomized_differential_streaming(seed, ours, oracle, monkeypatch):
         what = f"stream seed {seed}: A={A} Q={qlen} n={n} gaps {go}/{ge} {mode} st={st} lanes={lanes or 'auto'}"
         _check(got, want, mode, what)
         assert (got[2] == want[2]).all() and (got[3] == want[3]).all(), what
+
+
+@pytest.mark.parametrize("mode", ["SW", "OV"])
+def test_alignment_search_sharded_over_devices(mode, ours, monkeypatch):
+    """OPAL_SEARCH_ALIGNMENT with the call sharded over several devices ("0,0": two contexts on this box's one GPU): the
+    operations traced per shard land in the right result structs -- same start cells and operation strings as unsharded."""
+    from opal_amd import synth
+    from opal_amd.score_matrix import blosum50
+    res, offs, lens = synth.database(900, seed=42, first=52000)
+    db = [res[offs[i]:offs[i + 1]] for i in range(900)]
+    q = synth.query(250, seed=3)
+    m = blosum50()[1]
+    rc, s, eq, et, sset, (arr, _) = ours.search(q, db, 3, 1, m, 2, MODES[mode])
+    assert rc == 0
+    sq, st, ops = ours.alignments(arr)
+    monkeypatch.setenv("OPAL_HIP_DEVICES", "0,0")
+    rc2, s2, eq2, et2, sset2, (arr2, _) = ours.search(q, db, 3, 1, m, 2, MODES[mode])
+    assert rc2 == 0
+    sq2, st2, ops2 = ours.alignments(arr2)
+    np.testing.assert_array_equal(s, s2)
+    np.testing.assert_array_equal(eq, eq2)
+    np.testing.assert_array_equal(et, et2)
+    np.testing.assert_array_equal(sq, sq2)
+    np.testing.assert_array_equal(st, st2)
+    assert ops == ops2
