@@ -889,7 +889,7 @@ static StreamPlan plan_stream(int Q, int A, int mode, int wantEnd, long long res
  * reference (only the re-run granularity differs); here both map to the same schedule.
  */
 static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, const int* M, int A,
-                       int searchType, int mode, int* dScore, int* dEndQ, int* dEndT, float* kernelMs) {
+                       int searchType, int mode, int* dScore, int* dEndQ, int* dEndT, float* kernelMs, bool finalSync = true) {
     if (kernelMs) *kernelMs = 0.f;
     if (mode != OPAL_MODE_NW && mode != OPAL_MODE_HW && mode != OPAL_MODE_OV && mode != OPAL_MODE_SW)
         return OPAL_ERR_INVALID_MODE;
@@ -1103,7 +1103,8 @@ static int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, i
         }
     }
     if (evStop) opal_hip_event_record(evStop, st);
-    if (opal_hip_stream_sync(st)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    // (a caller that copies the results back on the same stream and waits for that copy needs no wait of its own here)
+    if ((finalSync || kernelMs) && opal_hip_stream_sync(st)) return OPAL_ERR_NO_SIMD_SUPPORT;
     if (kernelMs && evStart && evStop) *kernelMs = opal_hip_event_elapsed_ms(evStart, evStop);
     return rc;
 }
@@ -1347,7 +1348,8 @@ static int run_shard(int device, const unsigned char* query, int Q, unsigned cha
     void* st = pdb->main();
     // INT_MIN marks "not written by the search" (a sequence the search had to give up on)
     if (opal_hip_memset32(dS, INT_MIN, nn, st) || (wantEnd && opal_hip_memset32(dQ, -1, 2 * nn, st))) return OPAL_ERR_NO_SIMD_SUPPORT;
-    int rc = search_core(pdb, query, Q, Go, Ge, M, A, searchType, mode, dS, wantEnd ? dQ : nullptr, wantEnd ? dT : nullptr, nullptr);
+    int rc = search_core(pdb, query, Q, Go, Ge, M, A, searchType, mode, dS, wantEnd ? dQ : nullptr, wantEnd ? dT : nullptr, nullptr,
+                         /*finalSync=*/false);
     const double t3 = now_ms();
     if (rc == OPAL_ERR_NO_SIMD_SUPPORT || rc == OPAL_ERR_INVALID_MODE) return rc;
     int* h = pdb->hResults.p;
