@@ -401,8 +401,6 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
         opal_dp_body<WIDTH, MODE, 0, S>(p, sp.side, (int)blockIdx.x, STREAM_SIDE_WAVES);
         return;
     }
-    const int streamBlock = (int)blockIdx.x - sp.sideBlocks;
-    (void)streamBlock;
 
     const int log2G = p.log2G;
     const int G = 1 << log2G;
