@@ -329,12 +329,23 @@ def main():
         sl = np.sort(lens)[::-1].astype(np.int64)
         alg_bytes = float(2 * sl[0::2].sum() + 24 * ((n + 1) // 2) + 4 * nres * n)
         traffic, traffic_src = None, None
-        try:  # HBM bytes per step measured offline with rocprofv3 PMC passes (scripts/prof_hbm.sh) on this same workload
-            if (args.workload, args.qlen, args.seqs, args.mode, args.search_type, args.gap_open, world) == ("c2", 300, 100000, "SW", 0, 11, 1):
+        try:  # HBM bytes per step measured offline with rocprofv3 PMC passes on this same workload (never guessed for another)
+            key = (args.workload, args.qlen, total if strong else args.seqs, args.mode, args.search_type, args.gap_open, world)
+            if key == ("c2", 300, 100000, "SW", 0, 11, 1):
                 with open(os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")) as fh:
                     traffic = json.load(fh)["hbm_bytes_per_step"]
                     traffic_src = "offline: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r02_pmc_hbm.json)"
-        except (OSError, KeyError, ValueError):
+            else:  # the per-configuration profiles of scripts/prof_round2.sh
+                tags = {("c3", 300, 100000, "SW", 1): "c2end", ("c3", 300, 100000, "NW", 1): "c3nw", ("c3", 300, 100000, "HW", 1): "c3hw",
+                        ("c3", 300, 100000, "OV", 1): "c3ov", ("c4", 513, 625000, "SW", 0): "c4", ("c5", 2000, 100000, "SW", 0): "c5",
+                        ("c5", 2000, 100000, "SW", 1): "c5end", ("c5", 2000, 100000, "NW", 1): "c5nw", ("c5", 2000, 100000, "HW", 1): "c5hw",
+                        ("c5", 2000, 100000, "OV", 1): "c5ov"}
+                tag = tags.get(key[:5]) if (key[5], key[6]) == (11, 1) else None
+                if tag:
+                    with open(os.path.join(ROOT, "profiles", f"r02_{tag}.json")) as fh:
+                        traffic = json.load(fh)["hbm_bytes_per_step"]
+                        traffic_src = f"offline: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (profiles/r02_{tag}.json)"
+        except (OSError, KeyError, ValueError, TypeError):
             traffic = None
         hbm = {"peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes": alg_bytes,
                "algorithmic_gbs": round(alg_bytes / (kms * 1e-3) / 1e9, 2),
