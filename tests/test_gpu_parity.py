@@ -681,3 +681,39 @@ def test_alignment_search_sharded_over_devices(mode, ours, monkeypatch):
     np.testing.assert_array_equal(sq, sq2)
     np.testing.assert_array_equal(st, st2)
     assert ops == ops2
+
+
+def test_reentrant_streaming_and_alignment_from_host_threads(ours, oracle, monkeypatch):
+    """Four host threads at once, every one on the streaming kernels (persistent workgroups of different searches share
+    the GPU: each must still run to completion) or in an alignment search with the traceback on the device."""
+    import threading
+    from opal_amd import synth
+    from opal_amd.score_matrix import blosum50
+    monkeypatch.setenv("OPAL_HIP_STREAM", "1")
+    m = blosum50()[1]
+    jobs = []
+    for t in range(4):
+        res, offs, lens = synth.database(700 + 100 * t, seed=600 + t)
+        db = [res[offs[i]:offs[i + 1]] for i in range(len(lens))]
+        q = synth.query([1100, 700, 1500, 333][t], seed=20 + t)
+        jobs.append((q, db, ["SW", "NW", "OV", "HW"][t], [0, 1, 1, 2][t]))
+    out = [None] * 4
+    errs = []
+
+    def run(i):
+        q, db, mode, st = jobs[i]
+        try:
+            for _ in range(3):
+                r = ours.search(q, db, 11, 1, m, st, MODES[mode])
+                if st == 2:
+                    ours.alignments(r[5][0])
+                out[i] = r[:4]
+        except Exception as e:  # noqa
+            errs.append((i, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(4)]
+    for th in threads: th.start()
+    for th in threads: th.join(timeout=300)
+    assert not errs and all(not th.is_alive() for th in threads), errs
+    for i, (q, db, mode, st) in enumerate(jobs):
+        _check(out[i], oracle.search(q, db, 11, 1, m, min(st, 1), MODES[mode]), mode, f"thread {i} {mode} st={st}")
