@@ -239,7 +239,11 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
         const reg Qv = (reg)info.x, Rv = (reg)info.y;
 
         reg f = inF;
-        reg cm = 0;  // SWEND: this column's maximum over my rows
+        // SWEND: this column's maximum over my rows, kept per HALF of the rows during the row blocks (which accumulator a
+        // row block uses costs nothing), so that a row scan only visits the first half that holds the column maximum
+        constexpr int NBLK4Q = (S + 3) / 4;
+        constexpr int NQ = 2;  // (halves measured better than quarters: fewer accumulators to combine)
+        reg cq[NQ] = {0, 0};
         {
             constexpr int NBLK = SPAD / RB;
             int4 pc = lds_ld16(offv);
@@ -261,7 +265,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
                     if constexpr (j0 < S) {
                         constexpr int n = (S - j0) < 4 ? (S - j0) : 4;
                         constexpr bool last = j0 + n == S;
-                        V::template rows<ROWS_SWV, n, last>(&Hp[j0], &En[j0], &Pv[j0 - rb * RB + 1], f, SWEND ? cm : mx, d, t, Qv, Rv);
+                        V::template rows<ROWS_SWV, n, last>(&Hp[j0], &En[j0], &Pv[j0 - rb * RB + 1], f, SWEND ? cq[(j0 / 4) * NQ / NBLK4Q] : mx, d, t, Qv, Rv);
                     }
                 });
                 pc = pn;
@@ -288,14 +292,23 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
                 const int old = atomicMax(ring + (flushCount & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4) + 7, mv);
                 seqM1 = V::splat((old > mv ? old : mv) - 1);
             }
+            const reg cm = V::maxs(cq[0], cq[1]);
             const reg bar = V::maxs(V::maxs(mx, seqM1), pmIn);
             if ((short)cm > (short)bar) {
+                // the first half whose maximum is the column's, then the smallest row in it
+                const int qsel = V::same(cq[0], cm, 0) ? 0 : 1;
                 int r = 0;
-                constexpr int NBLK4 = (S + 3) / 4;
-                static_for<NBLK4>([&](auto bc) {  // highest block first: the smallest row holding it wins
-                    constexpr int b = NBLK4 - 1 - decltype(bc)::value;
-                    constexpr int n = (S - 4 * b) < 4 ? (S - 4 * b) : 4;
-                    V::template scan_rows<n, 4 * b>(&Hp[4 * b], cm, r);
+                static_for<NQ>([&](auto qc) {
+                    constexpr int qi = decltype(qc)::value;
+                    if (qsel == qi) {
+                        static_for<NBLK4Q>([&](auto bc) {  // highest block first: the smallest row holding it wins
+                            constexpr int b = NBLK4Q - 1 - decltype(bc)::value;
+                            if constexpr (b * NQ / NBLK4Q == qi) {
+                                constexpr int n = (S - 4 * b) < 4 ? (S - 4 * b) : 4;
+                                V::template scan_rows<n, 4 * b>(&Hp[4 * b], cm, r);
+                            }
+                        });
+                    }
                 });
                 endRow = r0 + r;
                 endCol = s - k - myStart;
