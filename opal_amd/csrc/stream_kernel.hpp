@@ -503,7 +503,8 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
     SlotStream st;  // the stream of this slot
     int started = 0;                    // entries this lane has begun
     int myStart = 0, myLen = 0, myNext = 0;  // my current sequence: first stream position, length; where my next one begins
-    int best = INT_MIN, bestCol = -1, prevBest = INT_MIN;  // HW/OV (last lane): last-row maximum, its first column; OV: before the last column
+    reg bestF = V::splat(-32768);  // HW/OV: last-row maximum so far, in the skewed frame of the step at hand
+    int bestCol = -1;              // its first column
     int outLcV = INT_MIN, outLcRow = -1;                    // OV: last-column maximum handed down the lanes
 
     auto fetch = [&](const int x) { stream_fetch<0>(st, p, sp.next, ring, x, k, G, slotLane0, PAD); };
@@ -541,7 +542,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
                 });
                 diagIn = (reg)lds_ld16(myInit + 2 * SP4 * 4).x;
                 sRv = V::splat(k * Ge);
-                best = INT_MIN; bestCol = -1; prevBest = INT_MIN;
+                bestF = V::splat(-32768); bestCol = -1;
             }
         }
         const int c = x - myStart;  // my column
@@ -593,12 +594,11 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
         diagIn = inH;
 
         // ---- results (caller index and length of my sequence: descriptor started-1)
-        const int* desc = ring + ((started - 1) & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4);
         if (MODE == MODE_NW) {
             if (k == kLast && c == myLen - 1 && myLen > 0) {  // the final cell: once per sequence
                 const reg hl = SelectRow<reg, S, 0, S>::get(Hp, jLast);
                 const int v = V::half(V::subs(hl, V::adds(sRv, V::splat(jLast * Ge))), 0);
-                const int seq = desc[2];
+                const int seq = ring[((started - 1) & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4) + 2];
                 if (seq >= 0) {
                     p.outScore[seq] = v;
                     if (p.outEndQ) { p.outEndQ[seq] = Q - 1; p.outEndT[seq] = myLen - 1; }
@@ -644,21 +644,28 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
                     }
                 }
             }
-            if (k == kLast && c >= 0 && c < myLen) {
-                // last query row = last register of the last lane = this column's outH
-                const int v = V::half(V::subs(outH, V::adds(sRv, SR1v)), 0);
-                if (lastc) prevBest = best;
-                if (v > best) { best = v; bestCol = c; }  // strict >: first column wins (opal.cpp:824-834)
-                if (lastc) {
-                    int sc = best, eq = Q - 1, et = bestCol;
-                    if (MODE == MODE_OV && lcV > prevBest) { sc = lcV; et = myLen - 1; eq = lcRow; }
-                    const int seq = desc[2];
-                    if (seq >= 0) {
-                        p.outScore[seq] = sc;
-                        if (p.outEndQ) { p.outEndQ[seq] = eq; p.outEndT[seq] = et; }
-                    }
+            // Last-row maximum and its first column (last query row = last register of the last lane = this column's outH),
+            // tracked by EVERY lane in the skewed frame with full-rate 16-bit instructions -- no branch, no unskewing per
+            // step: the running best moves into the frame of the new step with one addition (only the last lane's value is
+            // ever used; columns beyond the sequence come after its result has been written).
+            const reg prevF = bestF;                      // OV: the maximum over columns 0 .. c-1, in this step's frame
+            const bool better = (short)outH > (short)bestF;  // strict >: first column wins (opal.cpp:824-834)
+            bestF = better ? outH : bestF;
+            bestCol = better ? c : bestCol;
+            if (k == kLast && lastc) {
+                const reg frame = V::adds(sRv, SR1v);
+                int sc = V::half(V::subs(bestF, frame), 0), eq = Q - 1, et = bestCol;
+                if (MODE == MODE_OV) {
+                    const int prevBest = (myLen > 1) ? V::half(V::subs(prevF, frame), 0) : INT_MIN;
+                    if (lcV > prevBest) { sc = lcV; et = myLen - 1; eq = lcRow; }
+                }
+                const int seq = ring[((started - 1) & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4) + 2];
+                if (seq >= 0) {
+                    p.outScore[seq] = sc;
+                    if (p.outEndQ) { p.outEndQ[seq] = eq; p.outEndT[seq] = et; }
                 }
             }
+            bestF = V::adds(bestF, Rv);  // into the frame of the next step
         }
         sRv = V::adds(sRv, Rv);
     }
