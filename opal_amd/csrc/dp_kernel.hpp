@@ -311,6 +311,23 @@ __host__ __device__ inline int opal_profile_stride(int es, int G, int S, int pad
     return stride;
 }
 
+// OV, last column of a sequence: the maximum over a lane's rows in the skewed frame. The running best moves from the frame
+// of row J+1 to that of row J with one subtraction; a row that reaches it takes over (ties: the smaller row). Four
+// full-rate 16-bit instructions per row (and the wait between a compare and the selects that read its mask).
+template <typename V, int S, int J> struct OvColumnScan {
+    static __device__ __forceinline__ void run(const typename V::reg (&Hp)[S], typename V::reg Rv, typename V::reg& bf, int& bj) {
+        unsigned long long m;
+        asm("v_sub_u16_e32 %[bf], %[bf], %[rv]\n\t"
+            "v_cmp_ge_i16_e64 %[m], %[h], %[bf]\n\t"
+            "s_nop 1\n\t"
+            "v_cndmask_b32_e64 %[bf], %[bf], %[h], %[m]\n\t"
+            "v_cndmask_b32_e64 %[bj], %[bj], %[j], %[m]"
+            : [bf] "+v"(bf), [bj] "+v"(bj), [m] "=&s"(m)
+            : [h] "v"(Hp[J]), [rv] "v"(Rv), [j] "n"(J));
+        if constexpr (J > 0) OvColumnScan<V, S, J - 1>::run(Hp, Rv, bf, bj);
+    }
+};
+
 // ------------------------------------------------------------------ the DP kernel
 // (the second launch bound asks the register allocator for 4 waves per SIMD, i.e. at most 128 VGPRs, on the single-launch
 // plain-16-bit kernels: OV at 38-39 rows per lane compiled to 129-131 registers without it, one wave per SIMD less)
@@ -754,6 +771,16 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
                     for (int hh = 0; hh < NH; hh++) {
                         if (c == len[hh] - 1) {
                             int bv = lcMax[hh], bj = -1;
+                            if constexpr (SKEW) {  // (SKEW: single launch, one sequence per lane, lcMax still at its start value)
+                                if (jlo == 0 && jhi == S) {  // all my rows are query rows: the scan in the skewed frame
+                                    reg bf = Hp[S - 1];
+                                    bj = S - 1;
+                                    if constexpr (S > 1) OvColumnScan<V, S, S - 2>::run(Hp, Rv, bf, bj);
+                                    bv = V::half(V::subs(bf, V::splat(s * Ge)), hh);
+                                    lcMax[hh] = bv; lcRow[hh] = r0 + bj;
+                                    continue;
+                                }
+                            }
 #pragma unroll
                             for (int j = S - 1; j >= 0; j--) {
                                 const int v = V::half(SKEW ? V::subs(Hp[j], V::splat((j + s) * Ge)) : Hp[j], hh);

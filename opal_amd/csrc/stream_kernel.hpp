@@ -393,23 +393,6 @@ __host__ __device__ inline size_t opal_gl_stream_lds_bytes(int G, int S, int A) 
            (size_t)STREAM_WAVES * (64 / G) * STREAM_RING * STREAM_DESC_BYTES;
 }
 
-// OV, last column of a sequence: the maximum over a lane's rows in the skewed frame. The running best moves from the frame
-// of row J+1 to that of row J with one subtraction; a row that reaches it takes over (ties: the smaller row). Four
-// full-rate 16-bit instructions per row (and the wait between a compare and the selects that read its mask).
-template <typename V, int S, int J> struct OvColumnScan {
-    static __device__ __forceinline__ void run(const typename V::reg (&Hp)[S], typename V::reg Rv, typename V::reg& bf, int& bj) {
-        unsigned long long m;
-        asm("v_sub_u16_e32 %[bf], %[bf], %[rv]\n\t"
-            "v_cmp_ge_i16_e64 %[m], %[h], %[bf]\n\t"
-            "s_nop 1\n\t"
-            "v_cndmask_b32_e64 %[bf], %[bf], %[h], %[m]\n\t"
-            "v_cndmask_b32_e64 %[bj], %[bj], %[j], %[m]"
-            : [bf] "+v"(bf), [bj] "+v"(bj), [m] "=&s"(m)
-            : [h] "v"(Hp[J]), [rv] "v"(Rv), [j] "n"(J));
-        if constexpr (J > 0) OvColumnScan<V, S, J - 1>::run(Hp, Rv, bf, bj);
-    }
-};
-
 template <int WIDTH, int MODE, int S>
 __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const StreamParams sp) {
     using V = Vec<WIDTH>;
