@@ -222,6 +222,12 @@ def test_two_rank_bench_on_one_gpu():
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
     assert one["verify"]["score_crc32"] == two["verify"]["score_crc32"]
     assert one["roofline"]["bound"] == "valu-issue" and 0 < one["roofline"]["frac"] < 1
+    # the same with a long query: both ranks on the streaming kernels (persistent workgroups of two processes share the GPU)
+    common = ["--workload", "c5", "--total-seqs", "60000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e"]
+    one = _run_bench(["--gpus", "1"] + common)
+    two = _run_bench(["--gpus", "2"] + common, {"BENCH_SHARE_GPU": "1", "BENCH_BACKEND": "gloo"})
+    assert one["verified"] and two["verified"] and two["n_gpus"] == 2
+    assert one["verify"]["score_crc32"] == two["verify"]["score_crc32"]
 
 
 def test_api_context_reuse_and_multi_device(oracle):
