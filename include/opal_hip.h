@@ -180,6 +180,11 @@ typedef struct OpalHipRevLaunch {
     int* flags;                   /* [2], zeroed by the caller: [0] length of `redo`, [1] sequences with no start found */
     int* redo;                    /* [N] sequences whose start the host must recompute (see rev_kernel.hip) */
     void* stream;
+    /* Second pass over a `redo` list (items = that list): the stop COLUMN of every listed sequence is final (start_target holds
+       it), only its row is in doubt -- the reference takes the first row of that column holding the score, whatever cell it
+       is. exact_row != 0 recomputes the prefix up to that column and writes that row; sequences without a stop column are
+       appended to `redo` (counted in flags[0]) for the host. */
+    int exact_row;
 } OpalHipRevLaunch;
 /* rows per lane the reverse kernel would use for this query length (0: longer than 64 x 40 rows, unsupported) */
 int opal_hip_rev_rows_supported(int query_length);

@@ -1128,9 +1128,9 @@ static int search_starts(OpalxDb* db, const unsigned char* query, int Q, int Go,
             return OPAL_ERR_NO_SIMD_SUPPORT;
         db->seqItemValid = true;
     }
-    if (!db->revFlags.ensure(2) || !db->redo.ensure((size_t)n, db->cached ? 1.15 : 1.0)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (!db->revFlags.ensure(4) || !db->redo.ensure(2 * (size_t)n, db->cached ? 1.15 : 1.0)) return OPAL_ERR_NO_SIMD_SUPPORT;
     if (ensure_query_buffers(db, query, Q, M, A)) return OPAL_ERR_NO_SIMD_SUPPORT;
-    if (opal_hip_memset(db->revFlags.p, 0, 2 * sizeof(int), st)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (opal_hip_memset(db->revFlags.p, 0, 4 * sizeof(int), st)) return OPAL_ERR_NO_SIMD_SUPPORT;
     OpalHipRevLaunch a;
     memset(&a, 0, sizeof a);
     a.mode = mode; a.query = db->query.p; a.query_length = Q; a.score_matrix = db->matrix.p; a.alphabet_length = A;
@@ -1144,12 +1144,29 @@ static int search_starts(OpalxDb* db, const unsigned char* query, int Q, int Go,
     int flags[2] = {0, 0};
     if (opal_hip_memcpy_d2h(flags, db->revFlags.p, sizeof flags, st) || opal_hip_stream_sync(st)) return OPAL_ERR_NO_SIMD_SUPPORT;
     // empty sequences have no token stream and no end cell: nothing to start from (the kernel saw endT = -1)
-    if (flags[0] > 0 && redoHost) {
-        if (opal_hip_memcpy_d2h(redoHost, db->redo.p, (size_t)flags[0] * sizeof(int), st) || opal_hip_stream_sync(st))
+    const int doubtful = flags[0];
+    int left = doubtful;
+    const int* leftList = db->redo.p;
+    if (doubtful > 0 && !getenv("OPAL_HIP_NO_EXACT_ROW")) {
+        // Second pass over the doubtful ones (OV: a cell that is not an allowed end held the score in the stop column): their
+        // stop column is final, the reference's row scan of that column is repeated exactly on the device. Only sequences
+        // without a stop column at all stay for the host.
+        a.items = db->redo.p; a.num_items = doubtful; a.exact_row = 1;
+        a.flags = db->revFlags.p + 2; a.redo = db->redo.p + n;
+        int flags2[2] = {0, 0};
+        if (opal_hip_rev_launch(&a) || opal_hip_memcpy_d2h(flags2, db->revFlags.p + 2, sizeof flags2, st) || opal_hip_stream_sync(st))
+            return OPAL_ERR_NO_SIMD_SUPPORT;
+        left = flags2[0];
+        leftList = db->redo.p + n;
+    }
+    if (left > 0 && redoHost) {
+        if (opal_hip_memcpy_d2h(redoHost, leftList, (size_t)left * sizeof(int), st) || opal_hip_stream_sync(st))
             return OPAL_ERR_NO_SIMD_SUPPORT;
     }
-    if (redoCount) *redoCount = flags[0];
-    if (debug_on()) fprintf(stderr, "[opal] start locations on the device: %d sequences, %d to redo on the host, %d not found\n", n, flags[0], flags[1]);
+    if (redoCount) *redoCount = left;
+    if (debug_on())
+        fprintf(stderr, "[opal] start locations on the device: %d sequences, %d with a second (exact-row) pass, %d to redo on the host, %d not found\n", n,
+                doubtful, left, flags[1]);
     return 0;
 }
 

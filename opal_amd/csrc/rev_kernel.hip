@@ -46,6 +46,7 @@ struct RevParams {
     int* startQ; int* startT;
     int* flags;           // [2]: [0] sequences whose start must be recomputed by the host (OV coincidence), [1] not found
     int* redo;            // list of caller indices counted in flags[0]
+    int exactRow;         // second pass: the stop column is known (startT), find the first row of it holding the score
 };
 
 __device__ __forceinline__ int rev_shr1(int v) {  // lane i receives lane i-1's value (lane 0: 0)
@@ -76,6 +77,12 @@ __global__ void __launch_bounds__(REV_WAVES_PER_BLOCK * 64) opal_rev_kernel(cons
         return;
     }
     const int Go = p.Go, Ge = p.Ge;
+    // second pass: column (of the reversed target prefix) in which the first pass stopped
+    const int exactC = p.exactRow ? eT - p.startT[seq] : -1;
+    if (p.exactRow && (p.startT[seq] < 0 || exactC < 0 || exactC >= at)) {  // no stop column: the host's full pass
+        if (lane == 0) p.redo[atomicAdd(p.flags, 1)] = seq;
+        return;
+    }
     const int item = p.seqItem[seq];
     const uint16_t* tok = p.tokens + p.pairOff[item >> 1];
     const int hiHalf = item & 1;
@@ -100,7 +107,8 @@ __global__ void __launch_bounds__(REV_WAVES_PER_BLOCK * 64) opal_rev_kernel(cons
     unsigned long long hist0 = 0, hist1 = 0;
     int sLast = 0;
     int tLetter = 0;
-    int limit = at + 63;  // steps: lane k computes column s - k
+    int limit = p.exactRow ? exactC + 64 : at + 63;  // steps: lane k computes column s - k
+    int exactR = INT_MAX;  // second pass: smallest row of mine holding the score in column exactC
     for (int s = 0; s < limit; s++) {
         // target letters travel down the lanes with the columns; lane 0 takes column s from memory
         int fresh = 0;
@@ -132,6 +140,7 @@ __global__ void __launch_bounds__(REV_WAVES_PER_BLOCK * 64) opal_rev_kernel(cons
                 const bool allowed = mode == REV_MODE_SW ? real : (j == jl || (mode == REV_MODE_OV && lastCol && real));
                 cm = max(cm, allowed ? h : REV_NEG);
                 if (mode == REV_MODE_OV) coincidence |= (h == score && real && !allowed);
+                if (c == exactC && h == score && real && exactR == INT_MAX) exactR = r0 + j;
                 const int hq = h - Go;
                 En[j] = max(e - Ge, hq);
                 f = max(f - Ge, hq);
@@ -157,7 +166,17 @@ __global__ void __launch_bounds__(REV_WAVES_PER_BLOCK * 64) opal_rev_kernel(cons
         sLast = s;
         // The first hit in TIME (step s0) need not be the smallest column, but a smaller one, c* <= s0, is computed by
         // lane k at step c* + k <= s0 + 63: run 64 more steps. (And c* + k >= s0 - 63, so 128 bits of history suffice.)
-        if (__ballot(found) != 0ull) limit = min(limit, s + 65);
+        if (!p.exactRow && __ballot(found) != 0ull) limit = min(limit, s + 65);
+    }
+    if (p.exactRow) {  // the reference's row scan of the stop column (opal.cpp:1353-1357): first row holding the score
+        int er = exactR;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(er, d, 64); er = o < er ? o : er; }
+        if (lane == 0) {
+            if (er == INT_MAX) p.redo[atomicAdd(p.flags, 1)] = seq;  // (cannot happen: the first pass found the score there)
+            else p.startQ[seq] = eQ - er;
+        }
+        return;
     }
     // the slot's answer: smallest column, then smallest row
     int bc = bestC, br = bestR;
@@ -217,7 +236,7 @@ extern "C" int opal_hip_rev_launch(const OpalHipRevLaunch* a) {
     p.matrix = a->score_matrix; p.tokens = a->tokens; p.pairOff = a->pair_token_offset; p.seqItem = a->seq_item;
     p.items = a->items; p.numItems = a->num_items;
     p.score = a->score; p.endQ = a->end_query; p.endT = a->end_target;
-    p.startQ = a->start_query; p.startT = a->start_target; p.flags = a->flags; p.redo = a->redo;
+    p.startQ = a->start_query; p.startT = a->start_target; p.flags = a->flags; p.redo = a->redo; p.exactRow = a->exact_row;
     const int blocks = (a->num_items + REV_WAVES_PER_BLOCK - 1) / REV_WAVES_PER_BLOCK;
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(REV_WAVES_PER_BLOCK * 64), lds, (hipStream_t)a->stream, p);
     return hipGetLastError() == hipSuccess ? 0 : 2;

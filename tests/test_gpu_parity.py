@@ -231,7 +231,7 @@ def test_device_start_locations_differential(mode, ours, monkeypatch):
     keep = np.ones(len(db), bool); keep[redo] = False
     np.testing.assert_array_equal(dsq[keep], sq[keep])
     np.testing.assert_array_equal(dst[keep], st[keep])
-    assert len(redo) <= 35, f"{len(redo)} of 700 sequences needed the host pass"
+    assert len(redo) == 0, f"{len(redo)} of 700 sequences needed the host pass"  # (doubtful rows: second pass on the device)
 
 
 REF_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
