@@ -230,6 +230,11 @@ OpalxDb* opalx_db_create_flat_device(const unsigned char* d_residues, const int6
 void opalx_release_cached(void);
 /* Number of searches of this process that ran on the streaming SW kernel (diagnostics and tests). */
 long long opalx_stream_launch_count(void);
+/* What the searches of this process ran on, cumulative (diagnostics and tests). Fills out[0 .. min(capacity, 8)):
+   [0] searches on the streaming SW kernels, [1] on the streaming NW/HW/OV kernels, [2] one-launch class kernels,
+   [3] class kernels launched one class at a time, [4] row-chunk launches of queries beyond one wave, [5] launches of the
+   32-bit rung, [6] alignments traced on the device, [7] alignments traced or started by the host. Returns 8. */
+int opalx_counters(long long* out, int capacity);
 void opalx_db_destroy(OpalxDb* db);
 int opalx_db_num_sequences(const OpalxDb* db);
 int64_t opalx_db_num_residues(const OpalxDb* db);

@@ -1,0 +1,478 @@
+// ladder.cpp -- the scheduler of one search: plays the role of the reference's precision ladder
+// (reference src/opal.cpp:496-535 searchDatabaseSW, :983-1021 searchDatabase<MODE>) with the rungs gfx950 has -- 16 bit
+// first, 32 bit for whatever saturates or cannot be proven safe -- and turns every rung into kernel launches (one-launch
+// class kernels, separate class launches, row chunks of long queries, streaming kernels).
+#include "opal_internal.hpp"
+
+namespace opal_host {
+
+static void fill_launch(OpalHipLaunch& a, const SearchCtx& c, int width, int swEndPass, int detectWrap, const int* work,
+                        int* ovfCounter) {
+    memset(&a, 0, sizeof a);
+    OpalxDb* db = c.db;
+    a.width = width; a.mode = c.mode; a.want_end = swEndPass; a.detect_wrap = detectWrap;
+    a.query = db->query.p; a.query_length = c.Q; a.score_matrix = db->matrix.p; a.alphabet_length = c.A;
+    a.gap_open = c.Go; a.gap_ext = c.Ge;
+    a.tokens = db->tokens.p; a.pair_token_offset = db->pairOff.p; a.pair_len = db->dPairLen.p; a.pair_seq = db->dPairSeq.p;
+    a.work = work;
+    a.out_score = c.dScore; a.out_end_query = c.wantEnd ? c.dEndQ : nullptr; a.out_end_target = c.wantEnd ? c.dEndT : nullptr;
+    a.overflow_count = ovfCounter; a.overflow_items = db->ovfItems.p;
+    a.sat_limit = c.satLimit; a.neg_pad = c.negPad;
+    a.stream = db->main();
+}
+
+// Queries that no single wave geometry can hold (more than 64 lanes x 40 rows, or a query profile
+// beyond the 160 KiB of LDS): the query is cut into row chunks processed top to bottom by one launch each;
+// the bottom row of a chunk (H and the F input of the next row, per column) travels through HBM.
+static int launch_chunked(const SearchCtx& c, int width, int swEndPass, int detectWrap, const int* work, int firstItem,
+                          int numItems, int* ovfCounter) {
+    int bestG = 0, bestS = 0;
+    for (int G = 64; G >= 1; G /= 2)
+        for (int S = OPAL_HIP_MAX_ROWS; S >= 1; S--) {
+            if (opal_hip_rows_supported(width, c.mode, swEndPass | 2, S) != S) continue;
+            if (opal_hip_lds_bytes(width, G, S, c.A) > 160 * 1024) continue;
+            if ((long long)G * S > (long long)bestG * bestS) { bestG = G; bestS = S; }
+            break;  // largest S for this G
+        }
+    if (const char* geo = getenv("OPAL_HIP_CHUNK_GEOMETRY")) {  // "G,S": test hook to force small chunks
+        int g = 0, r = 0;
+        if (sscanf(geo, "%d,%d", &g, &r) == 2 && opal_hip_rows_supported(width, c.mode, swEndPass | 2, r) == r &&
+            opal_hip_lds_bytes(width, g, r, c.A) <= 160 * 1024) { bestG = g; bestS = r; }
+    }
+    if (!bestG) {
+        fprintf(stderr, "[opal] alphabet of %d letters does not fit the on-chip query profile at width %d\n", c.A, width);
+        return OPAL_ERR_NO_SIMD_SUPPORT;
+    }
+    OpalxDb* db = c.db;
+    if (!db->boundary.ensure(16 * (db->numTokens + 8)) || !db->scratch.ensure(2 * (size_t)std::max(db->numSeqs, 1)))
+        return OPAL_ERR_NO_SIMD_SUPPORT;
+    int wpb = 4, ldsPad = 0;
+    pick_occupancy(kernel_vgprs(width, c.mode, swEndPass, 1, 0, bestS), opal_hip_lds_bytes(width, bestG, bestS, c.A), &wpb, &ldsPad);
+    // Equal chunks: with nchunks passes needed anyway, the smallest rows-per-lane value that still covers Q in that many
+    // passes (a 3000-aa query ran as 440 + 2560 rows at 40 rows per lane, 2 900 GCUPS; as 2 x 1500 at 24 rows per lane ...)
+    if (!getenv("OPAL_HIP_CHUNK_GEOMETRY")) {
+        const int passes = (c.Q + bestG * bestS - 1) / (bestG * bestS);
+        const int need = ((c.Q + passes - 1) / passes + bestG - 1) / bestG;  // rows per lane of a balanced chunk
+        const int rows = opal_hip_rows_supported(width, c.mode, swEndPass | 2, need);
+        if (rows && rows < bestS) bestS = rows;
+    }
+    const int cap = bestG * bestS;
+    const int nchunks = (c.Q + cap - 1) / cap;
+    const int firstRows = c.Q - (nchunks - 1) * cap;  // SW/HW/OV: the partial chunk is the first one
+    for (int ch = 0; ch < nchunks; ch++) {
+        int row0, rows;
+        if (c.mode == OPAL_MODE_NW) { row0 = ch * cap; rows = std::min(cap, c.Q - row0); }
+        else { row0 = ch == 0 ? 0 : firstRows + (ch - 1) * cap; rows = ch == 0 ? firstRows : cap; }
+        OpalHipLaunch a;
+        fill_launch(a, c, width, swEndPass, detectWrap, work, ovfCounter);
+        a.lanes_per_seq = bestG; a.rows_per_lane = bestS; a.waves_per_block = wpb;
+        a.first_item = firstItem; a.num_items = numItems;
+        a.chunk_flags = (ch > 0 ? 1 : 0) | (ch < nchunks - 1 ? 2 : 0);
+        a.chunk_row0 = row0; a.chunk_rows = rows;
+        a.boundary = db->boundary.p; a.scratch = db->scratch.p;
+        if (debug_on())
+            fprintf(stderr, "[opal] chunk %d/%d rows [%d,+%d) width=%d mode=%d end=%d G=%d rows/lane=%d waves/block=%d\n", ch + 1,
+                    nchunks, row0, rows, width, c.mode, swEndPass, bestG, bestS, wpb);
+        if (opal_hip_launch(&a)) return OPAL_ERR_NO_SIMD_SUPPORT;
+        count(CNT_CHUNK_LAUNCHES);
+        if (width == 32) count(CNT_WIDTH32);
+    }
+    return 0;
+}
+
+static int launch_range(const SearchCtx& c, int width, int swEndPass, int detectWrap, const int* work, int firstItem,
+                        int numItems, LenView lenOf, int* ovfCounter) {
+    if (numItems <= 0) return 0;
+    OpalxDb* db = c.db;
+    // skewed kernels (width 17, NW/HW/OV) add up to (rows + steps) * Ge to every value: allowed for a class when
+    // even its longest sequence stays inside the 16-bit range
+    auto skew_ok = [&](int item) {
+        const long long L0 = lenOf(item);
+        return std::min<long long>(c.Q, L0) * c.maxScore + (OPAL_HIP_MAX_ROWS + L0 + 64 + 4) * (long long)c.Ge < 32000;
+    };
+    const bool maySkew = width == 17 && c.mode != OPAL_MODE_SW && !work && !getenv("OPAL_HIP_NO_SKEW");
+    // One launch for all classes where a one-launch kernel exists (plain 16-bit, no re-run list): see dp_kernel.hpp.
+    const bool uberEligible = width == 17 && !work && !getenv("OPAL_HIP_NO_UBER") && !getenv("OPAL_HIP_LANES_PER_SEQ");
+    std::vector<LaunchClass> classes;
+    std::string key;
+    if (!work) {  // (re-run lists differ from search to search: planned every time)
+        char buf[160];
+        const char* e1 = getenv("OPAL_HIP_LANES_PER_SEQ"); const char* e2 = getenv("OPAL_HIP_TAIL_FRACTION"); const char* e3 = getenv("OPAL_HIP_TAIL_MODEL");
+        snprintf(buf, sizeof buf, "%d/%d/%d/%d/%d/%d/%d/%lld/%d/%d/%d|%s|%s|%s", width, c.mode, swEndPass, c.Q, c.A, c.Go, c.Ge, c.maxScore, firstItem, numItems,
+                 (int)uberEligible, e1 ? e1 : "", e2 ? e2 : "", e3 ? e3 : "");
+        key = buf;
+        auto it = db->planCache.find(key);
+        if (it != db->planCache.end()) {
+            const std::vector<int>& v = it->second;
+            for (size_t i = 0; i + 6 <= v.size(); i += 6) classes.push_back({v[i], v[i + 1], v[i + 2], v[i + 3], v[i + 4], v[i + 5]});
+        }
+    }
+    if (classes.empty()) {
+        classes = plan_classes(width, c.mode, swEndPass, maySkew && skew_ok(firstItem + numItems - 1), c.Q, c.A, lenOf, firstItem, numItems,
+                               uberEligible ? 4 : 0);
+        if (!work && !classes.empty()) {
+            std::vector<int>& v = db->planCache[key];
+            v.clear();
+            for (const LaunchClass& k : classes) v.insert(v.end(), {k.first, k.count, k.G, k.rows, k.wpb, k.ldsPad});
+        }
+    }
+    if (classes.empty() || getenv("OPAL_HIP_FORCE_CHUNKS"))
+        return launch_chunked(c, width, swEndPass, detectWrap, work, firstItem, numItems, ovfCounter);
+    if (uberEligible && classes.size() >= 2 && classes.size() <= 3) {
+        const LaunchClass& bulk = classes.back();
+        const int skewBulk = maySkew && skew_ok(bulk.first);
+        bool ok = bulk.wpb == 4 && bulk.ldsPad == 0 && opal_hip_uber_supported(c.mode, swEndPass, skewBulk, bulk.rows);
+        OpalHipUberLaunch u;
+        memset(&u, 0, sizeof u);
+        for (size_t ki = 0; ok && ki + 1 < classes.size(); ki++) {
+            const LaunchClass& k = classes[ki];
+            if ((maySkew && skew_ok(k.first)) != skewBulk) ok = false;  // a class that cannot use the skewed kernels: separate launches
+            else if (k.G == 2 * bulk.G) { u.long_first_item = k.first; u.long_num_items = k.count; u.long_priority = 1; }
+            else if (k.G == 4 * bulk.G) { u.longest_first_item = k.first; u.longest_num_items = k.count; u.longest_priority = 1; }
+            else ok = false;
+        }
+        if (ok) {
+            fill_launch(u.base, c, width, swEndPass, detectWrap, nullptr, ovfCounter);
+            u.base.lanes_per_seq = bulk.G; u.base.rows_per_lane = bulk.rows; u.base.waves_per_block = 4;
+            u.base.first_item = bulk.first; u.base.num_items = bulk.count; u.base.skew = skewBulk;
+            if (debug_on())
+                fprintf(stderr, "[opal] one launch width=%d mode=%d end=%d G0=%d rows=%d%s: bulk [%d,+%d) long [%d,+%d) longest [%d,+%d)\n", width,
+                        c.mode, swEndPass, bulk.G, bulk.rows, skewBulk ? " skew" : "", bulk.first, bulk.count, u.long_first_item,
+                        u.long_num_items, u.longest_first_item, u.longest_num_items);
+            if (opal_hip_launch_uber(&u)) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
+            count(CNT_ONE_LAUNCH);
+            return 0;
+        }
+    }
+    // The last class (the bulk of the database) runs on the main stream; the classes of long
+    // sequences run beside it on up to three side streams (one hardware queue each), forked from and
+    // joined back into the main stream with events, longest sequences enqueued first.
+    const int nside = std::min<int>((int)classes.size() - 1, 3);
+    void* fork = nullptr;
+    if (nside > 0) {
+        fork = db->event(0);
+        if (!fork || opal_hip_event_record(fork, db->main())) return OPAL_ERR_NO_SIMD_SUPPORT;
+    }
+    int err = 0;
+    bool recorded[3] = {false, false, false};
+    // Submission order matters: the side launches (long sequences) go first. Submitting the bulk launch first was
+    // measured at 2.2 ms instead of 1.55 ms on C2: its workgroups fill every CU and the long sequences start late.
+    for (size_t ki = 0; ki < classes.size() && !err; ki++) {
+        LaunchClass k = classes[ki];
+        const int skew = maySkew && skew_ok(k.first);
+        {   // the plan assumed the skewed kernels (every rows-per-lane value exists); a class that cannot use them
+            // takes the plain kernel's next instantiated value
+            const int rows = opal_hip_rows_supported(width, c.mode, swEndPass | (skew ? 4 : 0), k.rows);  // k.rows if it exists
+            if (rows && rows != k.rows && opal_hip_lds_bytes(width, k.G, rows, c.A) <= 160 * 1024) {
+                k.rows = rows;
+                pick_occupancy(kernel_vgprs(width, c.mode, swEndPass, 0, skew, rows), opal_hip_lds_bytes(width, k.G, rows, c.A), &k.wpb, &k.ldsPad,
+                               opal_hip_max_waves_per_block(width));
+            }
+        }
+        OpalHipLaunch a;
+        fill_launch(a, c, width, swEndPass, detectWrap, work, ovfCounter);
+        a.lanes_per_seq = k.G; a.rows_per_lane = k.rows; a.waves_per_block = k.wpb; a.lds_bytes_min = k.ldsPad;
+        a.first_item = k.first; a.num_items = k.count;
+        a.skew = skew;
+        const bool side = (int)ki < nside;
+        if (side) a.stream = db->stream((int)ki);
+        a.priority = side ? 1 : 0;
+        if (const char* pe = getenv("OPAL_HIP_SIDE_PRIO")) a.priority = side ? atoi(pe) : 0;  // tuning hook
+        if (debug_on())
+            fprintf(stderr, "[opal] launch width=%d mode=%d end=%d items=[%d,+%d) G=%d rows=%d waves/block=%d ldsPad=%d%s%s\n", width,
+                    c.mode, swEndPass, k.first, k.count, k.G, k.rows, k.wpb, k.ldsPad, skew ? " skew" : "", side ? " (side stream)" : "");
+        if (side && (!a.stream || opal_hip_stream_wait_event(a.stream, fork))) { err = 1; break; }
+        if (opal_hip_launch(&a)) { err = 1; break; }
+        count(CNT_CLASS_LAUNCHES);
+        if (width == 32) count(CNT_WIDTH32);
+        if (side) {
+            void* done = db->event(1 + (int)ki);
+            if (!done || opal_hip_event_record(done, a.stream)) { err = 1; break; }
+            recorded[ki] = true;
+        }
+    }
+    for (int i = 0; i < 3; i++)
+        if (recorded[i] && opal_hip_stream_wait_event(db->main(), db->event(1 + i))) err = 1;
+    if (err) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }  // nothing of this call stays in flight
+    return 0;
+}
+
+// reference opal.cpp:178-198 / :610-630 at 32 bits
+bool args_fit_int32(int Go, int Ge, const int* M, int A) {
+    const int lo = INT_MIN / 2, hi = INT_MAX / 2;
+    if (Go <= lo || hi <= Go || Ge <= lo || hi <= Ge) return false;
+    for (int i = 0; i < A * A; i++)
+        if (M[i] <= lo || hi <= M[i]) return false;
+    return true;
+}
+
+// Query, score matrix and zeroed counters reach the device as ONE copy from pinned memory (three separate small
+// copies and a memset cost ~10 us of stream time each, on a search whose kernels take 1.6 ms).
+int ensure_query_buffers(OpalxDb* db, const unsigned char* query, int Q, const int* M, int A) {
+    const size_t mb = (size_t)A * A * sizeof(int);
+    const size_t bytes = (16 + mb + (size_t)std::max(Q, 1) + 15) / 16 * 16;
+    if (!db->header.ensure(bytes, 1.5) || !db->hHeader.ensure(bytes, 1.5)) return 1;
+    unsigned char* h = db->hHeader.p;
+    memset(h, 0, 16);
+    memcpy(h + 16, M, mb);
+    if (Q) memcpy(h + 16 + mb, query, (size_t)Q);
+    if (opal_hip_memcpy_h2d(db->header.p, h, 16 + mb + (size_t)Q, db->main())) return 1;
+    db->ovfCount.p = (int*)db->header.p;
+    db->matrix.p = (int*)(db->header.p + 16);
+    db->query.p = db->header.p + 16 + mb;
+    return 0;
+}
+
+// Values for the degenerate shapes the kernels never see (empty query or empty target): the
+// boundary column/row of the DP matrix (same definitions as oracle/opal_oracle.c).
+static void degenerate_result(int mode, int Q, int L, int Go, int Ge, int* score, int* endQ, int* endT) {
+    if (mode == OPAL_MODE_SW) { *score = 0; *endQ = -1; *endT = -1; return; }
+    if (mode == OPAL_MODE_NW) {
+        const int n = Q + L;
+        *score = n ? (int)(-(long long)Go - (long long)(n - 1) * Ge) : 0;
+    } else if (mode == OPAL_MODE_HW) {
+        *score = (Q && !L) ? (int)(-(long long)Go - (long long)(Q - 1) * Ge) : 0;
+    } else {
+        *score = 0;
+    }
+    *endQ = Q - 1; *endT = L - 1;
+}
+
+// {caller index, score, endQ, endT} quads -> one upload, one scatter kernel
+static int write_degenerate(OpalxDb* db, const std::vector<int>& quads, int* dScore, int* dEndQ, int* dEndT) {
+    const int count = (int)(quads.size() / 4);
+    if (!count) return 0;
+    if (!db->quads.ensure(quads.size(), 1.5)) return 1;
+    if (opal_hip_memcpy_h2d(db->quads.p, quads.data(), quads.size() * sizeof(int), db->main())) return 1;
+    if (opal_hip_scatter_results(db->quads.p, count, dScore, dEndQ, dEndT, db->main())) return 1;
+    return opal_hip_stream_sync(db->main());  // `quads` is pageable host memory of the caller's frame
+}
+
+/*
+ * The scheduler. Plays the role of the reference's precision ladder (opal.cpp:496-535, :983-1021)
+ * with the rungs gfx950 has: 16-bit first, 32-bit for whatever saturates or cannot be
+ * proven safe. OPAL_OVERFLOW_SIMPLE and OPAL_OVERFLOW_BUCKETS give identical results in the
+ * reference (only the re-run granularity differs); here both map to the same schedule.
+ */
+int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, const int* M, int A,
+                       int searchType, int mode, int* dScore, int* dEndQ, int* dEndT, float* kernelMs, bool finalSync) {
+    if (kernelMs) *kernelMs = 0.f;
+    if (mode != OPAL_MODE_NW && mode != OPAL_MODE_HW && mode != OPAL_MODE_OV && mode != OPAL_MODE_SW)
+        return OPAL_ERR_INVALID_MODE;
+    if (!args_fit_int32(Go, Ge, M, A)) return OPAL_ERR_OVERFLOW;
+    if (Go < 0 || Ge < 0) {
+        fprintf(stderr, "[opal] negative gap penalties are not supported (opal.h: non-negative)\n");
+        return OPAL_ERR_OVERFLOW;
+    }
+    if (!device_ok()) return OPAL_ERR_NO_SIMD_SUPPORT;
+    const int wantEnd = searchType != OPAL_SEARCH_SCORE;
+    const int P = db->numPairs;
+    void* const st = db->main();
+    if (!st) return OPAL_ERR_NO_SIMD_SUPPORT;
+    int rc = 0;
+
+    // ---- degenerate shapes: answered from the matrix boundary
+    {
+        std::vector<int> quads;
+        auto add = [&](int idx, int L) {
+            int s, eq, et;
+            degenerate_result(mode, Q, L, Go, Ge, &s, &eq, &et);
+            if (!wantEnd) { eq = et = -1; }
+            quads.insert(quads.end(), {idx, s, eq, et});
+        };
+        for (int idx : db->emptySeqs) add(idx, 0);
+        if (Q == 0)
+            for (int i = 0; i < 2 * P; i++)
+                if (db->pairSeq[i] >= 0) add(db->pairSeq[i], db->pairLen[i]);
+        if (write_degenerate(db, quads, dScore, dEndQ, dEndT)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    }
+    if (Q == 0 || P == 0) return opal_hip_stream_sync(st) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
+
+    if (ensure_query_buffers(db, query, Q, M, A)) return OPAL_ERR_NO_SIMD_SUPPORT;  // (also zeroes the counters)
+
+    long long maxS = 0, minS = 0;
+    for (int i = 0; i < A * A; i++) { maxS = std::max<long long>(maxS, M[i]); minS = std::min<long long>(minS, M[i]); }
+    bool fits16 = Go <= 32767 && Ge <= 32767 && maxS <= 32767 && minS >= -32768;
+    if (const char* e = getenv("OPAL_HIP_FORCE_WIDTH")) { if (atoi(e) == 32) fits16 = false; }  // test / profiling hook
+
+    // Narrow rung: 17 = plain 16-bit, one sequence per lane (full-rate VALU, 4-byte LDS profile entries); 16 = packed
+    // pairs (half-rate VALU, 2-byte entries: queries whose 4-byte profile exceeds LDS); 18 = plain with 2-byte entries
+    // (+0.5 instructions per cell; experimental, on request only).
+    int narrow = 17;
+    if (const char* e = getenv("OPAL_HIP_NARROW")) { const int v = atoi(e); narrow = (v == 16 || v == 18) ? v : 17; }
+    {
+        auto fits = [&](int width) {  // does some single-launch geometry hold the query at this width?
+            for (int G = 1; G <= 64; G *= 2) {
+                const int need = (Q + G - 1) / G;
+                if (need > OPAL_HIP_MAX_ROWS) continue;
+                const int rows = opal_hip_rows_supported(width, mode, 0, need);
+                if (rows && opal_hip_lds_bytes(width, G, rows, A) <= 160 * 1024) return true;
+            }
+            return false;
+        };
+        const char* force = getenv("OPAL_HIP_NARROW_FORCE");  // "17": run width 17 in row chunks rather than switching width
+        // (width 18 measured SLOWER than the packed pairs on the 2000-aa workload, 15.1 vs 14.8 ms, so it is never
+        // chosen automatically: OPAL_HIP_NARROW=18 selects it for experiments)
+        if (narrow == 17 && !fits(17) && !(force && atoi(force) == 17)) {
+            narrow = 16;
+            // ... except where the plain kernels with 2-byte profile entries measure faster (2000-aa query, class kernels,
+            // 100 000 / 20 000 sequences: SW + end 4 150 against 3 350 / 3 720 against 2 970 GCUPS, OV 4 270 : 4 130 / 3 810 : 3 660,
+            // NW and HW 4 970 : 5 100 / 4 400 : 4 040)
+            if (!getenv("OPAL_HIP_NARROW") && fits(18) &&
+                ((mode == OPAL_MODE_SW && wantEnd) || mode == OPAL_MODE_OV || (mode != OPAL_MODE_SW && db->numSeqs < 50000)))
+                narrow = 18;
+        }
+        if (narrow == 18 && !fits(18)) narrow = 16;
+    }
+    // SW score-only searches with long queries stream their sequences through persistent waves (plain 16-bit arithmetic)
+    StreamPlan splan;
+    if (mode == OPAL_MODE_SW && fits16) splan = plan_stream(Q, A, mode, wantEnd, db->residues, db->pairLen.empty() ? 0 : db->pairLen[0], db->numSeqs);
+    const bool plain = narrow != 16 || splan.G;
+    const int satLimit = plain ? (int)(32767 - maxS) : 32767;
+    SearchCtx c{db, Q, A, Go, Ge, mode, wantEnd, dScore, dEndQ, dEndT, satLimit, mode == OPAL_MODE_SW ? -satLimit : 0, maxS};
+    const int nNarrow = narrow == 16 ? P : 2 * P;  // items of the narrow rung: pairs or sequences
+    const LenView pairLenOf{db->pairLen.data(), 2, nullptr};  // width-16 items are pairs
+    const LenView seqLenOf{db->pairLen.data(), 1, nullptr};   // width-17/18/32 items are pair*2+half
+    void* evStart = nullptr; void* evStop = nullptr;
+    if (kernelMs) { evStart = db->event(4); evStop = db->event(5); }
+    if (evStart) opal_hip_event_record(evStart, st);
+
+    if (mode == OPAL_MODE_SW) {
+        // rung 1: everything at 16 bits (if the inputs fit), saturated scores go to the re-run list.
+        // End locations are found in the same pass (the kernels record where a lane's running maximum
+        // was first reached).
+        int n32 = 0;
+        const int* work32 = nullptr;
+        std::vector<int> rerun;  // the re-run list, longest sequence first
+        if (fits16) {
+            if (splan.G) {
+                OpalHipLaunch a;
+                fill_launch(a, c, splan.width, wantEnd, 0, nullptr, db->ovfCount.p);
+                a.lanes_per_seq = splan.G; a.rows_per_lane = splan.rows;
+                a.first_item = 0; a.num_items = 2 * P;
+                if (debug_on())
+                    fprintf(stderr, "[opal] streaming launch width=%d G=%d rows=%d end=%d items=%d\n", splan.width, splan.G, splan.rows, wantEnd, 2 * P);
+                rc = opal_hip_launch_stream(&a, db->ovfCount.p + 2) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
+                count(CNT_STREAM_SW);
+            }
+            else if (narrow == 16) rc = launch_range(c, 16, wantEnd, 0, nullptr, 0, nNarrow, pairLenOf, db->ovfCount.p);
+            else rc = launch_range(c, narrow, wantEnd, 0, nullptr, 0, nNarrow, seqLenOf, db->ovfCount.p);
+            if (rc) return rc;
+            int cnt = 0;
+            // The re-run list can only be non-empty if some score can reach the rung's limit at all: with
+            // min(Q, longest sequence) * max(matrix) below it (a 300-aa query on BLOSUM50: 4 500 against 32 752) the
+            // count need not be read back, and the search has no host round trip between its launches and its end.
+            const bool canSaturate = (long long)std::min<long long>(Q, db->pairLen[0]) * maxS >= (long long)satLimit;
+            if (canSaturate && (opal_hip_memcpy_d2h(&cnt, db->ovfCount.p, sizeof(int), st) || opal_hip_stream_sync(st)))
+                return OPAL_ERR_NO_SIMD_SUPPORT;
+            if (cnt > 0) {
+                // The kernels append in completion order: sort the list by length so that the width-32 launch
+                // classes get the geometry of the sequences they really hold (not the database's longest).
+                rerun.resize((size_t)cnt);
+                if (opal_hip_memcpy_d2h(rerun.data(), db->ovfItems.p, (size_t)cnt * sizeof(int), st) || opal_hip_stream_sync(st))
+                    return OPAL_ERR_NO_SIMD_SUPPORT;
+                std::sort(rerun.begin(), rerun.end(), [&](int a, int b) {
+                    const int la = db->pairLen[(size_t)a], lb = db->pairLen[(size_t)b];
+                    return la != lb ? la > lb : a < b;
+                });
+                if (opal_hip_memcpy_h2d(db->ovfItems.p, rerun.data(), (size_t)cnt * sizeof(int), st) || opal_hip_stream_sync(st))
+                    return OPAL_ERR_NO_SIMD_SUPPORT;
+            }
+            n32 = cnt; work32 = db->ovfItems.p;
+        } else {
+            n32 = 2 * P; work32 = nullptr;  // items pair*2+half enumerate every sequence
+        }
+        // rung 2: width 32, with the reference's wrap test when a wrap is arithmetically possible
+        if (n32 > 0) {
+            const long long maxLen = db->pairLen[0];
+            const int detect = (double)std::min<long long>(Q, maxLen) * (double)maxS > (double)INT_MAX;
+            if (work32) {
+                const LenView rerunLenOf{db->pairLen.data(), 1, rerun.data()};
+                rc = launch_range(c, 32, wantEnd, detect, work32, 0, n32, rerunLenOf, db->ovfCount.p + 1);
+            } else {
+                rc = launch_range(c, 32, wantEnd, detect, nullptr, 0, n32, seqLenOf, db->ovfCount.p + 1);
+            }
+            if (rc) return rc;
+            if (detect) {
+                int wraps = 0;
+                if (opal_hip_memcpy_d2h(&wraps, db->ovfCount.p + 1, sizeof(int), st) || opal_hip_stream_sync(st))
+                    return OPAL_ERR_NO_SIMD_SUPPORT;
+                if (wraps) rc = OPAL_ERR_OVERFLOW;
+            }
+        }
+    } else {
+        // NW/HW/OV: width 16 where an a-priori bound proves that no value leaves the 16-bit range,
+        // width 32 otherwise. Pairs are sorted by length (descending) and both bounds grow with the
+        // length, so the width-32 pairs form a prefix of the pair list.
+        int p32 = 0;
+        if (!fits16) p32 = P;
+        else {
+            while (p32 < P) {
+                const long long L = db->pairLen[2 * (size_t)p32];
+                const long long lo = 3LL * Go + (Q + L + 2) * (long long)Ge - minS;  // -minS: diag + P must not wrap either
+                const long long hi = std::min<long long>(Q, L) * maxS;
+                if (lo < 32768 - 1 && hi < 32767) break;
+                p32++;
+            }
+        }
+        // Long queries on large databases: the 16-bit part as a stream of sequences through persistent waves
+        // (stream_kernel.hpp, diagonal-skewed kernels). The few sequences whose skewed values could leave 16 bits (the longest
+        // ones) run on the unskewed class body in the first workgroups of the same launch; if they hold more than 2 % of the
+        // residues the class kernels run everything.
+        StreamPlan gplan;
+        int q32 = p32;  // pairs [p32, q32): 16-bit, but not safe for the skewed stream kernels -> class kernels beside the stream
+        if (fits16 && p32 < P) {
+            long long moved = 0;
+            auto skew_safe = [&](long long L) {
+                return std::min<long long>(Q, L) * maxS + (OPAL_HIP_MAX_ROWS + L + 64 + 4) * (long long)Ge < 32000;
+            };
+            while (q32 < P && !skew_safe(db->pairLen[2 * (size_t)q32])) { moved += db->pairLen[2 * (size_t)q32] + db->pairLen[2 * (size_t)q32 + 1]; q32++; }
+            const char* sen = getenv("OPAL_HIP_STREAM");
+            if (q32 < P && (moved * 50 <= db->residues || (sen && *sen == '1')) && !getenv("OPAL_HIP_NO_SKEW")) {
+                gplan = plan_stream(Q, A, mode, wantEnd, db->residues - moved, db->pairLen[2 * (size_t)q32], db->numSeqs - 2 * q32);
+            }
+            if (!gplan.G) q32 = p32;
+        }
+        auto launch_global_stream = [&]() -> int {
+            OpalHipLaunch a;
+            fill_launch(a, c, gplan.width, 0, 0, nullptr, db->ovfCount.p);
+            a.lanes_per_seq = gplan.G; a.rows_per_lane = gplan.rows; a.skew = 1;
+            a.first_item = 2 * q32; a.num_items = 2 * (P - q32);
+            // the skew-unsafe sequences (the longest ones) ride along in the same launch on the unskewed class body
+            a.side_first_item = 2 * p32; a.side_num_items = 2 * (q32 - p32);
+            if (debug_on())
+                fprintf(stderr, "[opal] streaming launch mode=%d width=%d G=%d rows=%d items=[%d,+%d)\n", mode, gplan.width, gplan.G, gplan.rows,
+                        a.first_item, a.num_items);
+            count(CNT_STREAM_GLOBAL);
+            return opal_hip_launch_stream(&a, db->ovfCount.p + 2);
+        };
+        // 32-bit safety (our definition where the reference is undefined, see oracle/opal_oracle.c):
+        // sequences whose bound leaves [-2^30, 2^30] are not computed and the call returns OVERFLOW.
+        // Width-32 items (pair*2+half) enumerate the sequences in descending length, so the unsafe
+        // ones are a prefix of the item list.
+        int nBad = 0;
+        while (nBad < 2 * p32) {
+            const long long L = db->pairLen[nBad];
+            const long long lo = 3LL * Go + (Q + L + 2) * (long long)Ge;
+            const long long hi = std::min<long long>(Q, L) * maxS;
+            if (lo < (1LL << 30) && hi < (1LL << 30)) break;
+            nBad++;
+        }
+        if (nBad > 0) rc = OPAL_ERR_OVERFLOW;
+        if (2 * p32 > nBad && launch_range(c, 32, 0, 0, nullptr, nBad, 2 * p32 - nBad, seqLenOf, db->ovfCount.p + 1))
+            return OPAL_ERR_NO_SIMD_SUPPORT;
+        if (P > q32) {
+            const int e = gplan.G ? launch_global_stream()
+                        : narrow == 16 ? launch_range(c, 16, 0, 0, nullptr, p32, P - p32, pairLenOf, db->ovfCount.p)
+                                       : launch_range(c, narrow, 0, 0, nullptr, 2 * p32, 2 * (P - p32), seqLenOf, db->ovfCount.p);
+            if (e) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
+        }
+    }
+    if (evStop) opal_hip_event_record(evStop, st);
+    // (a caller that copies the results back on the same stream and waits for that copy needs no wait of its own here)
+    if ((finalSync || kernelMs) && opal_hip_stream_sync(st)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (kernelMs && evStart && evStop) *kernelMs = opal_hip_event_elapsed_ms(evStart, evStop);
+    return rc;
+}
+
+}  // namespace opal_host

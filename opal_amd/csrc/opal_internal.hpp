@@ -1,0 +1,276 @@
+// opal_internal.hpp -- declarations shared by the host translation units of libopal.so (not installed; the public
+// interface is include/opal.h + include/opal_hip.h). Plain C++: everything that touches the device goes through the
+// extern "C" shim of include/opal_hip.h.
+//
+//   db_pack.cpp       database packer, (re)fill of a device-resident database, cached contexts, opalx_db_* handles
+//   planner.cpp       launch planning: occupancy, length classes, streaming geometry
+//   ladder.cpp        the precision ladder (reference src/opal.cpp:496-535, :983-1021): launchers + search_core
+//   trace_driver.cpp  start cells and alignment operations on the device (drivers of rev_kernel.hip / trace_kernel.hip)
+//   multi_gpu.cpp     devices of a call, residue-balanced deal of sequences
+//   opal_api.cpp      the opal.h C API and the opalx_search_* entries on top of the above
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <climits>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <chrono>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "host_pool.hpp"
+#include "opal.h"
+#include "opal_hip.h"
+
+namespace opal_host {
+
+inline double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+inline bool debug_on() {
+    static const int on = [] { const char* e = getenv("OPAL_HIP_DEBUG"); return (e && *e && *e != '0') ? 1 : 0; }();
+    return on != 0;
+}
+
+// What the searches of this process ran on (diagnostics and tests: opalx_counters).
+enum Counter {
+    CNT_STREAM_SW = 0,   // searches on the streaming SW kernels
+    CNT_STREAM_GLOBAL,   // searches on the streaming NW/HW/OV kernels
+    CNT_ONE_LAUNCH,      // class kernels, all length classes as one grid
+    CNT_CLASS_LAUNCHES,  // class kernels launched one class at a time
+    CNT_CHUNK_LAUNCHES,  // row-chunk launches of queries beyond one wave
+    CNT_WIDTH32,         // launches of the 32-bit rung
+    CNT_DEVICE_TRACED,   // alignments traced on the device
+    CNT_HOST_TRACED,     // alignments traced (or started) by the host
+    CNT_COUNT
+};
+extern std::atomic<long long> g_counters[CNT_COUNT];
+inline void count(Counter c, long long n = 1) { g_counters[c].fetch_add(n, std::memory_order_relaxed); }
+
+// ------------------------------------------------------------------------------------ buffers
+// Device / pinned-host buffers that only ever grow: a cached context keeps them across calls.
+// (A cached context that once held a multi-gigabyte database does not keep those buffers for a later small one:
+// a buffer more than 4x too large and above 256 MiB is given back first.)
+template <typename T> struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;  // elements
+    bool ensure(size_t n, double slack = 1.0) {
+        if (p && cap > 4 * std::max<size_t>(n, 1) && cap * sizeof(T) > (256u << 20)) release();
+        if (n <= cap && p) return true;
+        opal_hip_free(p);
+        const size_t want = std::max<size_t>((size_t)((double)n * slack), 1);
+        p = (T*)opal_hip_malloc(want * sizeof(T));
+        cap = p ? want : 0;
+        return p != nullptr;
+    }
+    void release() { opal_hip_free(p); p = nullptr; cap = 0; }
+};
+template <typename T> struct PinBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t n, double slack = 1.0) {
+        if (p && cap > 4 * std::max<size_t>(n, 1) && cap * sizeof(T) > (256u << 20)) release();
+        if (n <= cap && p) return true;
+        opal_hip_host_free(p);
+        const size_t want = std::max<size_t>((size_t)((double)n * slack), 1);
+        p = (T*)opal_hip_host_malloc(want * sizeof(T));
+        cap = p ? want : 0;
+        return p != nullptr;
+    }
+    void release() { opal_hip_host_free(p); p = nullptr; cap = 0; }
+};
+
+// ------------------------------------------------------------------------------------ packed db
+// Sequences sorted by length (descending), paired up neighbour with neighbour. A pair is the unit a
+// wave slot works on at width 16 (two sequences packed in one register); its residues are stored
+// column by column as 16-bit tokens (low byte A, high byte B) so one 2-byte load feeds both.
+// The host only decides the order and gathers the residues into one buffer; the interleaving into
+// tokens is done on the device (opal_hip_pack_tokens) at HBM speed.
+struct HostPack {
+    std::vector<uint64_t> pairOff;  // [P] start of each pair's token stream
+    std::vector<int> pairLen;       // [2P]
+    std::vector<int> pairSeq;       // [2P] caller index, -1 = absent
+    std::vector<uint64_t> rawOff;   // [2P] where each sequence's residues start in the raw buffer
+    std::vector<int> emptySeqs;     // caller indices of zero-length sequences (answered on the host)
+    uint64_t rawBytes = 0;
+    uint64_t numTokens = 0;
+    int64_t residues = 0;
+    int numSeqs = 0;
+};
+
+void pack_order(int n, const int* lens, HostPack& out);
+
+}  // namespace opal_host
+
+struct OpalxDb {
+    int device = 0;
+    bool cached = false;  // a context of the opalSearchDatabase cache (returned to the free list, not destroyed)
+    int numSeqs = 0;
+    int numPairs = 0;
+    int64_t residues = 0;
+    size_t numTokens = 0;
+    // host copies the scheduler needs
+    std::vector<int> pairLen;  // [2P], pairs sorted by length of A descending
+    std::vector<int> pairSeq;
+    std::vector<int> emptySeqs;
+    // device: the packed database
+    opal_host::DevBuf<uint16_t> tokens;
+    opal_host::DevBuf<uint64_t> pairOff;
+    opal_host::DevBuf<int> dPairLen, dPairSeq;
+    // One "search header" per search, uploaded with a single copy: {counters[4], score matrix, query}. ovfCount[0] =
+    // length of the 16-bit rung's re-run list, [1] = width-32 wrap count.
+    opal_host::DevBuf<unsigned char> header;
+    opal_host::PinBuf<unsigned char> hHeader;
+    struct View32 { int* p = nullptr; } ovfCount, matrix;
+    struct View8 { unsigned char* p = nullptr; } query;
+    opal_host::DevBuf<int> ovfItems;  // [2P]
+    // device: per-search scratch
+    opal_host::DevBuf<unsigned char> boundary;  // 16 B per token: chunk-boundary rows of long queries (allocated on first use)
+    opal_host::DevBuf<int> scratch;             // [2N] per-sequence values carried across query chunks
+    opal_host::DevBuf<int> results;             // [3N] device staging of host-array searches
+    opal_host::DevBuf<int> quads;               // degenerate results on their way to the scatter kernel
+    // start-location pass (rev_kernel.hip): caller index -> pair*2+half, flags and the host-redo list
+    opal_host::DevBuf<int> seqItem;
+    bool seqItemValid = false;
+    opal_host::DevBuf<int> revFlags;
+    opal_host::DevBuf<int> redo;
+    // alignment operations on the device (trace_kernel.hip): flag matrices, operation strings, per-batch lists and outputs
+    opal_host::DevBuf<unsigned char> trDirs, trOps;
+    opal_host::DevBuf<uint64_t> trOff;
+    opal_host::DevBuf<int> trItems, trOut;
+    // launch plans of this database, keyed by what they depend on (cleared when the database is refilled): a search
+    // with the same query length, alphabet and mode re-uses the class split instead of recomputing it with the GPU idle
+    std::map<std::string, std::vector<int>> planCache;
+    // staging used while (re)filling the database
+    opal_host::DevBuf<unsigned char> raw;
+    opal_host::DevBuf<uint64_t> rawOff;
+    opal_host::PinBuf<unsigned char> hRaw;
+    opal_host::PinBuf<int> hResults;
+    // Streams: everything of one search runs on `main` (a non-blocking stream: no implicit ordering
+    // against the legacy null stream or against other contexts); long-sequence classes run on up to three
+    // HIGH-priority side streams (hardware queues of their own), forked from and joined back into `main` with events.
+    void* mainStream = nullptr;
+    void* streams[3] = {nullptr, nullptr, nullptr};
+    void* events[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // 0 fork, 1-3 joins, 4-5 timing
+    void* main() {
+        if (!mainStream) mainStream = opal_hip_stream_create();
+        return mainStream;
+    }
+    void* stream(int i) {
+        if (!streams[i]) { const char* e = getenv("OPAL_HIP_SIDE_STREAM_PRIO"); streams[i] = (e && *e == '0') ? opal_hip_stream_create() : opal_hip_stream_create_high(); }
+        return streams[i];
+    }
+    void* event(int i) {
+        if (!events[i]) events[i] = opal_hip_event_create();
+        return events[i];
+    }
+    // Wait for everything this handle may have in flight (used on error paths before buffers are reused).
+    void quiesce() {
+        for (void* st : streams) if (st) opal_hip_stream_sync(st);
+        if (mainStream) opal_hip_stream_sync(mainStream);
+    }
+};
+
+namespace opal_host {
+
+bool device_ok();
+void db_release(OpalxDb* db);
+
+enum RawKind { RAW_POINTERS, RAW_HOST_FLAT, RAW_DEVICE_FLAT };
+bool db_fill(OpalxDb* db, HostPack& hp, RawKind kind, const std::function<const unsigned char*(int)>& getSeq,
+             const unsigned char* flat, const int* orderLens = nullptr, int orderN = 0);
+
+// ------------------------------------------------------------------------------------ context cache
+// Contexts borrowed by opalSearchDatabase / opalSearchDatabaseCharSW: per device, a free list. A call takes one
+// (or creates it), fills it with its database, searches, and gives it back with all buffers kept. They are
+// never destroyed implicitly (opalx_release_cached() frees them on request): freeing device memory from a
+// static destructor races with the HIP runtime's own shutdown.
+struct ContextCache {
+    std::mutex m;
+    std::map<int, std::vector<OpalxDb*>> freeList;
+    OpalxDb* acquire(int device) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            auto& v = freeList[device];
+            if (!v.empty()) { OpalxDb* db = v.back(); v.pop_back(); return db; }
+        }
+        OpalxDb* db = new (std::nothrow) OpalxDb;
+        if (db) { db->cached = true; db->device = device; }
+        return db;
+    }
+    void give_back(OpalxDb* db) {
+        std::lock_guard<std::mutex> lk(m);
+        freeList[db->device].push_back(db);
+    }
+    static ContextCache& get() {
+        static ContextCache* c = new ContextCache;
+        return *c;
+    }
+};
+
+struct BorrowedContext {
+    OpalxDb* db;
+    explicit BorrowedContext(int device) : db(ContextCache::get().acquire(device)) {}
+    ~BorrowedContext() {
+        if (db) { db->quiesce(); ContextCache::get().give_back(db); }
+    }
+};
+
+// ------------------------------------------------------------------------------------ scheduling
+struct LaunchClass { int first, count, G, rows, wpb, ldsPad; };
+
+struct SearchCtx {
+    OpalxDb* db;
+    int Q, A, Go, Ge, mode, wantEnd;
+    int* dScore; int* dEndQ; int* dEndT;
+    int satLimit, negPad;  // width 17 (plain 16-bit) parameters
+    long long maxScore;    // largest matrix entry (>= 0)
+};
+
+// Lengths of the items of a launch range: item i has length lens[(idx ? idx[i] : i) * stride]
+// (width-16 items are pairs: stride 2 over pairLen; width-17/18/32 items are pair*2+half: stride 1; a re-run list
+// goes through idx).
+struct LenView {
+    const int* lens; int stride; const int* idx;
+    int operator()(int i) const { return lens[(size_t)(idx ? idx[i] : i) * (size_t)stride]; }
+};
+
+int kernel_vgprs(int width, int mode, int swEndPass, int multi, int skew, int rows);
+int pick_occupancy(int vgprs, size_t ldsBytes, int* wpbOut, int* ldsPadOut, int maxWpb = 8);
+std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass, int skew, int Q, int A, LenView lenOf, int first,
+                                      int count, int maxGFactor = 0);
+struct StreamPlan { int width = 0, G = 0, rows = 0; };
+StreamPlan plan_stream(int Q, int A, int mode, int wantEnd, long long residues, int longest, int numSeqs);
+
+bool args_fit_int32(int Go, int Ge, const int* M, int A);
+int ensure_query_buffers(OpalxDb* db, const unsigned char* query, int Q, const int* M, int A);
+int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, const int* M, int A, int searchType, int mode,
+                int* dScore, int* dEndQ, int* dEndT, float* kernelMs, bool finalSync = true);
+
+int search_starts(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, const int* M, int A, int mode,
+                  const int* dScore, const int* dEndQ, const int* dEndT, int* dStartQ, int* dStartT, int* redoHost,
+                  int* redoCount);
+// Operations traced on the device, by position in the shard: at(i)[0 .. len[i]), or len[i] < 0 (not traced: the host does it).
+struct TraceOut {
+    std::vector<std::vector<unsigned char>> chunks;  // one buffer of operation strings per device batch, as downloaded
+    std::vector<int> chunk;                          // [n] which one
+    std::vector<uint64_t> off;
+    std::vector<int> len;
+    const unsigned char* at(size_t i) const { return chunks[(size_t)chunk[i]].data() + off[i]; }
+};
+void device_traceback(OpalxDb* db, int Q, int Go, int Ge, int A, int mode, int n, const int* score, const int* endQ,
+                      const int* endT, const int* startQ, const int* startT, const int* dEndQ, const int* dEndT,
+                      const int* dStartQ, const int* dStartT, TraceOut& out);
+
+std::vector<int> call_devices();
+std::vector<std::vector<int>> deal_groups(const int* lens, int n, int parts);
+
+}  // namespace opal_host

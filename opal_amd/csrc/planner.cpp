@@ -1,0 +1,237 @@
+// planner.cpp -- launch planning for the database search: which wave geometry (lanes per sequence x rows per lane,
+// waves per workgroup) a kernel shape gets, how a length-sorted item range is cut into length classes, and when the
+// streaming kernels take over. Plays the part of the reference's loadNextSequence bookkeeping (reference
+// src/opal.cpp:472-490): deciding which lanes work on which sequence, done ahead of the launch instead of per column.
+#include "opal_internal.hpp"
+
+namespace opal_host {
+
+// Measured on MI355X (profiles/r01_ubench_*): packed-int16 and 32-bit max/min issue one wave
+// instruction per ~4 clocks per SIMD. A lane's column step costs about (12*rows + 25) instructions.
+static double step_clocks(int width, int rows) {
+    if (width == 17) return 2.15 * 9.5 * rows + 90.0;  // full-rate scalar 16-bit ops, fixed per-step overhead
+    if (width == 18) return 2.15 * 10.0 * rows + 90.0; // + one shift per two rows (2-byte profile entries)
+    return 4.3 * (11.0 * rows + 12.0);
+}
+
+// A wave that is alone on its critical path (the longest sequences of a database) issues one instruction per ~4.8
+// clocks whatever the pipe could take (profiles/r01_ubench_rowblock.txt: 42.9 clk per 9-instruction row on one wave):
+// clocks per column step of such a wave.
+static double lone_step_clocks(int width, int rows) {
+    if (width == 17 || width == 18) return 4.8 * (9.5 * rows + 16.0);
+    return 4.8 * (11.0 * rows + 14.0);
+}
+
+// Registers per lane of a kernel variant, asked once per variant from the code object.
+int kernel_vgprs(int width, int mode, int swEndPass, int multi, int skew, int rows) {
+    static std::mutex m;
+    static std::map<long long, int> cache;
+    const long long key = ((((long long)width * 8 + mode) * 4 + (swEndPass & 1) * 2 + (multi ? 1 : 0)) * 2 + (skew ? 1 : 0)) * 64 + rows;
+    std::lock_guard<std::mutex> lk(m);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    OpalHipLaunch a;
+    memset(&a, 0, sizeof a);
+    a.width = width; a.mode = mode; a.want_end = swEndPass & 1; a.chunk_flags = multi ? 1 : 0; a.skew = skew; a.rows_per_lane = rows;
+    const int v = opal_hip_kernel_vgprs(&a);
+    cache[key] = v;
+    return v;
+}
+
+// Measured: one wave per SIMD issues at half rate; two fill the VALU pipe of a pure-arithmetic loop (r01 ubench) but the
+// real kernels (LDS reads with bank conflicts, DPP hand-offs) run 10-16 % slower on 2 or 3 waves than on 4
+// (round 2: the OV kernel at 38 rows per lane, 129 VGPRs -> 2 waves, against 40 rows, 125 VGPRs -> 4 waves).
+static double issue_factor(int wavesPerSimd) {
+    return wavesPerSimd <= 1 ? 0.5 : wavesPerSimd == 2 ? 0.86 : wavesPerSimd == 3 ? 0.8 : 1.0;
+}
+
+/*
+ * Occupancy of one kernel shape (profiles/r01_ubench_rowblock.txt: one wave per SIMD issues at half
+ * rate, odd wave counts lose, two or four fill the pipe). Registers: 512 per lane per SIMD in granules
+ * of 8 (MI355X_MICROARCH.md, register files); LDS: 160 KiB per CU, the query profile is per workgroup;
+ * at most 32 waves per CU. Picks the waves per workgroup (and, when the register count alone would
+ * give an odd number of waves, an LDS request padded so that fewer workgroups fit) giving every SIMD
+ * an even number of waves. Returns waves per SIMD; `ldsPad` is the LDS bytes to request (0: the profile's own size).
+ */
+int pick_occupancy(int vgprs, size_t ldsBytes, int* wpbOut, int* ldsPadOut, int maxWpb) {
+    const int alloc = vgprs > 0 ? (vgprs + 7) / 8 * 8 : 128;
+    const int regWaves = std::max(1, std::min(8, 512 / alloc));
+    int bestW = 0, bestWpb = 4, bestPad = 0;
+    double bestScore = -1;
+    for (int wpb : {4, 8, 16}) {
+        if (wpb > maxWpb) continue;
+        const int perSimdPerBlock = wpb / 4;
+        const int blocksByLds = (int)std::max<size_t>(1, (160 * 1024) / std::max<size_t>(ldsBytes, 1));
+        int blocks = std::min({blocksByLds, 32 / wpb, regWaves / perSimdPerBlock});
+        if (blocks < 1) {
+            if (perSimdPerBlock > regWaves) continue;  // a workgroup of this size does not fit the register file
+            blocks = 1;
+        }
+        int w = blocks * perSimdPerBlock;
+        int pad = 0;
+        if (w > 2 && (w & 1)) {  // odd: drop to the even count below by padding the LDS request
+            const int wantBlocks = (w - 1) / perSimdPerBlock;
+            if (wantBlocks >= 1 && wantBlocks * perSimdPerBlock == w - 1) {
+                pad = (160 * 1024) / (wantBlocks + 1) + 1024;  // wantBlocks fit, wantBlocks+1 do not
+                if ((size_t)pad < ldsBytes) pad = 0;
+                if ((size_t)pad * wantBlocks > 160 * 1024) pad = 0;
+                if (pad) w = w - 1;
+            }
+        }
+        const double score = issue_factor(w) + 0.001 * w + (wpb == 4 ? 0.0005 : 0.0);
+        if (score > bestScore) { bestScore = score; bestW = w; bestWpb = wpb; bestPad = pad; }
+    }
+    *wpbOut = bestWpb;
+    *ldsPadOut = bestPad;
+    return bestW;
+}
+/*
+ * Split the item range [first, first+count) (sorted by length, longest first) into classes of
+ * equal wave geometry. Each sequence (pair) is spread over G lanes; a wave therefore needs
+ * len+G-1 column steps of `rows` rows each. Short sequences want a small G (little fill/drain and
+ * per-step overhead), the few very long ones a large G so that no single wave outlives the rest of
+ * the launch. `lenOf(i)` is the length of item i.
+ */
+std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass, int skew, int Q, int A, LenView lenOf, int first,
+                                      int count, int maxGFactor) {
+    std::vector<LaunchClass> out;
+    if (count <= 0) return out;
+    struct Cand { int G, rows, wpb, ldsPad; double eff; };
+    std::vector<Cand> cands;
+    const char* forceG = getenv("OPAL_HIP_LANES_PER_SEQ");
+    double lenSum = 0;
+    const int sample = std::max(1, count / 4096);
+    int nsamp = 0;
+    for (int i = 0; i < count; i += sample) { lenSum += lenOf(first + i); nsamp++; }
+    const double lavg = lenSum / nsamp;
+    for (int G = 1; G <= 64; G *= 2) {
+        if (forceG && *forceG && atoi(forceG) != G) continue;
+        const int need = (Q + G - 1) / G;
+        if (need > OPAL_HIP_MAX_ROWS) continue;
+        // rows per lane: the smallest instantiated value, or up to 3 more if that one compiles to a register count
+        // that leaves fewer waves per SIMD (a few padding rows cost less than an odd or halved occupancy)
+        Cand best{0, 0, 4, 0, -1.0};
+        int prevRows = 0;
+        for (int want = need; want <= need + 3 && want <= OPAL_HIP_MAX_ROWS; want++) {
+            const int rows = opal_hip_rows_supported(width, mode, swEndPass | (skew ? 4 : 0), want);
+            if (!rows || rows == prevRows) continue;
+            prevRows = rows;
+            const size_t lds = opal_hip_lds_bytes(width, G, rows, A);
+            if (lds > 160 * 1024) continue;
+            if (G > 1 && (G / 2) * rows >= Q && !(forceG && *forceG)) continue;  // half the lanes would hold padding only
+            int wpb = 4, ldsPad = 0;
+            const int waves = pick_occupancy(kernel_vgprs(width, mode, swEndPass, 0, skew, rows), lds, &wpb, &ldsPad, opal_hip_max_waves_per_block(width));
+            const double eff = ((double)Q / (G * rows)) * (rows / step_clocks(width, rows)) * (lavg / (lavg + G - 1)) * issue_factor(waves);
+            if (debug_on())
+                fprintf(stderr, "[opal] plan width=%d mode=%d G=%d rows=%d: %d VGPRs, %zu B LDS -> %d waves/SIMD (waves/block %d, ldsPad %d), eff %.5f\n",
+                        width, mode, G, rows, kernel_vgprs(width, mode, swEndPass, 0, skew, rows), lds, waves, wpb, ldsPad, eff);
+            if (eff > best.eff) best = Cand{G, rows, wpb, ldsPad, eff};
+        }
+        if (best.eff > 0) cands.push_back(best);
+    }
+    if (cands.empty()) return out;
+    size_t base = 0;
+    for (size_t i = 1; i < cands.size(); i++)
+        if (cands[i].eff > cands[base].eff * 1.02) base = i;
+    // one-launch kernels hold the bodies for G0, 2*G0 and 4*G0 lanes per sequence: keep the classes inside that chain
+    if (maxGFactor > 0)
+        while (cands.size() > base + 1 && cands.back().G > maxGFactor * cands[base].G) cands.pop_back();
+    // time of the whole range at the base geometry if the machine were perfectly filled
+    const double simds = 1024.0;
+    const int slotsBase = 64 / cands[base].G;
+    const double totalClocks = lenSum * sample / slotsBase * step_clocks(width, cands[base].rows) / simds;
+    const char* budEnv = getenv("OPAL_HIP_TAIL_FRACTION");
+    const double budget = std::max(totalClocks * (budEnv && *budEnv ? atof(budEnv) : 0.7), 20000.0);
+    // walk from the longest item: the smallest geometry (>= base) whose lone-wave time fits the budget
+    size_t ci = cands.size() - 1;
+    int start = first;
+    // A class of long sequences is a handful of waves, each the oldest wave of its SIMD and therefore running at the
+    // lone-wave rate: that is the time a boundary candidate is judged by. (Round 2, C2 database, 100 000 / 50 000
+    // sequences: 1.594 -> 1.567 ms and 1.013 -> 0.967 ms against the pipe-rate model; OPAL_HIP_TAIL_MODEL=pipe restores it.)
+    const char* tm = getenv("OPAL_HIP_TAIL_MODEL");
+    const bool pipeModel = tm && !strcmp(tm, "pipe");
+    auto fits = [&](size_t c, int len) {
+        const double per = pipeModel ? step_clocks(width, cands[c].rows) : lone_step_clocks(width, cands[c].rows);
+        return (len + cands[c].G - 1) * per <= budget;
+    };
+    auto cls = [&](int s, int n, size_t c) { return LaunchClass{s, n, cands[c].G, cands[c].rows, cands[c].wpb, cands[c].ldsPad}; };
+    int i = first;
+    while (i < first + count) {
+        const int len = lenOf(i);
+        size_t want = base;
+        while (want + 1 < cands.size() && !fits(want, len)) want++;
+        if (i == first) ci = want;
+        if (want != ci) {
+            // close the current class at a multiple of its slots-per-wave
+            out.push_back(cls(start, i - start, ci));
+            start = i;
+            ci = want;
+        }
+        if (ci == base) break;  // everything from here on uses the base geometry
+        i += 64 / cands[ci].G;
+    }
+    out.push_back(cls(start, first + count - start, ci));
+    // Two side streams by default (three classes). HIP multiplexes normal-priority streams onto 4 hardware queues
+    // shared with the caller's own streams: with normal-priority side streams two launches of one search could land on
+    // the same queue and run one after the other (2.3 ms instead of 1.6 ms on C2, depending on how many streams the
+    // process had created: scripts/gpu_queue_probe.py). The side streams are therefore HIGH-priority streams, which
+    // get queues of their own; with them three side streams work too but measure 1-3 % slower than two.
+    const char* nsEnv = getenv("OPAL_HIP_SIDE_STREAMS");  // tuning hook: 3 side streams
+    const size_t maxClasses = (nsEnv && atoi(nsEnv) == 3) ? 4 : 3;
+    while (out.size() > maxClasses) {  // fold the two longest classes together
+        out[1].count += out[0].count;
+        out[1].first = out[0].first;
+        out[1].G = out[0].G; out[1].rows = out[0].rows; out[1].wpb = out[0].wpb; out[1].ldsPad = out[0].ldsPad;
+        out.erase(out.begin());
+    }
+    return out;
+}
+
+// Streaming SW score search (stream_kernel.hpp): which geometry, if any. Long queries need 32 or 64 lanes per sequence,
+// where the class kernels lose (G-1)/(L+G-1) of their steps to pipeline fill and drain; the streaming kernel has no
+// such loss, so it is chosen by the cost of a column step per useful query row alone.
+StreamPlan plan_stream(int Q, int A, int mode, int wantEnd, long long residues, int longest, int numSeqs) {
+    StreamPlan best;
+    const char* en = getenv("OPAL_HIP_STREAM");          // "0": never, "1": whenever a geometry exists (tests), unset: long queries
+    if (en && *en == '0') return best;
+    const bool force = en && *en == '1';
+    const char* forceG = getenv("OPAL_HIP_LANES_PER_SEQ");
+    const char* forceW = getenv("OPAL_HIP_NARROW");
+    double bestCost = 1e30;
+    for (int width : {17, 18}) {
+        if (forceW && *forceW && atoi(forceW) != width && (atoi(forceW) == 17 || atoi(forceW) == 18)) continue;
+        for (int G = 1; G <= 64; G *= 2) {
+            if (forceG && *forceG && atoi(forceG) != G) continue;
+            const int need = (Q + G - 1) / G;
+            if (need > OPAL_HIP_MAX_ROWS) continue;
+            const int rows = opal_hip_stream_rows_supported(width, mode, wantEnd, need);
+            if (!rows || opal_hip_stream_lds_bytes(width, mode, G, rows, A) > 160 * 1024) continue;
+            const double perRow = (mode == OPAL_MODE_SW ? 9.0 + (wantEnd ? 1.5 : 0.0) : 6.0) + (width == 18 ? 0.5 : 0.0);
+            const double cost = (perRow * rows + 30.0) * G / Q;
+            if (cost < bestCost) { bestCost = cost; best.width = width; best.G = G; best.rows = rows; }
+        }
+    }
+    if (best.G && !force && (wantEnd || mode != OPAL_MODE_SW) && best.G < 32) best = StreamPlan();  // (end locations, NW/HW/OV at 16 lanes or fewer: class kernels, unmeasured otherwise)
+    if (best.G && !force) {
+        // A sequence stays on its G lanes from its first column to its last: the longest one (handed out first) sets a
+        // floor of (longest + G) steps at the rate of a wave that ends up alone on its SIMD (~3.5 clk per instruction).
+        // On a small database that floor exceeds the time of the whole search and the class kernels (4*G lanes for
+        // the longest sequences) win: measured with 20 000 sequences, 1000-aa query 2.6 ms against 1.7 ms; with 100 000
+        // sequences 4.9 ms against 7.0 ms.
+        const double stepInstr = (best.width == 18 ? 9.5 : 9.0) * best.rows + 30.0;
+        const double total = (double)residues * best.G / 64.0 * stepInstr * 2.15 / 1024.0;
+        const double crit = ((double)longest + best.G) * stepInstr * 3.5;
+        if (best.G >= 32) {
+            if (crit > 1.5 * total) best = StreamPlan();
+        } else {
+            // 16 lanes per sequence or fewer: the class kernels lose little to fill and drain, and streaming only wins
+            // (2-4 %: 513-aa query x 625 000 sequences 6 790 -> 7 050 GCUPS, 300-aa x 1 000 000 7 230 -> 7 390) when every
+            // slot works through many sequences; with ~3 per slot (300-aa x 100 000) it is 14 % slower.
+            const double perSlot = (double)numSeqs / (4096.0 * (64 / best.G));
+            if (crit > 0.5 * total || perSlot < 20.0) best = StreamPlan();  // (300-aa query: break-even at ~18 sequences per slot, 600 000 sequences)
+        }
+    }
+    return best;
+}
+
+}  // namespace opal_host
