@@ -44,11 +44,28 @@ def _residue_table():
     return cdf, codes
 
 
-def lengths(seed, first, count):
-    """int32[count]: lengths of sequences first .. first+count-1 of database `seed`."""
+SPROT_SEQS = 541762     # UniProtKB/Swiss-Prot as the reference was published on it (reference aligner_comparison.md:6)
+SPROT_MAX_LEN = 35213   # its longest entry (titin)
+SPROT_STRIDE = 36000    # residue-stream stride of the "sprot" distribution (see database_subset)
+
+
+def lengths(seed, first, count, dist="c2"):
+    """int32[count]: lengths of sequences first .. first+count-1 of database `seed`.
+
+    dist "c2" (SURVEY.md 8d): log-normal clamped to [30, 5000].
+    dist "sprot": the same body with the long tail a real protein database has -- 0.2 % of the sequences are drawn from
+    a Pareto tail L = 2000 * (1-u)^(-1/1.6), capped at 35 213 (on 541 762 sequences: ~250 beyond 5 000 residues, ~80
+    beyond 10 000, ~10 at the cap)."""
     u1 = _uniform(seed, 2 * first, 2 * count)
     z = np.sqrt(-2.0 * np.log(u1[0::2])) * np.cos(2.0 * np.pi * u1[1::2])
-    return np.clip(np.rint(np.exp(5.70 + 0.55 * z)), 30, 5000).astype(np.int32)
+    body = np.clip(np.rint(np.exp(5.70 + 0.55 * z)), 30, 5000)
+    if dist == "c2":
+        return body.astype(np.int32)
+    if dist != "sprot":
+        raise ValueError(dist)
+    ut = _uniform(seed ^ 0x7A11, 2 * first, 2 * count)
+    tail = np.minimum(np.rint(2000.0 * (1.0 - ut[1::2]) ** (-1.0 / 1.6)), SPROT_MAX_LEN)
+    return np.where(ut[0::2] < 0.002, tail, body).astype(np.int32)
 
 
 def _residues(seed, start, count):
@@ -89,10 +106,12 @@ def database(num_seqs, seed=42, first=0):
     return out, offsets, lens
 
 
-def database_subset(ids, seed=42, lens=None):
+def database_subset(ids, seed=42, lens=None, stride=5000):
     """The sequences with GLOBAL indices `ids` (any order, any subset) of database `seed`, as
     (residues, offsets, lens). Used by the multi-GPU sharding (opal_amd/shard.py): a rank owns a
-    length-balanced, non-contiguous set of sequences and generates exactly those."""
+    length-balanced, non-contiguous set of sequences and generates exactly those.
+    `stride`: residue k of sequence g is element g*stride + k of the residue stream (5000 for the clamped "c2"
+    lengths; SPROT_STRIDE for the "sprot" lengths, which must be passed in `lens`)."""
     ids = np.asarray(ids, dtype=np.int64)
     n = len(ids)
     if lens is None:
@@ -109,7 +128,7 @@ def database_subset(ids, seed=42, lens=None):
         m = int(offsets[b] - offsets[a])
         loc = np.repeat(np.arange(a, b, dtype=np.int64), lens[a:b])
         pos = np.arange(m, dtype=np.int64) - (offsets[a:b] - offsets[a])[loc - a]
-        c = (ids[loc] * 5000 + pos).astype(np.uint64)
+        c = (ids[loc] * stride + pos).astype(np.uint64)
         with np.errstate(over="ignore"):
             z = rseed + (c + np.uint64(1)) * _GOLDEN
             z = (z ^ (z >> np.uint64(30))) * _M1
@@ -134,7 +153,7 @@ def _lengths_of(seed, ids):
     return out
 
 
-def residues_device(ids, lens, seed, device):
+def residues_device(ids, lens, seed, device, stride=5000):
     """Same residues as database_subset(ids)[0], generated ON THE GPU with torch integer arithmetic
     (bench.py: a 5-million-sequence shard is 1.7 GB of residues; numpy needs minutes for that).
     Lengths come from the host (float64 log/cos are not guaranteed bit-identical on the device); the
@@ -171,7 +190,7 @@ def residues_device(ids, lens, seed, device):
             continue
         loc = torch.repeat_interleave(torch.arange(a, b, device=device), lens_t[a:b])
         pos = torch.arange(m, device=device, dtype=torch.int64) - (offs_t[loc] - int(offsets[a]))
-        c = ids_t[loc] * 5000 + pos
+        c = ids_t[loc] * stride + pos
         z = rseed + (c + 1) * G
         z = (z ^ lsr(z, 30)) * M1
         z = (z ^ lsr(z, 27)) * M2

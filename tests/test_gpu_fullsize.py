@@ -156,20 +156,22 @@ def test_c4_shard_all_modes(c4shard, oracle):
         np.testing.assert_array_equal(out[mode][2][pick], et, err_msg=mode)
 
 
-def test_c5_long_query_buckets(oracle):
-    """BASELINE.json configs[4]: a 2000-aa query (16-bit rung, then the 32-bit re-run) on 100 000 sequences,
-    OPAL_OVERFLOW_BUCKETS. BLOSUM50 cannot push a 2000-aa alignment past 16 bits, so the forced
-    overflow comes from planted self-matches under a x3-scaled matrix, as the survey prescribes."""
+def test_c5_long_query_buckets(c4shard, oracle):
+    """BASELINE.json configs[4] at its stated size: a 2000-aa query on one rank's share of the C4 database (625 000 of the
+    5 000 000 sequences, shard 3 of the 8-way deal), OPAL_OVERFLOW_BUCKETS, all four modes with end locations + SW
+    score-only: size-independent properties on everything, bit-exact oracle comparison on a sample. BLOSUM50 cannot push a
+    2000-aa alignment past 16 bits, so the forced 16 -> 32 bit re-run comes from planted self-matches under
+    a x3-scaled matrix, as the survey prescribes (second half of the test)."""
     from opal_amd import synth
-    from opal_amd.api import PreparedDb
     from opal_amd.score_matrix import blosum50
-    n = 100000
-    res, offs, lens = synth.database(n, seed=42)
+    pdb, lens, owned = c4shard["pdb"], c4shard["lens"], c4shard["owned"]
+    assert 600000 < len(owned) < 650000
     q = synth.query(2000, seed=7)
     m = blosum50()[1]
-    pdb = PreparedDb(res, offs)
+    Q = len(q)
     pick = _sample(lens, 60, seed=5, n_edge=10)
-    db = [res[offs[i]:offs[i + 1]] for i in pick]
+    sres, soffs, _ = synth.database_subset(owned[pick], 42, lens=lens[pick])
+    db = [sres[soffs[i]:soffs[i + 1]] for i in range(len(pick))]
     out = {}
     for mode in ("SW", "OV", "HW", "NW"):
         rc, s, eq, et = pdb.search(q, 3, 1, m, 1, oracle_lib.MODES[mode], overflow_method=1)
@@ -179,9 +181,18 @@ def test_c5_long_query_buckets(oracle):
         np.testing.assert_array_equal(s[pick], so, err_msg=mode)
         np.testing.assert_array_equal(eq[pick], oq, err_msg=mode)
         np.testing.assert_array_equal(et[pick], ot, err_msg=mode)
+        live = s != 0 if mode == "SW" else np.ones(len(s), bool)
+        assert (eq[live] >= 0).all() and (eq[live] < Q).all() and (et[live] >= 0).all() and (et[live] < lens[live]).all()
+        if mode in ("NW", "HW"):
+            assert (eq == Q - 1).all()
+        if mode == "NW":
+            assert (et == lens - 1).all()
     assert (out["SW"] >= out["OV"]).all() and (out["OV"] >= out["HW"]).all() and (out["HW"] >= out["NW"]).all()
     rc, s0, _, _ = pdb.search(q, 3, 1, m, 0, oracle_lib.MODE_SW, overflow_method=1)
+    assert rc == 0
     np.testing.assert_array_equal(s0, out["SW"])
+    from opal_amd.api import PreparedDb
+    res, offs, _ = synth.database(3000, seed=42)
     # forced 16 -> 32 bit: x3 matrix, the query itself (and two mutilated copies) planted among 3000 sequences
     m3 = (m * 3).astype(np.int32)
     seqs = [res[offs[i]:offs[i + 1]] for i in range(3000)]
@@ -198,6 +209,65 @@ def test_c5_long_query_buckets(oracle):
     np.testing.assert_array_equal(eq[chk], oq)
     np.testing.assert_array_equal(et[chk], ot)
     assert (s[sorted(planted)] > 32767).all()
+
+
+def test_c4_eight_way_equals_unsharded(monkeypatch):
+    """BASELINE.json configs[3] whole: P18080 x all 5 000 000 sequences. Once unsharded on the device-resident database
+    (opalx_search_device), once through opalSearchDatabase itself with the in-library sharding over eight contexts
+    (OPAL_HIP_DEVICES = eight times this box's one GPU: the deal, the per-shard pipelines and the host-side merge are
+    those of an 8-GPU call) -- identical score / end-cell arrays, SW score-only and HW with end locations."""
+    import ctypes as C
+    import torch
+    import zlib
+    from opal_amd import _lib, synth
+    from opal_amd.api import OpalSearchResult, PreparedDb
+    from opal_amd.fasta import read_fasta
+    from opal_amd.score_matrix import blosum50
+    import cases
+    n = 5000000
+    dev = torch.device("cuda", 0)
+    lens = synth.lengths(42, 0, n)
+    d_res, offs = synth.residues_device(np.arange(n, dtype=np.int64), lens, 42, dev)
+    torch.cuda.synchronize()
+    q = read_fasta(os.path.join(cases.DATA, "query_P18080.fasta"), blosum50()[0])[0]
+    m = np.ascontiguousarray(blosum50()[1], np.int32)
+    pdb = PreparedDb(None, offs, device_ptr=d_res.data_ptr())
+    out = torch.empty(3 * n, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    want = {}
+    for mode, st in (("SW", 0), ("HW", 1)):
+        out.fill_(-7)
+        torch.cuda.synchronize()
+        rc, _ = pdb.search_device(q, 3, 1, m, st, oracle_lib.MODES[mode], out[:n].data_ptr(), out[n:2 * n].data_ptr() if st else 0,
+                                  out[2 * n:].data_ptr() if st else 0)
+        assert rc == 0
+        want[mode] = out.cpu().numpy().reshape(3, n).copy()
+    pdb.close()
+    res_host = d_res.cpu().numpy()
+    del d_res, out
+    torch.cuda.empty_cache()
+    L = _lib.lib()
+    lens32 = np.ascontiguousarray(lens, np.int32)
+    ptrs = np.ascontiguousarray(res_host.ctypes.data + np.asarray(offs[:-1], dtype=np.uint64), dtype=np.uint64)
+    arr = (OpalSearchResult * n)()
+    words = np.frombuffer(arr, dtype=np.int32).reshape(n, 10)
+    rptrs = np.ascontiguousarray(C.addressof(arr) + 40 * np.arange(n, dtype=np.uint64), dtype=np.uint64)
+    monkeypatch.setenv("OPAL_HIP_DEVICES", "0,0,0,0,0,0,0,0")
+    for mode, st in (("SW", 0), ("HW", 1)):
+        words[:, 0] = 0
+        words[:, 2:6] = -1
+        rc = L.opalSearchDatabase(q.ctypes.data_as(C.POINTER(C.c_ubyte)), len(q), C.c_void_p(ptrs.ctypes.data), n,
+                                  lens32.ctypes.data_as(C.POINTER(C.c_int)), 3, 1, m.ctypes.data_as(C.POINTER(C.c_int)), int(m.shape[0]),
+                                  C.c_void_p(rptrs.ctypes.data), st, oracle_lib.MODES[mode], 1)
+        assert rc == 0
+        assert (words[:, 0] == 1).all()
+        assert zlib.crc32(np.ascontiguousarray(words[:, 1]).tobytes()) == zlib.crc32(want[mode][0].tobytes()), f"{mode}: 8-way scores differ"
+        if st:
+            np.testing.assert_array_equal(words[:, 3], want[mode][1], err_msg="endQ")  # struct order: endLocationTarget, then Query
+            np.testing.assert_array_equal(words[:, 2], want[mode][2], err_msg="endT")
+        else:
+            assert (words[:, 2] == -1).all() and (words[:, 3] == -1).all()
+    L.opalx_release_cached()
 
 
 def _run_bench(extra, env_extra=None):
