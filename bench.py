@@ -3,18 +3,23 @@
 
 A "step" is one pass of the hot path over one batch: one query against the whole synthetic protein
 database shard of this rank, database already packed and resident in HBM, results written to device
-buffers in caller order, then ONE gather of the per-sequence results to rank 0 (the path's only exchange).
+buffers in database order, then (N > 1 only) ONE gather of the per-sequence results to rank 0 -- the path's only exchange.
 
 Workloads (BASELINE.json `configs`):
   c2 (default)  300-aa synthetic query x 100 000 synthetic sequences PER GPU, SW score-only, gaps 11/1  -> "weak"
   c3            the c2 database, --mode NW|HW|OV|SW with end locations
   c4            P18080 (513 aa) x 5 000 000 synthetic sequences in total, sharded over the GPUs        -> "strong"
   c5            2000-aa synthetic query on the c4 database (16 -> 32 bit re-run ladder)                 -> "strong"
-The global database is dealt to the ranks in 64-sequence groups balancing the residue count
-(opal_amd/shard.py); rank 0 puts the gathered results back into database order.
+  sprot         the shape the reference was published on (reference aligner_comparison.md:6-34): 541 762 sequences with a
+                Swiss-Prot-like length tail (up to 35 213 residues), gaps 3/1, SW score-only, the published queries
+                O74807 / P19930 / Q3ZAI3 / P18080 (--query-fasta picks the timed one, default P18080)  -> "strong"
+With N > 1 the global database is dealt to the ranks in 64-sequence groups balancing the residue count
+(opal_amd/shard.py); rank 0 puts the gathered results back into database order with one index operation.
+With N = 1 the rank owns the database in its own order: the library writes every result straight to its database index.
 
 `--gpus N` with no RANK in the environment starts the N ranks itself (fresh child processes, before this
-process touches torch or the GPU) and relays rank 0's JSON line; under torchrun (RANK set) it runs as one rank.
+process touches torch or the GPU), watches them (first failure or the deadline kills the rest) and relays rank 0's
+JSON line; under torchrun (RANK set) it runs as one rank.
 
 GCUPS = queryLength * sum(dbSeqLengths) / 1e9 / seconds (reference src/opal_aligner.cpp:203-207;
 cells of overflow re-runs are not counted).  Prints ONE JSON line on rank 0.
@@ -26,6 +31,7 @@ import os
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 import zlib
 
@@ -40,10 +46,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 # v_sub_u16 clamp / v_max_i16 issue one wave-instruction per 2 clocks per SIMD; a Smith-Waterman cell costs 9 of
 # them (6 for the skewed NW/HW/OV kernels), a wave-instruction covers 64 lanes = 64 cells.
 SIMDS, CLOCK_HZ, CLK_PER_INSTR, LANES = 1024, 2.4e9, 2.0, 64.0
+PUBLISHED_S = {"O74807": 5.2, "P19930": 6.9, "Q3ZAI3": 10.8, "P18080": 14.7}  # reference aligner_comparison.md:32 (OpAl AVX2, i7-4770K, 1 thread)
 
 
-def valu_peak_gcups(instr_per_cell):
-    return SIMDS * CLOCK_HZ / (instr_per_cell * CLK_PER_INSTR / LANES) / 1e9
+def valu_peak_gcups(instr_per_cell, clock_hz=CLOCK_HZ):
+    return SIMDS * clock_hz / (instr_per_cell * CLK_PER_INSTR / LANES) / 1e9
 
 
 def parse_args(argv=None):
@@ -51,11 +58,11 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5", "sprot"])
     ap.add_argument("--seqs", type=int, default=None, help="database sequences per GPU (weak scaling)")
     ap.add_argument("--total-seqs", type=int, default=None, help="database sequences in total (strong scaling)")
     ap.add_argument("--qlen", type=int, default=None)
-    ap.add_argument("--gap-open", type=int, default=11)
+    ap.add_argument("--gap-open", type=int, default=None)
     ap.add_argument("--gap-ext", type=int, default=1)
     ap.add_argument("--mode", default="SW")
     ap.add_argument("--search-type", type=int, default=None)
@@ -64,10 +71,15 @@ def parse_args(argv=None):
     ap.add_argument("--query-fasta", default=None, help="use the first record of this FASTA file as the query")
     args = ap.parse_args(argv)
     wl = args.workload
+    data = os.path.join(ROOT, "tests", "golden", "data")
     if wl in ("c4", "c5") and args.total_seqs is None and args.seqs is None:
         args.total_seqs = 5000000
-    if wl == "c4" and args.query_fasta is None and args.qlen is None:
-        args.query_fasta = os.path.join(ROOT, "tests", "golden", "data", "query_P18080.fasta")
+    if wl == "sprot" and args.total_seqs is None and args.seqs is None:
+        args.total_seqs = 541762
+    if wl in ("c4", "sprot") and args.query_fasta is None and args.qlen is None:
+        args.query_fasta = os.path.join(data, "query_P18080.fasta")
+    if args.gap_open is None:
+        args.gap_open = 3 if wl == "sprot" else 11
     if wl == "c5" and args.qlen is None:
         args.qlen = 2000
     if args.qlen is None:
@@ -81,68 +93,150 @@ def parse_args(argv=None):
         args.steps = 5 if big else 100
     if args.warmup is None:
         args.warmup = 1 if big else 10
+    args.dist = "sprot" if wl == "sprot" else "c2"
     return args
 
 
+def _tail(path, limit=3000):
+    try:
+        with open(path, "rb") as fh:
+            fh.seek(0, os.SEEK_END)
+            size = fh.tell()
+            fh.seek(max(0, size - limit))
+            return fh.read().decode(errors="replace")
+    except OSError:
+        return ""
+
+
 def spawn_ranks(n):
-    """Start the N ranks as fresh children of this process (which has not imported torch nor touched the GPU),
-    one per GPU, rendezvous on 127.0.0.1. Rank 0's stdout is relayed; any failing rank fails the run."""
+    """Start the N ranks as fresh children of this process (which has not imported torch nor touched the GPU), one
+    per GPU, rendezvous on 127.0.0.1, and WATCH them: every child is polled; the first non-zero exit, or the deadline
+    (BENCH_DEADLINE_S, default 1500 s), kills the others within a fraction of a second -- a rank that died at init would
+    otherwise leave the rest waiting in the rendezvous or in a collective until torch's own watchdog fires, minutes later.
+    Every rank's stdout/stderr is kept; on failure their tails are printed. Rank 0's stdout (the JSON line) is relayed."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    deadline = time.time() + float(os.environ.get("BENCH_DEADLINE_S", "1500"))
+    tmp = tempfile.mkdtemp(prefix="bench_ranks_")
+    procs, files = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    rcs = [p.wait() for p in procs]
-    if any(rcs):
+        out = open(os.path.join(tmp, f"rank{r}.out"), "wb")
+        err = open(os.path.join(tmp, f"rank{r}.err"), "wb")
+        files.append((out, err))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out, stderr=err))
+    why = None
+    while why is None:
+        rcs = [p.poll() for p in procs]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            why = "rank %d exited with code %d" % bad[0]
+        elif all(rc == 0 for rc in rcs):
+            break
+        elif time.time() > deadline:
+            why = "deadline (BENCH_DEADLINE_S) passed"
+        else:
+            time.sleep(0.1)
+    if why is not None:
         for p in procs:
             if p.poll() is None:
                 p.kill()
-        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
+        for p in procs:
+            p.wait()
+    for out, err in files:
+        out.close(); err.close()
+    out0 = _tail(os.path.join(tmp, "rank0.out"), 1 << 20)
+    if why is not None:
+        sys.stderr.write(f"bench.py: {why}; exit codes {[p.returncode for p in procs]}\n")
+        for r in range(n):
+            sys.stderr.write(f"--- rank {r} stderr (tail)\n{_tail(os.path.join(tmp, f'rank{r}.err'))}\n")
+            if r:
+                sys.stderr.write(f"--- rank {r} stdout (tail)\n{_tail(os.path.join(tmp, f'rank{r}.out'), 1000)}\n")
         sys.stdout.write(out0)
         return 1
+    sys.stderr.write(_tail(os.path.join(tmp, "rank0.err")))
     sys.stdout.write(out0)
     return 0
 
 
+def cpu_quota_cores():
+    """CPU cores this container may use on average (cgroup v2 cpu.max / v1 cfs quota), None = unlimited."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fh:
+            quota = int(fh.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+            period = int(fh.read())
+        return None if quota <= 0 else quota / period
+    except (OSError, ValueError):
+        return None
+
+
+class RefCpu:
+    """The reference's own AVX2 path (oracle/_ref/libopal_ref.so, built from /root/reference in the build container)
+    behind a small pthread harness (oracle/ref_bench.c). Checker / baseline only."""
+
+    def __init__(self):
+        import oracle_lib
+        bench_so = os.path.join(oracle_lib.ORACLE_DIR, "_ref", "libref_bench.so")
+        self.ok = oracle_lib.have_ref() and os.path.exists(bench_so)
+        if self.ok:
+            C.CDLL(oracle_lib.ref_lib_path(), mode=C.RTLD_GLOBAL)
+            self.lib = C.CDLL(bench_so)
+            self.lib.ref_bench_run.restype = C.c_double
+
+    def run(self, query, res, offs, n, matrix, gap_open, gap_ext, mode_code, threads):
+        """seconds for the first n sequences on `threads` threads"""
+        q = np.ascontiguousarray(query, np.uint8); o = np.ascontiguousarray(offs, np.int64)
+        m = np.ascontiguousarray(matrix, np.int32)
+        up = lambda a: a.ctypes.data_as(C.POINTER(C.c_ubyte))
+        return self.lib.ref_bench_run(up(q), len(q), up(res), o.ctypes.data_as(C.POINTER(C.c_int64)), int(n), int(gap_open),
+                                      int(gap_ext), m.ctypes.data_as(C.POINTER(C.c_int)), int(m.shape[0]), int(mode_code),
+                                      int(threads), None)
+
+
 def cpu_baseline(query, res, offs, matrix, gap_open, gap_ext, mode_code):
-    """The reference's own AVX2 path (oracle/_ref/libopal_ref.so, built from /root/reference in the build
-    container) timed on this host's cores through a small pthread harness (oracle/ref_bench.c); falls back
-    to the scalar oracle port if the reference build is absent. Bounded to ~10-30 s of CPU work."""
+    """The reference timed on this host's cores; falls back to the scalar oracle port if the reference build is absent.
+    Bounded to ~10-30 s of CPU work. `value` is the SUSTAINED all-thread figure (back-to-back runs for >= 1 s): a
+    container with a CPU quota runs a short burst on every hardware thread far above what it can sustain."""
     import oracle_lib
     n_all = len(offs) - 1
-    cores = os.cpu_count() or 1
-    bench_so = os.path.join(oracle_lib.ORACLE_DIR, "_ref", "libref_bench.so")
-    if oracle_lib.have_ref() and os.path.exists(bench_so):
-        C.CDLL(oracle_lib.ref_lib_path(), mode=C.RTLD_GLOBAL)
-        lib = C.CDLL(bench_so)
-        lib.ref_bench_run.restype = C.c_double
-        q = np.ascontiguousarray(query, np.uint8); r = np.ascontiguousarray(res, np.uint8)
-        o = np.ascontiguousarray(offs, np.int64); m = np.ascontiguousarray(matrix, np.int32)
-        up = lambda a: a.ctypes.data_as(C.POINTER(C.c_ubyte))
-
-        def run(n, threads):
-            return lib.ref_bench_run(up(q), len(q), up(r), o.ctypes.data_as(C.POINTER(C.c_int64)), int(n), int(gap_open),
-                                     int(gap_ext), m.ctypes.data_as(C.POINTER(C.c_int)), int(m.shape[0]), int(mode_code),
-                                     int(threads), None)
-        # bounded samples: a prefix of the shard (it is sorted longest first) holding ~5e9 cells for the one-thread
-        # run (the reference's own methodology, aligner_comparison.md:11) and at most 5e10 cells for all threads
-        csum = float(len(q)) * o[1:].astype(np.float64)
+    hw = os.cpu_count() or 1
+    quota = cpu_quota_cores()
+    ref = RefCpu()
+    res = np.ascontiguousarray(res, np.uint8)
+    if ref.ok:
+        o = np.ascontiguousarray(offs, np.int64)
+        run = lambda n, t: ref.run(query, res, o, n, matrix, gap_open, gap_ext, mode_code, t)
+        # bounded samples: a prefix of the shard holding ~5e9 cells for the one-thread run (the reference's own
+        # methodology, aligner_comparison.md:11) and at most 5e10 cells for all threads
+        csum = float(len(query)) * o[1:].astype(np.float64)
         n1 = int(min(n_all, np.searchsorted(csum, 5e9) + 1))
         n_mt = int(min(n_all, np.searchsorted(csum, 5e10) + 1))
         run(min(n_all, 2000), 1)  # warm-up
         t1 = min(run(n1, 1) for _ in range(2))
-        one = float(len(q)) * float(o[n1]) / t1 / 1e9
-        nt = min(cores, 256)
-        tall = min(run(n_mt, nt) for _ in range(3))
-        allc = float(len(q)) * float(o[n_mt]) / tall / 1e9
-        return {"value": round(allc, 2), "unit": "GCUPS", "cores": nt, "kind": "reference",
-                "sample": f"the {n_mt} longest of {n_all} sequences on {nt} threads, best of 3; 1 thread on the "
-                          f"{n1} longest: {one:.2f} GCUPS", "one_thread_value": round(one, 2)}
+        one = float(len(query)) * float(o[n1]) / t1 / 1e9
+        nt_burst = min(hw, 256)
+        burst = float(len(query)) * float(o[n_mt]) / min(run(n_mt, nt_burst) for _ in range(3)) / 1e9
+        # sustained: as many threads as the container may keep busy, back-to-back runs for at least a second
+        nt = max(1, min(nt_burst, int(quota + 0.999) if quota else nt_burst))
+        reps, t0 = 0, time.perf_counter()
+        while reps < 3 or time.perf_counter() - t0 < 1.0:
+            run(n_mt, nt)
+            reps += 1
+        sustained = reps * float(len(query)) * float(o[n_mt]) / (time.perf_counter() - t0) / 1e9
+        return {"value": round(sustained, 2), "unit": "GCUPS", "cores": nt, "kind": "reference",
+                "sample": f"sustained: {reps} back-to-back runs of the {n_mt} first of {n_all} sequences on {nt} threads "
+                          f"({time.perf_counter() - t0:.1f} s); burst: best single run on {nt_burst} threads; 1 thread on the {n1} first",
+                "cpu_quota_cores": quota, "hardware_threads": hw, "burst_value": round(burst, 2), "burst_threads": nt_burst,
+                "one_thread_value": round(one, 2)}
     orc = oracle_lib.Oracle()
     n = min(n_all, 400)
     seqs = [res[offs[i]:offs[i + 1]] for i in range(n)]
@@ -150,12 +244,12 @@ def cpu_baseline(query, res, offs, matrix, gap_open, gap_ext, mode_code):
     orc.search(query, seqs, gap_open, gap_ext, matrix, 0, mode_code)
     t1 = time.perf_counter() - t0
     return {"value": round(float(len(query)) * float(offs[n]) / t1 / 1e9, 4), "unit": "GCUPS", "cores": 1, "kind": "port",
-            "sample": f"scalar oracle on the first {n} sequences"}
+            "sample": f"scalar oracle on the first {n} sequences", "cpu_quota_cores": quota, "hardware_threads": hw}
 
 
-def e2e_call(query, res_host, offs, matrix, gap_open, gap_ext, search_type, mode_code, want_scores):
+def e2e_call(query, res_host, offs, matrix, gap_open, gap_ext, search_type, mode_code, want_scores, calls=6):
     """The call the reference's own timer brackets (opal_aligner.cpp:157-165): opalSearchDatabase with N separate
-    host pointers in and N result structs out, steady clock, best of 5. Returns (ms, scores_match)."""
+    host pointers in and N result structs out, steady clock, best of `calls`. Returns (ms, scores_match)."""
     from opal_amd import _lib
     from opal_amd.api import OpalSearchResult
     L = _lib.lib()
@@ -169,7 +263,7 @@ def e2e_call(query, res_host, offs, matrix, gap_open, gap_ext, search_type, mode
     words = np.frombuffer(arr, dtype=np.int32).reshape(n, 10)
     rptrs = np.ascontiguousarray(C.addressof(arr) + 40 * np.arange(n, dtype=np.uint64), dtype=np.uint64)
     best = None
-    for _ in range(6):
+    for _ in range(calls):
         words[:, 0] = 0            # scoreSet = 0 (opalInitSearchResult)
         words[:, 2:6] = -1
         t0 = time.perf_counter()
@@ -195,6 +289,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("BENCH_FAIL_RANK") == str(rank):  # test hook: this rank dies before the rendezvous
+        sys.stderr.write(f"bench.py: rank {rank} failing on request (BENCH_FAIL_RANK)\n")
+        sys.exit(7)
+    if str(rank) in os.environ.get("BENCH_HANG_RANK", "").split(","):  # test hook: this rank never reaches the rendezvous
+        time.sleep(3600)
 
     import torch
     import torch.distributed as dist
@@ -213,48 +312,53 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from opal_amd import shard, synth
+    from opal_amd import _lib, shard, synth
     from opal_amd.api import MODES, PreparedDb
+    from opal_amd.fasta import read_fasta
     from opal_amd.score_matrix import blosum50
 
     strong = args.total_seqs is not None
     total = args.total_seqs if strong else args.seqs * world
+    alphabet, matrix = blosum50()
+    qname = "seed 7"
     if args.query_fasta:
-        from opal_amd.fasta import read_fasta
-        query = read_fasta(args.query_fasta, blosum50()[0])[0]
+        query = read_fasta(args.query_fasta, alphabet)[0]
         args.qlen = len(query)
+        qname = os.path.basename(args.query_fasta).replace("query_", "").replace(".fasta", "")
     else:
         query = synth.query(args.qlen, seed=7)
-    matrix = blosum50()[1]
     mode = MODES[args.mode]
+    stride = synth.SPROT_STRIDE if args.dist == "sprot" else 5000
 
-    # ---- this rank's shard of the one global database (dealt by residue count, opal_amd/shard.py)
-    all_lens = synth.lengths(42, 0, total)
-    owned_lists = shard.deal(all_lens, world)
+    # ---- this rank's shard of the one global database. One rank: the database in its own order (results land at their
+    # database index). Several: 64-sequence groups dealt by residue count (opal_amd/shard.py).
+    all_lens = synth.lengths(42, 0, total, args.dist)
+    owned_lists = shard.deal(all_lens, world) if world > 1 else [np.arange(total, dtype=np.int64)]
     owned = owned_lists[rank]
     n = len(owned)
     npad = max(len(o) for o in owned_lists)
     lens = all_lens[owned]
-    d_res, offs = synth.residues_device(owned, lens, 42, dev)
-    torch.cuda.synchronize()
+    d_res, offs = synth.residues_device(owned, lens, 42, dev, stride=stride)
+    torch.cuda.synchronize()  # the library reads the buffer on its own stream: everything that produced it must be complete
     pdb = PreparedDb(None, offs, device_ptr=d_res.data_ptr())
     cells = float(args.qlen) * float(offs[-1])
     total_cells = float(args.qlen) * float(all_lens.astype(np.int64).sum())
 
     want_end = args.search_type != 0
     nres = 3 if want_end else 1
-    # {score, endQ, endT} blocks, padded to the largest shard. Two result buffers used in turn: the search runs on the
-    # library's own stream, the gather / permutation on torch's, so step i+1 must not overwrite what step i's gather is
-    # still reading; a buffer is reused two steps later, after waiting on the event recorded behind its last reader.
-    outs = [torch.zeros(nres * npad, dtype=torch.int32, device=dev) for _ in range(2)]
+    # {score, endQ, endT} blocks, padded to the largest shard. Two result buffers used in turn (N > 1): the search runs on
+    # the library's own stream, the gather on torch's, so step i+1 must not overwrite what step i's gather is still
+    # reading; a buffer is reused two steps later, after waiting on the event recorded behind its last reader.
+    outs = [torch.zeros(nres * npad, dtype=torch.int32, device=dev) for _ in range(2 if world > 1 else 1)]
     done = [None, None]
-    owned_dev = [torch.as_tensor(o, device=dev) for o in owned_lists] if rank == 0 else None
-    glob = torch.zeros(nres * total, dtype=torch.int32, device=dev) if rank == 0 else None
+    # position of every database sequence in the gathered [rank][value][npad] block: ONE index operation per step
+    plan = shard.GatherPlan(owned_lists, nres, dev if backend == "nccl" else "cpu", root=rank == 0) if world > 1 else None
+    torch.cuda.synchronize()  # (the zero fills above run on torch's stream, the searches on the library's)
     kernel_ms = []
     step_no = [0]
 
     def step():
-        b = step_no[0] & 1
+        b = step_no[0] % len(outs)
         step_no[0] += 1
         out = outs[b]
         if done[b] is not None:
@@ -267,18 +371,10 @@ def main():
         kernel_ms.append(kms)
         if world > 1:
             # the path's only exchange: ONE gather of the per-sequence result block to rank 0, which puts the
-            # blocks back into database order with the deal's permutation
-            got = shard.gather_results(out if backend == "nccl" else out.cpu(), world, rank)
-            if rank == 0:
-                for r, blk in enumerate(got):
-                    blk = blk.to(dev, non_blocking=True)
-                    for k in range(nres):
-                        glob[k * total:(k + 1) * total][owned_dev[r]] = blk[k * npad:k * npad + len(owned_lists[r])]
-        elif rank == 0:
-            for k in range(nres):
-                glob[k * total:(k + 1) * total][owned_dev[0]] = out[k * npad:k * npad + n]
-        done[b] = torch.cuda.Event()
-        done[b].record()
+            # blocks back into database order with the deal's permutation (one index_select for all result vectors)
+            plan.gather(out if backend == "nccl" else out.cpu(), rank)
+            done[b] = torch.cuda.Event()
+            done[b].record()
 
     def fence():
         if world > 1:
@@ -300,26 +396,53 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    # ---- verification, after the timed region: EVERY rank checks a fixed sample of its own shard against the CPU oracle
+    # (checker only); the verdicts are reduced into `verified`
+    import oracle_lib
+    oracle_lib.build_oracle()
+    mine = outs[(step_no[0] - 1) % len(outs)].cpu().numpy().reshape(nres, npad)[:, :n]
+    rng = np.random.RandomState(1 + rank)
+    nsamp = min(n, (300 if args.qlen <= 600 else 120) // (1 if world == 1 else 2))
+    pick = np.sort(rng.choice(n, nsamp, replace=False))
+    if args.dist == "sprot":  # the long tail must be part of the sample
+        pick = np.unique(np.concatenate([pick, np.argsort(lens)[-3:]]))
+    sres, soffs, _ = synth.database_subset(owned[pick], 42, lens=lens[pick], stride=stride)
+    sdb = [sres[soffs[i]:soffs[i + 1]] for i in range(len(pick))]
+    orc_rc, os_, oq, ot = oracle_lib.Oracle().search(query, sdb, args.gap_open, args.gap_ext, matrix, args.search_type, mode)
+    ok_local = bool(orc_rc == 0 and (mine[0][pick] == os_).all())
+    if want_end:
+        ok_local = ok_local and bool((mine[1][pick] == oq).all() and (mine[2][pick] == ot).all())
+    if not ok_local:
+        sys.stderr.write(f"bench.py: rank {rank}: results differ from the oracle on its shard sample\n")
+    vflag = torch.tensor([1 if ok_local else 0], dtype=torch.int32, device=rdev)
+    if world > 1:
+        dist.all_reduce(vflag, op=dist.ReduceOp.MIN)
+    verified = bool(int(vflag.item()) == 1)
+
     status = 0
     if rank == 0:
         gcups = total_cells * args.steps / dt / 1e9
         kms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         kernel_gcups = cells / (kms * 1e-3) / 1e9
-        gscore = glob[:total].cpu().numpy()
+        gall = plan.glob.cpu().numpy() if world > 1 else mine
+        gscore = np.ascontiguousarray(gall[0])
+        if world > 1:  # the gathered, re-ordered block must hold rank 0's own verified values at their database indices
+            verified = verified and bool((gall[:, owned] == mine).all())
 
-        # ---- verification: a fixed sample of the database against the CPU oracle (checker only, after the timed region)
-        import oracle_lib
-        oracle_lib.build_oracle()
-        rng = np.random.RandomState(1)
-        nsamp = min(total, 300 if args.qlen <= 600 else 120)
-        pick = np.sort(rng.choice(total, nsamp, replace=False))
-        sres, soffs, slens = synth.database_subset(pick, 42, lens=all_lens[pick])
-        sdb = [sres[soffs[i]:soffs[i + 1]] for i in range(nsamp)]
-        orc_rc, os_, oq, ot = oracle_lib.Oracle().search(query, sdb, args.gap_open, args.gap_ext, matrix, args.search_type, mode)
-        verified = bool(orc_rc == 0 and (gscore[pick] == os_).all())
-        if want_end:
-            verified = verified and bool((glob[total:2 * total].cpu().numpy()[pick] == oq).all() and
-                                         (glob[2 * total:].cpu().numpy()[pick] == ot).all())
+        # ---- the clock the chip holds under this kernel (it clocks to its power budget): a few more searches with the
+        # library's clock probe on, outside the timed region (the probe's read-back would otherwise be part of a step)
+        L = _lib.lib()
+        L.opalx_db_clock_probe.argtypes = [C.c_void_p, C.c_int]
+        L.opalx_db_last_clock_ghz.restype = C.c_double
+        L.opalx_db_last_clock_ghz.argtypes = [C.c_void_p]
+        L.opalx_db_clock_probe(pdb._h, 1)
+        clocks = []
+        for _ in range(5):
+            pdb.search_device(query, args.gap_open, args.gap_ext, matrix, args.search_type, mode, outs[0].data_ptr(),
+                              outs[0][npad:].data_ptr() if want_end else 0, outs[0][2 * npad:].data_ptr() if want_end else 0)
+            clocks.append(L.opalx_db_last_clock_ghz(pdb._h))
+        L.opalx_db_clock_probe(pdb._h, 0)
+        clock_ghz = float(np.median(clocks)) if clocks and min(clocks) > 0 else None
 
         instr_per_cell = 9.0 if args.mode == "SW" else 6.0
         peak = valu_peak_gcups(instr_per_cell)
@@ -331,55 +454,62 @@ def main():
         traffic, traffic_src = None, None
         try:  # HBM bytes per step measured offline with rocprofv3 PMC passes on this same workload (never guessed for another)
             key = (args.workload, args.qlen, total if strong else args.seqs, args.mode, args.search_type, args.gap_open, world)
-            if key == ("c2", 300, 100000, "SW", 0, 11, 1):
-                with open(os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")) as fh:
-                    traffic = json.load(fh)["hbm_bytes_per_step"]
-                    traffic_src = "offline: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r02_pmc_hbm.json)"
-            else:  # the per-configuration profiles of scripts/prof_round2.sh
-                tags = {("c3", 300, 100000, "SW", 1): "c2end", ("c3", 300, 100000, "NW", 1): "c3nw", ("c3", 300, 100000, "HW", 1): "c3hw",
-                        ("c3", 300, 100000, "OV", 1): "c3ov", ("c4", 513, 625000, "SW", 0): "c4", ("c5", 2000, 100000, "SW", 0): "c5",
-                        ("c5", 2000, 100000, "SW", 1): "c5end", ("c5", 2000, 100000, "NW", 1): "c5nw", ("c5", 2000, 100000, "HW", 1): "c5hw",
-                        ("c5", 2000, 100000, "OV", 1): "c5ov"}
-                tag = tags.get(key[:5]) if (key[5], key[6]) == (11, 1) else None
-                if tag:
-                    with open(os.path.join(ROOT, "profiles", f"r02_{tag}.json")) as fh:
+            tags = {("c2", 300, 100000, "SW", 0): "c2", ("c3", 300, 100000, "SW", 1): "c2end", ("c3", 300, 100000, "NW", 1): "c3nw",
+                    ("c3", 300, 100000, "HW", 1): "c3hw", ("c3", 300, 100000, "OV", 1): "c3ov", ("c4", 513, 625000, "SW", 0): "c4",
+                    ("c5", 2000, 100000, "SW", 0): "c5", ("c5", 2000, 100000, "SW", 1): "c5end", ("c5", 2000, 100000, "NW", 1): "c5nw",
+                    ("c5", 2000, 100000, "HW", 1): "c5hw", ("c5", 2000, 100000, "OV", 1): "c5ov"}
+            tag = tags.get(key[:5]) if (key[5], key[6]) == (11, 1) else None
+            for rnd in ("r03", "r02"):
+                path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}.json")
+                if tag and os.path.exists(path):
+                    with open(path) as fh:
                         traffic = json.load(fh)["hbm_bytes_per_step"]
-                        traffic_src = f"offline: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (profiles/r02_{tag}.json)"
+                    traffic_src = (f"offline: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (profiles/{rnd}_{tag}.json); "
+                                   "`achieved` divides those bytes by the live kernel time")
+                    break
         except (OSError, KeyError, ValueError, TypeError):
             traffic = None
         hbm = {"peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes": alg_bytes,
                "algorithmic_gbs": round(alg_bytes / (kms * 1e-3) / 1e9, 2),
                "achieved": round(traffic / (kms * 1e-3) / 1e9, 2) if traffic else None,
+               "achieved_source": "offline profile bytes / live kernel time" if traffic else None,
                "frac": round(traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
                "column_streaming_model_bytes": cells * 8.0,
                "note": "the DP column lives in VGPRs: HBM carries residue tokens in and results out only"}
+        what = f"{args.mode} {'score-only' if not want_end else 'score+end'}"
         res_line = {
-            "metric": "GCUPS (DP cell updates/s), SW score-only, 1 query vs synthetic protein DB",
+            "metric": f"GCUPS (DP cell updates/s), {what}, 1 query vs synthetic protein DB",
             "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "i16", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {args.qlen}-aa query ({'P18080' if args.query_fasta else 'seed 7'}) vs "
-                                   f"{total} synthetic protein seqs in total (seed 42, mean {float(all_lens.mean()):.0f} aa, "
-                                   f"{'fixed total' if strong else str(args.seqs) + ' per GPU'}), {args.mode} "
-                                   f"{'score-only' if not want_end else 'score+end'}, BLOSUM50, gaps "
+            "config": {"workload": f"{args.workload}: {args.qlen}-aa query ({qname}) vs "
+                                   f"{total} synthetic protein seqs in total (seed 42, mean {float(all_lens.mean()):.0f} aa, longest "
+                                   f"{int(all_lens.max())}, {'fixed total' if strong else str(args.seqs) + ' per GPU'}), {what}, BLOSUM50, gaps "
                                    f"{args.gap_open}/{args.gap_ext}, 16-bit first rung, 32-bit re-run",
                        "cells_per_step": total_cells, "cells_per_step_rank0": cells,
-                       "parallelism": f"db-shard x{world} (64-seq groups dealt by residue count), 1 gather"},
+                       "parallelism": f"db-shard x{world} (64-seq groups dealt by residue count), 1 gather" if world > 1 else
+                                      "one GPU, results written at their database index"},
             "verified": verified,
-            "verify": {"sample": f"{nsamp} sequences (fixed seed) vs oracle/opal_oracle.c", "score_crc32": zlib.crc32(gscore.tobytes())},
+            "verify": {"sample": f"{len(pick)} sequences of every rank's shard (fixed seeds) vs oracle/opal_oracle.c, verdicts all-reduced"
+                                 + ("; the gathered block vs rank 0's own values" if world > 1 else ""),
+                       "score_crc32": zlib.crc32(gscore.tobytes())},
             "roofline": {"bound": "valu-issue", "achieved": round(kernel_gcups, 1), "peak": round(peak, 0), "unit": "GCUPS",
                          "frac": round(kernel_gcups / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": round(kms, 4),
+                         "clock_ghz": round(clock_ghz, 3) if clock_ghz else None,
+                         "frac_at_measured_clock": round(kernel_gcups / valu_peak_gcups(instr_per_cell, clock_ghz * 1e9), 4) if clock_ghz else None,
                          "model": f"1024 SIMDs x 2.4 GHz x 64 lanes / ({instr_per_cell:.0f} full-rate 16-bit instr x 2 clk per cell); "
-                                  "kernel_ms = HIP events around all DP launches of a step on the launch stream (rank 0)",
+                                  "kernel_ms = HIP events around all DP launches of a step on the launch stream (rank 0); clock_ghz = "
+                                  "shader cycles / constant-rate ticks over one wave's lifetime per workgroup, measured in the DP kernels "
+                                  "themselves on 5 more searches after the timed region; frac_at_measured_clock prices the bound at it",
                          "hbm": hbm},
         }
         if not verified:
             status = 3
+        res_host = None
         if world == 1 and not args.no_e2e and total <= 1000000:
             res_host = d_res.cpu().numpy()
-            e2e_ms, e2e_ok = e2e_call(query, res_host, offs, matrix, args.gap_open, args.gap_ext, args.search_type, mode,
-                                      gscore[owned])
+            e2e_ms, e2e_ok = e2e_call(query, res_host, offs, matrix, args.gap_open, args.gap_ext, args.search_type, mode, gscore)
             res_line["e2e"] = {"ms": round(e2e_ms, 3), "gcups": round(cells / (e2e_ms * 1e-3) / 1e9, 1), "scores_match": e2e_ok,
                                "what": "opalSearchDatabase (host pointers in, result structs out), steady clock, best of 6 calls"}
             if not e2e_ok:
@@ -394,8 +524,37 @@ def main():
                 rc, k = pdb.search_device(query, other, args.gap_ext, matrix, 0, mode, outs[0].data_ptr())
                 ks.append(k)
             res_line["also"] = {f"kernel_gcups_gaps_{other}_{args.gap_ext}": round(cells / (float(np.median(ks)) * 1e-3) / 1e9, 1)}
+        if args.workload == "sprot" and world == 1:
+            # the published table (reference aligner_comparison.md:27-34): seconds per search for each of its four queries,
+            # next to the reference's published single-thread AVX2 seconds on an i7-4770K (context only: other hardware)
+            # and, with the reference build present, its time on THIS box (all threads it may keep busy; 1 thread on a sample)
+            if res_host is None:
+                res_host = d_res.cpu().numpy()
+            ref = RefCpu() if not args.no_cpu_baseline else None
+            quota = cpu_quota_cores()
+            table = {}
+            for name in ("O74807", "P19930", "Q3ZAI3", "P18080"):
+                qq = read_fasta(os.path.join(ROOT, "tests", "golden", "data", f"query_{name}.fasta"), alphabet)[0]
+                ks, ts = [], []
+                for _ in range(5):
+                    t1 = time.perf_counter()
+                    rc, k = pdb.search_device(qq, args.gap_open, args.gap_ext, matrix, 0, MODES["SW"], outs[0].data_ptr())
+                    ts.append(time.perf_counter() - t1)
+                    ks.append(k)
+                row = {"query_length": len(qq), "gpu_search_s": round(float(np.median(ts)), 5), "gpu_kernel_ms": round(float(np.median(ks)), 3),
+                       "gpu_kernel_gcups": round(len(qq) * float(offs[-1]) / (float(np.median(ks)) * 1e-3) / 1e9, 1),
+                       "published_opal_avx2_i7_4770K_1thread_s": PUBLISHED_S[name]}
+                if ref is not None and ref.ok:
+                    nt = max(1, min(os.cpu_count() or 1, int(quota + 0.999) if quota else 256, 256))
+                    row[f"reference_avx2_this_box_{nt}_threads_s"] = round(ref.run(qq, res_host, offs, n, matrix, args.gap_open, args.gap_ext, MODES["SW"], nt), 3)
+                    n1 = max(1, n // 64)
+                    t_one = ref.run(qq, res_host, offs, n1, matrix, args.gap_open, args.gap_ext, MODES["SW"], 1)
+                    row["reference_avx2_this_box_1_thread_s_extrapolated"] = round(t_one * float(offs[-1]) / float(offs[n1]), 2)
+                table[name] = row
+            res_line["published_shape"] = table
         if not args.no_cpu_baseline and world == 1:
-            res_host = d_res.cpu().numpy()
+            if res_host is None:
+                res_host = d_res.cpu().numpy()
             res_line["cpu_baseline"] = cpu_baseline(query, res_host, offs, matrix, args.gap_open, args.gap_ext, mode)
         print(json.dumps(res_line), flush=True)
     if world > 1:

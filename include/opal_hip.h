@@ -92,6 +92,10 @@ typedef struct OpalHipLaunch {
     /* opal_hip_launch_stream, NW/HW/OV only: items [side_first_item, +side_num_items) (sequences too long for the skewed
        arithmetic of the stream) run on the unskewed class body inside the same launch, ahead of the streaming workgroups */
     int side_first_item, side_num_items;
+    /* Clock probe (NULL: off): two device counters; wave 0 of every workgroup adds the shader cycles and the constant-rate
+       ticks (opal_hip_wall_clock_hz per second) of its lifetime to [0] / [1] -- their ratio is the clock the chip held
+       under this kernel. */
+    unsigned long long* clock_probe;
 } OpalHipLaunch;
 
 /* ONE launch for up to three length classes of a search (plain 16-bit kernels): the bulk of the database on
@@ -123,6 +127,7 @@ int opal_hip_device_count(void);
 /* Select `device` for the calling thread. 0 on success. */
 int opal_hip_set_device(int device);
 int opal_hip_get_device(void);             /* the calling thread's current device, -1 on error */
+double opal_hip_wall_clock_hz(void);       /* ticks per second of the constant-rate device counter (clock probe) */
 void* opal_hip_malloc(size_t bytes);
 void opal_hip_free(void* p);
 void* opal_hip_host_malloc(size_t bytes);  /* pinned host memory (staging of residues and results) */
@@ -236,6 +241,12 @@ long long opalx_stream_launch_count(void);
    32-bit rung, [6] alignments traced on the device, [7] alignments traced or started by the host. Returns 8. */
 int opalx_counters(long long* out, int capacity);
 void opalx_db_destroy(OpalxDb* db);
+/* Clock probe for measurements (bench.py): while enabled, every search on this handle also measures the shader clock
+   its DP kernels ran at (cycle counter / constant-rate counter over the lifetime of one wave per workgroup) and reads it
+   back after the search (one extra small copy: leave it off in timed loops). opalx_db_last_clock_ghz returns the figure
+   of the last probed search, 0 if none. */
+void opalx_db_clock_probe(OpalxDb* db, int enable);
+double opalx_db_last_clock_ghz(const OpalxDb* db);
 int opalx_db_num_sequences(const OpalxDb* db);
 int64_t opalx_db_num_residues(const OpalxDb* db);
 

@@ -267,5 +267,7 @@ extern "C" void opalx_release_cached(void) {
     if (cur >= 0) opal_hip_set_device(cur);
 }
 
+extern "C" void opalx_db_clock_probe(OpalxDb* db, int enable) { if (db) db->clockProbe = enable != 0; }
+extern "C" double opalx_db_last_clock_ghz(const OpalxDb* db) { return db ? db->lastClockGhz : 0.0; }
 extern "C" int opalx_db_num_sequences(const OpalxDb* db) { return db ? db->numSeqs : 0; }
 extern "C" int64_t opalx_db_num_residues(const OpalxDb* db) { return db ? db->residues : 0; }

@@ -72,7 +72,31 @@ struct KParams {
     uint2* bnd;    // per column {H, F-input} of the chunk boundary: width 16 [tokOff+c], width 32 [2*(tokOff+c)+half]
     int* scratch;  // [2N] OV only: last-column maximum and its row carried across chunks
     int satLimit, negPad;  // width 17 only
+    // Clock probe (bench.py, off = nullptr): wave 0 of every workgroup adds the shader cycles (s_memtime) and the
+    // constant-rate ticks (s_memrealtime) of its own lifetime to clk[0] / clk[1]; their ratio is the clock the chip
+    // sustained under THIS kernel (it clocks to its power budget: MI355X_MICROARCH.md, DVFS).
+    unsigned long long* clk;
 };
+
+// The two start stamps -- and the pointer itself -- wait in 32 bytes behind the workgroup's LDS data, so that nothing of
+// the probe is live in a register across the column loop (the 40-row kernels sit at 128 VGPRs).
+__device__ __forceinline__ void clk_begin(unsigned long long* clk, unsigned char* slot) {
+    if (threadIdx.x == 0) {
+        unsigned long long* s = reinterpret_cast<unsigned long long*>(slot);
+        s[2] = (unsigned long long)(uintptr_t)clk;
+        if (clk) { s[0] = (unsigned long long)clock64(); s[1] = (unsigned long long)wall_clock64(); }
+    }
+}
+__device__ __forceinline__ void clk_end(const unsigned char* slot) {
+    if (threadIdx.x == 0) {
+        const unsigned long long* s = reinterpret_cast<const unsigned long long*>(slot);
+        unsigned long long* clk = reinterpret_cast<unsigned long long*>((uintptr_t)s[2]);
+        if (clk) {
+            atomicAdd(clk, (unsigned long long)clock64() - s[0]);
+            atomicAdd(clk + 1, (unsigned long long)wall_clock64() - s[1]);
+        }
+    }
+}
 
 // What differs between the length classes of one search (the rest of KParams is shared).
 struct KClass {
@@ -368,6 +392,8 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
     const int CR = MULTI ? p.chunkRows : Q;
     const bool hasPrev = MULTI && (p.chunkFlags & 1), hasNext = MULTI && (p.chunkFlags & 2);
     const int padTop = (MODE == MODE_NW || hasPrev) ? 0 : (G * S - CR);
+    unsigned char* const clkSlot = lds + (size_t)(A + 1) * stride;  // (the launch reserves 32 bytes behind the profile)
+    clk_begin(p.clk, clkSlot);
 
     // ---- stage the query profile in LDS: QP[letter][k][j] = M[query[k*S+j-padTop]][letter]; letter A = padding.
     // A thread owns (lane k, row j) positions and walks the letters: one query byte per position, then matrix reads
@@ -879,6 +905,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
             }
         }
     }
+    clk_end(clkSlot);
 }
 
 template <int WIDTH, int MODE, int FLAGS, int S>

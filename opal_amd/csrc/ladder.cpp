@@ -19,6 +19,7 @@ static void fill_launch(OpalHipLaunch& a, const SearchCtx& c, int width, int swE
     a.overflow_count = ovfCounter; a.overflow_items = db->ovfItems.p;
     a.sat_limit = c.satLimit; a.neg_pad = c.negPad;
     a.stream = db->main();
+    a.clock_probe = db->clockProbe ? (unsigned long long*)(db->header.p + 16) : nullptr;
 }
 
 // Queries that no single wave geometry can hold (more than 64 lanes x 40 rows, or a query profile
@@ -210,16 +211,17 @@ bool args_fit_int32(int Go, int Ge, const int* M, int A) {
 // copies and a memset cost ~10 us of stream time each, on a search whose kernels take 1.6 ms).
 int ensure_query_buffers(OpalxDb* db, const unsigned char* query, int Q, const int* M, int A) {
     const size_t mb = (size_t)A * A * sizeof(int);
-    const size_t bytes = (16 + mb + (size_t)std::max(Q, 1) + 15) / 16 * 16;
+    const size_t head = 32;  // {counters[4], clock probe[2 x u64]}
+    const size_t bytes = (head + mb + (size_t)std::max(Q, 1) + 15) / 16 * 16;
     if (!db->header.ensure(bytes, 1.5) || !db->hHeader.ensure(bytes, 1.5)) return 1;
     unsigned char* h = db->hHeader.p;
-    memset(h, 0, 16);
-    memcpy(h + 16, M, mb);
-    if (Q) memcpy(h + 16 + mb, query, (size_t)Q);
-    if (opal_hip_memcpy_h2d(db->header.p, h, 16 + mb + (size_t)Q, db->main())) return 1;
+    memset(h, 0, head);
+    memcpy(h + head, M, mb);
+    if (Q) memcpy(h + head + mb, query, (size_t)Q);
+    if (opal_hip_memcpy_h2d(db->header.p, h, head + mb + (size_t)Q, db->main())) return 1;
     db->ovfCount.p = (int*)db->header.p;
-    db->matrix.p = (int*)(db->header.p + 16);
-    db->query.p = db->header.p + 16 + mb;
+    db->matrix.p = (int*)(db->header.p + head);
+    db->query.p = db->header.p + head + mb;
     return 0;
 }
 
@@ -472,6 +474,11 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
     // (a caller that copies the results back on the same stream and waits for that copy needs no wait of its own here)
     if ((finalSync || kernelMs) && opal_hip_stream_sync(st)) return OPAL_ERR_NO_SIMD_SUPPORT;
     if (kernelMs && evStart && evStop) *kernelMs = opal_hip_event_elapsed_ms(evStart, evStop);
+    if (db->clockProbe) {  // (measurement runs only: one more small copy and wait)
+        unsigned long long v[2] = {0, 0};
+        if (!opal_hip_memcpy_d2h(v, db->header.p + 16, sizeof v, st) && !opal_hip_stream_sync(st) && v[1])
+            db->lastClockGhz = (double)v[0] / (double)v[1] * opal_hip_wall_clock_hz() * 1e-9;
+    }
     return rc;
 }
 

@@ -125,7 +125,9 @@ struct OpalxDb {
     opal_host::DevBuf<uint16_t> tokens;
     opal_host::DevBuf<uint64_t> pairOff;
     opal_host::DevBuf<int> dPairLen, dPairSeq;
-    // One "search header" per search, uploaded with a single copy: {counters[4], score matrix, query}. ovfCount[0] =
+    bool clockProbe = false;   // opalx_db_clock_probe
+    double lastClockGhz = 0;
+    // One "search header" per search, uploaded with a single copy: {counters[4], clock probe[2 x u64], score matrix, query}. ovfCount[0] =
     // length of the 16-bit rung's re-run list, [1] = width-32 wrap count.
     opal_host::DevBuf<unsigned char> header;
     opal_host::PinBuf<unsigned char> hHeader;

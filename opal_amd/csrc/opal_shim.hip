@@ -54,6 +54,14 @@ extern "C" void* opal_hip_host_malloc(size_t bytes) {
 
 extern "C" void opal_hip_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
+// Ticks per second of s_memrealtime (the constant-rate counter the clock probe divides shader cycles by).
+extern "C" double opal_hip_wall_clock_hz(void) {
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0.0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) return 1e8;  // gfx9: 100 MHz
+    return 1e3 * (double)khz;
+}
+
 extern "C" int opal_hip_get_device(void) {
     int d = -1;
     if (hipGetDevice(&d) != hipSuccess) return -1;
@@ -213,7 +221,7 @@ static int raise_lds_limit(const void* fn) {
 
 static size_t lds_bytes(int width, int G, int rows, int A) {
     const int es = (width == 16 || width == 18) ? 2 : 4;  // widths 17 and 32 keep 4-byte profile entries
-    return (size_t)(A + 1) * (size_t)opal_profile_stride(es, G, rows, width == 18) + 16;
+    return (size_t)(A + 1) * (size_t)opal_profile_stride(es, G, rows, width == 18) + 32;  // (+32: clock-probe slot, dp_kernel.hpp)
 }
 
 extern "C" size_t opal_hip_lds_bytes(int width, int lanes_per_seq, int rows_per_lane, int alphabet_length) {
@@ -312,6 +320,7 @@ extern "C" int opal_hip_launch_uber(const OpalHipUberLaunch* u) {
     b.ovfCount = a->overflow_count; b.ovfItems = a->overflow_items;
     b.chunkRows = a->query_length;
     b.satLimit = a->sat_limit; b.negPad = a->neg_pad;
+    b.clk = a->clock_probe;
     size_t lds = 0;
     int blocks = 0;
     for (int k = 0; k < 3; k++) {
@@ -369,6 +378,7 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
     p.scratch = a->scratch;
     p.satLimit = a->sat_limit;
     p.negPad = a->neg_pad;
+    p.clk = a->clock_probe;
     const int slots = 64 / G;
     const int jobs = (a->num_items + slots - 1) / slots;
     const int maxWpb = opal_max_waves_per_block(a->width);
@@ -446,6 +456,7 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
     p.ovfCount = a->overflow_count; p.ovfItems = a->overflow_items;
     p.chunkRows = a->query_length;
     p.satLimit = a->sat_limit; p.negPad = a->neg_pad;
+    p.clk = a->clock_probe;
     sp.next = next_counter;
     // persistent workgroups: one per CU (16 waves = 4 per SIMD), fewer when there are not enough sequences to go round
     const int perBlock = STREAM_WAVES * (64 / G);

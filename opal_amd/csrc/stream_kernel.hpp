@@ -53,7 +53,7 @@ __host__ __device__ inline int opal_stream_stride(int G, int S) {
 }
 template <int WIDTH>
 __host__ __device__ inline size_t opal_stream_lds_bytes(int G, int S, int A) {
-    return (size_t)(A + 3) * (size_t)opal_stream_stride<WIDTH>(G, S) + (size_t)STREAM_WAVES * (64 / G) * STREAM_RING * STREAM_DESC_BYTES;
+    return (size_t)(A + 3) * (size_t)opal_stream_stride<WIDTH>(G, S) + (size_t)STREAM_WAVES * (64 / G) * STREAM_RING * STREAM_DESC_BYTES + 32;  // (+32: clock-probe slot)
 }
 
 
@@ -146,6 +146,8 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     const int Q = p.Q, A = p.A;
     const int padTop = G * S - Q;  // virtual rows above the query (profile 0: H, E, F stay 0 there)
     const int PAD = A, SEP1 = A + 1, SEP2 = A + 2;
+    unsigned char* const clkSlot = lds + (size_t)(A + 3) * stride + (size_t)STREAM_WAVES * (64 >> log2G) * STREAM_RING * STREAM_DESC_BYTES;
+    clk_begin(p.clk, clkSlot);
 
     // ---- stage the profile: QP[letter][k][j]; letters A (beyond a slot's last sequence), A+1, A+2 (separators)
     {
@@ -366,6 +368,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
             }
         }
     }
+    clk_end(clkSlot);
 }
 
 // ------------------------------------------------------------------ NW / HW / OV as a stream of sequences
@@ -390,7 +393,7 @@ __host__ __device__ inline int opal_gl_init_entries(int S) { return 2 * ((S + 3)
 template <int WIDTH>
 __host__ __device__ inline size_t opal_gl_stream_lds_bytes(int G, int S, int A) {
     return (size_t)(A + 1) * (size_t)opal_gl_stream_stride<WIDTH>(G, S) + (size_t)G * opal_gl_init_entries(S) * 4 +
-           (size_t)STREAM_WAVES * (64 / G) * STREAM_RING * STREAM_DESC_BYTES;
+           (size_t)STREAM_WAVES * (64 / G) * STREAM_RING * STREAM_DESC_BYTES + 32;  // (+32: clock-probe slot)
 }
 
 template <int WIDTH, int MODE, int S>
@@ -424,6 +427,8 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
     const int PAD = A;
     const int sk = 2 * Ge;  // the skewed diagonal: H'(j,s) = H'(j-1,s-1) + P + 2*Ge
     unsigned char* const initBase = lds + (size_t)(A + 1) * stride;
+    unsigned char* const clkSlot = initBase + (size_t)G * INIT * 4 + (size_t)STREAM_WAVES * (64 >> log2G) * STREAM_RING * STREAM_DESC_BYTES;
+    clk_begin(p.clk, clkSlot);
 
     // ---- stage the profile (+2*Ge) and every lane's boundary block
     {
@@ -662,6 +667,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
         }
         sRv = V::adds(sRv, Rv);
     }
+    clk_end(clkSlot);
 }
 
 StreamFn opal_stream_s17(int rows);     // width 17 (4-byte profile entries), score only: rows 1..40

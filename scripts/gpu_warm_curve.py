@@ -10,7 +10,7 @@ from opal_amd.score_matrix import blosum50
 res, offs, lens = synth.database(100000, seed=42); q = synth.query(300, seed=7); m = blosum50()[1]
 pdb = PreparedDb(res, offs); score = torch.zeros(100000, dtype=torch.int32, device="cuda")
 t0 = time.perf_counter(); ks = []
-for it in range(4000):
+for it in range(2500):
     rc, kms = pdb.search_device(q, 11, 1, m, 0, 3, score.data_ptr())
     ks.append(kms)
     if (it + 1) % 250 == 0:

@@ -88,6 +88,83 @@ def test_two_rank_balanced_deal_and_gather(tmp_path, oracle):
     np.testing.assert_array_equal(got, want)
 
 
+def _worker_plan(rank, world, port, out_path, total):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    all_lens = synth.lengths(42, 0, total)
+    owned_lists = shard.deal(all_lens, world)
+    owned = owned_lists[rank]
+    plan = shard.GatherPlan(owned_lists, 3, "cpu", root=rank == 0)
+    res, offs, lens = synth.database_subset(owned, 42, lens=all_lens[owned])
+    db = [res[offs[i]:offs[i + 1]] for i in range(len(owned))]
+    rc, s, eq, et = oracle_lib.Oracle().search(synth.query(QLEN, seed=7), db, 11, 1, blosum50()[1], 1, oracle_lib.MODE_SW)
+    assert rc == 0
+    block = torch.full((3 * plan.npad,), -99, dtype=torch.int32)
+    for k, v in enumerate((s, eq, et)):
+        block[k * plan.npad:k * plan.npad + len(owned)] = torch.from_numpy(v.copy())
+    for _ in range(2):  # the buffers of a plan are reused from step to step
+        glob = plan.gather(block, rank)
+    dist.barrier()
+    if rank == 0:
+        np.save(out_path, glob.numpy())
+    else:
+        assert glob is None
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_plan_one_index_operation(tmp_path, oracle):
+    """bench.py's exchange as it runs with N > 1: every rank sends ONE padded {score, endQ, endT} block, the root puts all
+    three vectors back into database order with one index_select."""
+    world, total = 2, 300
+    out = str(tmp_path / "plan.npy")
+    mp.spawn(_worker_plan, args=(world, _free_port(), out, total), nprocs=world, join=True)
+    got = np.load(out)
+    res, offs, lens = synth.database(total, seed=42)
+    db = [res[offs[i]:offs[i + 1]] for i in range(total)]
+    rc, s, eq, et = oracle.search(synth.query(QLEN, seed=7), db, 11, 1, blosum50()[1], 1, oracle_lib.MODE_SW)
+    np.testing.assert_array_equal(got[0], s)
+    np.testing.assert_array_equal(got[1], eq)
+    np.testing.assert_array_equal(got[2], et)
+
+
+def test_bench_launcher_kills_the_other_ranks_when_one_dies():
+    """bench.py --gpus 2 with rank 1 failing before the rendezvous and rank 0 stuck (both hooks act before torch or the GPU
+    are touched, so this runs anywhere): the parent must notice, kill rank 0 and return non-zero within seconds, with the
+    ranks' stderr tails in its own."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_FAIL_RANK="1", BENCH_HANG_RANK="0")
+    env.pop("RANK", None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0
+    assert time.time() - t0 < 20
+    assert "rank 1 exited with code 7" in p.stderr and "failing on request" in p.stderr
+    # ... and the deadline: every rank stuck
+    env = dict(os.environ, BENCH_HANG_RANK="0,1", BENCH_DEADLINE_S="2")
+    env.pop("RANK", None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "deadline" in p.stderr and time.time() - t0 < 20
+
+
+def test_sprot_lengths_have_the_published_shape():
+    """The "sprot" length distribution (bench.py --workload sprot): Swiss-Prot-like body, a real tail."""
+    lens = synth.lengths(42, 0, synth.SPROT_SEQS, "sprot")
+    assert len(lens) == 541762 and lens.max() == synth.SPROT_MAX_LEN and lens.min() >= 30
+    assert 340 < lens.mean() < 370 and 150 < (lens > 5000).sum() < 400 and (lens > 20000).sum() >= 10
+    # a slice equals the same slice of the whole (counter-based generator), and stride-separated residues do not overlap
+    assert (synth.lengths(42, 1000, 500, "sprot") == lens[1000:1500]).all()
+    ids = np.argsort(lens)[-2:]
+    r, o, l = synth.database_subset(ids, 42, lens=lens[ids], stride=synth.SPROT_STRIDE)
+    assert len(r) == int(lens[ids].sum())
+
+
 def test_deal_balances_residues_and_partitions():
     lens = synth.lengths(42, 0, 50000)
     for world in (1, 2, 4, 8):

@@ -300,6 +300,22 @@ def test_two_rank_bench_on_one_gpu():
     assert one["verify"]["score_crc32"] == two["verify"]["score_crc32"]
 
 
+def test_bench_launcher_failing_rank_on_gpu():
+    """`bench.py --gpus 2` with rank 1 dying before the rendezvous while rank 0 really waits in it (gloo, shared GPU): the
+    parent kills rank 0 and returns non-zero within seconds instead of sitting out the rendezvous timeout."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_FAIL_RANK="1", BENCH_SHARE_GPU="1", BENCH_BACKEND="gloo")
+    env.pop("RANK", None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--total-seqs", "30000", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-e2e"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "rank 1 exited with code 7" in p.stderr
+    assert time.time() - t0 < 20
+
+
 def test_api_context_reuse_and_multi_device(oracle):
     """opalSearchDatabase keeps its device buffers between calls (cached contexts) and can shard one call over
     several GPUs (OPAL_HIP_DEVICES; "0,0" = two contexts on this box's one GPU): growing and shrinking databases,
