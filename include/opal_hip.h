@@ -49,9 +49,12 @@ typedef struct OpalHipLaunch {
     const int* score_matrix;     /* [alphabet_length^2], row = query letter */
     int alphabet_length;
     int gap_open, gap_ext;
-    /* packed database (see PackedDb in opal_api.cpp / DESIGN.md "data layout") */
-    const uint16_t* tokens;      /* per pair: max(lenA,lenB) entries, low byte = residue of A, high byte = B */
-    const uint64_t* pair_token_offset; /* [num_pairs] start of each pair's token stream */
+    /* packed database (OpalxDb in opal_internal.hpp / DESIGN.md "data layout"): the sequences sorted by length, longest
+       first; item i = position in that order = pair * 2 + half */
+    const unsigned char* residues;  /* one byte per residue, sequence after sequence in item order */
+    const uint64_t* seq_offset;     /* [items] start of each sequence in `residues` */
+    const uint16_t* tokens;      /* width 16 only. Per pair (items 2p, 2p+1): max(lenA,lenB) entries, low byte = residue of A, high byte = B */
+    const uint64_t* pair_token_offset; /* width 16 only. [num_pairs] start of each pair's token stream */
     const int* pair_len;         /* [2*num_pairs] lengths of A and B (0 = absent) */
     const int* pair_seq;         /* [2*num_pairs] caller index of A and B (-1 = absent) */
     /* work list: item i is work[i] if work != NULL else first_item + i.
@@ -75,7 +78,7 @@ typedef struct OpalHipLaunch {
        than lanes_per_seq*rows_per_lane; NW: only the LAST one. */
     int chunk_flags;
     int chunk_row0, chunk_rows;
-    void* boundary;       /* 16 bytes per token of the packed database */
+    void* boundary;       /* 8 bytes per residue of the packed database (width 16: per token) */
     /* width 17 only: additions wrap, so scores >= sat_limit (= 32767 - largest matrix entry) are handed to
        the re-run list; neg_pad is the profile value of padding columns (SW: -sat_limit, else 0) */
     int sat_limit, neg_pad;
@@ -146,10 +149,14 @@ void* opal_hip_stream_create(void);       /* non-blocking stream: ordered only t
 void* opal_hip_stream_create_high(void);  /* the same at the device's highest stream priority */
 void opal_hip_stream_destroy(void* stream);
 int opal_hip_stream_wait_event(void* stream, void* event);
-/* Interleave raw residues into the packed token streams on the device: for every pair p and column c,
+/* Interleave residues into the pair token streams of the width-16 kernels, on the device: for every pair p and column c,
    tokens[pair_off[p] + c] = raw[raw_off[2p] + c] | (c < pair_len[2p+1] ? raw[raw_off[2p+1] + c] : 0) << 8. */
 int opal_hip_pack_tokens(const unsigned char* raw, const uint64_t* raw_off, const uint64_t* pair_off,
                          const int* pair_len, int num_pairs, uint16_t* tokens, uint64_t tokens_capacity, void* stream);
+/* Copy `count` sequences on the device: dst[dst_off[i] + c] = src[src_off[i] + c] for c < len[i] (a database handed over
+   as one flat device buffer in caller order, into item order). */
+int opal_hip_reorder_residues(const unsigned char* src, const uint64_t* src_off, const uint64_t* dst_off, const int* len,
+                              int count, unsigned char* dst, void* stream);
 /* Enqueue one DP kernel. 0 on success, non-zero if the shape is not launchable. */
 int opal_hip_launch(const OpalHipLaunch* args);
 /* Smallest rows_per_lane >= min_rows for which this kernel variant is instantiated (0: none).
@@ -177,8 +184,8 @@ typedef struct OpalHipRevLaunch {
     const unsigned char* query; int query_length;
     const int* score_matrix; int alphabet_length;
     int gap_open, gap_ext;
-    const uint16_t* tokens; const uint64_t* pair_token_offset;
-    const int* seq_item;          /* [N] caller index -> pair*2 + half in the packed database */
+    const unsigned char* residues; const uint64_t* seq_offset;   /* the packed database (see OpalHipLaunch) */
+    const int* seq_item;          /* [N] caller index -> item in the packed database */
     const int* items; int num_items;   /* caller indices to process (NULL: 0..num_items-1) */
     const int* score; const int* end_query; const int* end_target;   /* [N], caller order */
     int* start_query; int* start_target;                             /* [N], caller order */
@@ -201,8 +208,8 @@ typedef struct OpalHipTraceLaunch {
     const unsigned char* query; int alphabet_length;
     const int* score_matrix;
     int gap_open, gap_ext;
-    const uint16_t* tokens; const uint64_t* pair_token_offset;
-    const int* seq_item;           /* [N] caller index -> pair*2 + half in the packed database */
+    const unsigned char* residues; const uint64_t* seq_offset;   /* the packed database (see OpalHipLaunch) */
+    const int* seq_item;           /* [N] caller index -> item in the packed database */
     const int* items; int num_items;    /* caller indices of this batch */
     int max_rows;                  /* largest number of box rows (endQ - startQ + 1) in the batch */
     const int* end_query; const int* end_target; const int* start_query; const int* start_target;   /* [N], caller order */

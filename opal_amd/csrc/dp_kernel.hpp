@@ -19,7 +19,8 @@
 //     once per block in LDS, laid out [letter][lane k][row j]; every read is one naturally aligned
 //     ds_read_b128 (8 rows of int16, 4 rows of 4-byte entries); lanes that hold the same letter
 //     broadcast, different letters fall in different 16-byte bank slots (odd letter stride).
-//   * Database residues stream from HBM as 16-bit tokens (low byte: sequence A, high byte: B).
+//   * Database residues stream from HBM one byte per column (the sequences sorted by length, back to back); only the
+//     packed kernels of width 16 read 16-bit tokens (low byte: sequence A, high byte: B of a pair).
 //   * The 16-bit kernels hand scores at their limit to a re-run list that the host schedules at
 //     width 32 (the 16 -> 32 bit rung of the reference's precision ladder, opal.cpp:496-535 /
 //     :983-1021; gfx950 has no packed 8-bit VALU, so an 8-bit rung would only add work).
@@ -54,10 +55,12 @@ struct KParams {
     const unsigned char* query;
     const int* matrix;
     int Q, A, Go, Ge;
-    const uint16_t* tokens;
-    const uint64_t* pairOff;
-    const int* pairLen;
-    const int* pairSeq;
+    const unsigned char* res;  // residues of every sequence (item order = sorted by length, longest first), one byte each
+    const uint64_t* seqOff;    // [items] where each one starts
+    const uint16_t* tokens;    // width 16 only: per pair (items 2p, 2p+1), column by column, residue of A | residue of B << 8
+    const uint64_t* pairOff;   // width 16 only: [pairs] start of each pair's token stream
+    const int* pairLen;        // [items] lengths (item = pair * 2 + half)
+    const int* pairSeq;        // [items] caller indices (-1: absent)
     const int* work;
     int firstItem, numItems, log2G;
     int* outScore;
@@ -69,7 +72,7 @@ struct KParams {
     // FLAG_MULTI only: this launch covers query rows [q0, q0+chunkRows); chunkFlags bit0 = a chunk above
     // exists (read its bottom row from `bnd`), bit1 = a chunk below exists (write ours to `bnd`).
     int q0, chunkRows, chunkFlags;
-    uint2* bnd;    // per column {H, F-input} of the chunk boundary: width 16 [tokOff+c], width 32 [2*(tokOff+c)+half]
+    uint2* bnd;    // per column {H, F-input} of the chunk boundary: [token offset + c] (width 16: of the pair's stream, else of the sequence)
     int* scratch;  // [2N] OV only: last-column maximum and its row carried across chunks
     int satLimit, negPad;  // width 17 only
     // Clock probe (bench.py, off = nullptr): wave 0 of every workgroup adds the shader cycles (s_memtime) and the
@@ -466,7 +469,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
         const int item = p.work ? p.work[w] : w;
         pairIdx = (NH == 2) ? item : (item >> 1);
         half0 = (NH == 2) ? 0 : (item & 1);
-        tokBase = p.pairOff[pairIdx];
+        tokBase = (NH == 2) ? p.pairOff[pairIdx] : p.seqOff[item];
 #pragma unroll
         for (int h = 0; h < NH; h++) {
             len[h] = p.pairLen[2 * pairIdx + half0 + h];
@@ -544,10 +547,11 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
     unsigned tokq[NH];
 #pragma unroll
     for (int h = 0; h < NH; h++) tokq[h] = padOff;
+    auto token = [&](int col) -> unsigned { return NH == 2 ? (unsigned)p.tokens[tokBase + (uint64_t)col] : (unsigned)p.res[tokBase + (uint64_t)col]; };
     unsigned tokNext = 0;
-    if (k < slotLen) tokNext = p.tokens[tokBase + (uint64_t)k];
+    if (k < slotLen) tokNext = token(k);
     // chunk boundary prefetch (one step ahead): {H, F-input} of the row above my chunk at the next column
-    auto bndIdx = [&](int c) -> uint64_t { return NH == 2 ? tokBase + (uint64_t)c : 2 * (tokBase + (uint64_t)c) + (uint64_t)half0; };
+    auto bndIdx = [&](int c) -> uint64_t { return tokBase + (uint64_t)c; };
     uint2 bndNext = make_uint2(0u, 0u);
     if (hasPrev && 0 < slotLen) bndNext = p.bnd[bndIdx(0)];
 
@@ -558,12 +562,11 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
         if ((sn & (G - 1)) == 0) {  // wave-uniform: refill the queue with columns sn .. sn+G-1
             const unsigned tok = tokNext;
             const int col = sn + k;
-            if (col + G < slotLen) tokNext = p.tokens[tokBase + (uint64_t)(col + G)];
+            if (col + G < slotLen) tokNext = token(col + G);
 #pragma unroll
             for (int h = 0; h < NH; h++) {
-                unsigned mine;
+                unsigned mine = tok;
                 if (NH == 2) mine = (h == 0) ? (tok & 0xffu) : ((tok >> 8) & 0xffu);
-                else mine = half0 ? ((tok >> 8) & 0xffu) : (tok & 0xffu);
                 tokq[h] = (col < len[h]) ? ldsBase + mine * (unsigned)stride : padOff;
             }
         }

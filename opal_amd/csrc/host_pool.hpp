@@ -4,8 +4,12 @@
 // once the DP itself takes under two milliseconds).
 //
 // One job at a time (submissions from several caller threads queue up); the submitting thread works
-// too. The pool is created on first use and intentionally never destroyed: joining threads from a
+// too (parallel_for) or goes on with its own work while the workers run the job (begin / end: opalSearchDatabase
+// launches the search of the sequences that have reached the device while the workers are still gathering the rest).
+// The pool is created on first use and intentionally never destroyed: joining threads from a
 // static destructor, after the HIP runtime has begun to shut down, is a known way to hang at exit.
+// After fork() the child has no worker threads (only the forking thread survives): the pool notices the new pid and
+// runs jobs inline there instead of waiting for workers that do not exist.
 #pragma once
 #include <atomic>
 #include <condition_variable>
@@ -14,6 +18,8 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+
+#include <unistd.h>
 
 class HostPool {
 public:
@@ -39,7 +45,7 @@ public:
     // fn(task) for task in [0, ntasks); returns when every task has finished.
     void parallel_for(int ntasks, const std::function<void(int)>& fn) {
         if (ntasks <= 0) return;
-        if (ntasks == 1 || workers_.empty()) {
+        if (ntasks == 1 || workers_.empty() || getpid() != pid_) {
             for (int t = 0; t < ntasks; t++) fn(t);
             return;
         }
@@ -59,6 +65,37 @@ public:
         job_ = nullptr;
     }
 
+    // The same job run by the WORKERS ONLY: begin() returns at once, the caller does something else and calls end()
+    // (exactly once) to wait for the last task. Tasks are handed out in increasing order. `fn` must stay alive until
+    // end() returns. With no workers (one hardware thread, or a forked child) the tasks run inside begin().
+    void begin(int ntasks, const std::function<void(int)>& fn) {
+        submit_.lock();  // held until end(): one job at a time
+        if (ntasks <= 0 || workers_.empty() || getpid() != pid_) {
+            for (int t = 0; t < ntasks; t++) fn(t);
+            asyncActive_ = false;
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &fn;
+            ntasks_ = ntasks;
+            next_.store(0, std::memory_order_relaxed);
+            active_ = (int)workers_.size();
+            gen_++;
+        }
+        asyncActive_ = true;
+        cvWork_.notify_all();
+    }
+    void end() {
+        if (asyncActive_) {
+            std::unique_lock<std::mutex> lk(m_);
+            cvDone_.wait(lk, [&] { return active_ == 0; });
+            job_ = nullptr;
+            asyncActive_ = false;
+        }
+        submit_.unlock();
+    }
+
     static int default_threads() {
         unsigned nt = std::thread::hardware_concurrency();
         if (nt == 0) nt = 1;
@@ -71,7 +108,7 @@ public:
     }
 
 private:
-    explicit HostPool(int threads) {
+    explicit HostPool(int threads) : pid_(getpid()) {
         for (int i = 1; i < threads; i++) {
             workers_.emplace_back([this] { worker(); });
             workers_.back().detach();
@@ -105,6 +142,8 @@ private:
     }
 
     std::vector<std::thread> workers_;
+    const pid_t pid_;           // the process that owns the worker threads
+    bool asyncActive_ = false;  // between begin() and end(), protected by submit_
     std::mutex m_, submit_;
     std::condition_variable cvWork_, cvDone_;
     const std::function<void(int)>* job_ = nullptr;

@@ -183,6 +183,29 @@ extern "C" int opal_hip_pack_tokens(const unsigned char* raw, const uint64_t* ra
     return e == hipSuccess ? 0 : fail("pack kernel launch", e);
 }
 
+// One wave per sequence: a database handed over as one flat device buffer (caller order) into item order.
+__global__ void __launch_bounds__(256) opal_reorder_kernel(const unsigned char* __restrict__ src, const uint64_t* __restrict__ srcOff,
+                                                           const uint64_t* __restrict__ dstOff, const int* __restrict__ len, int count,
+                                                           unsigned char* __restrict__ dst) {
+    const int lane = threadIdx.x & 63;
+    const int i = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (i >= count) return;
+    const unsigned char* a = src + srcOff[i];
+    unsigned char* d = dst + dstOff[i];
+    const int n = len[i];
+    for (int c = lane; c < n; c += 64) d[c] = a[c];
+}
+
+extern "C" int opal_hip_reorder_residues(const unsigned char* src, const uint64_t* src_off, const uint64_t* dst_off, const int* len,
+                                         int count, unsigned char* dst, void* stream) {
+    if (count <= 0) return 0;
+    const int wpb = 4;
+    hipLaunchKernelGGL(opal_reorder_kernel, dim3((count + wpb - 1) / wpb), dim3(wpb * 64), 0, (hipStream_t)stream, src, src_off, dst_off,
+                       len, count, dst);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("reorder kernel launch", e);
+}
+
 // Degenerate shapes (empty targets, empty query) are answered on the host: their values reach the
 // caller-order result arrays through one small scatter instead of one copy per sequence.
 __global__ void opal_scatter_results_kernel(const int* __restrict__ quad, int count, int* __restrict__ score,
@@ -314,6 +337,7 @@ extern "C" int opal_hip_launch_uber(const OpalHipUberLaunch* u) {
     KParams& b = p.base;
     b.query = a->query; b.matrix = a->score_matrix; b.Q = a->query_length; b.A = a->alphabet_length;
     b.Go = a->gap_open; b.Ge = a->gap_ext;
+    b.res = a->residues; b.seqOff = a->seq_offset;
     b.tokens = a->tokens; b.pairOff = a->pair_token_offset; b.pairLen = a->pair_len; b.pairSeq = a->pair_seq;
     b.work = nullptr;
     b.outScore = a->out_score; b.outEndQ = a->out_end_query; b.outEndT = a->out_end_target;
@@ -366,6 +390,7 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
     memset(&p, 0, sizeof p);
     p.query = a->query; p.matrix = a->score_matrix; p.Q = a->query_length; p.A = a->alphabet_length;
     p.Go = a->gap_open; p.Ge = a->gap_ext;
+    p.res = a->residues; p.seqOff = a->seq_offset;
     p.tokens = a->tokens; p.pairOff = a->pair_token_offset; p.pairLen = a->pair_len; p.pairSeq = a->pair_seq;
     p.work = a->work; p.firstItem = a->first_item; p.numItems = a->num_items; p.log2G = log2G;
     p.outScore = a->out_score; p.outEndQ = a->out_end_query; p.outEndT = a->out_end_target;
@@ -450,6 +475,7 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
     KParams& p = sp.base;
     p.query = a->query; p.matrix = a->score_matrix; p.Q = a->query_length; p.A = a->alphabet_length;
     p.Go = a->gap_open; p.Ge = a->gap_ext;
+    p.res = a->residues; p.seqOff = a->seq_offset;
     p.tokens = a->tokens; p.pairOff = a->pair_token_offset; p.pairLen = a->pair_len; p.pairSeq = a->pair_seq;
     p.firstItem = a->first_item; p.numItems = a->num_items; p.log2G = log2G;
     p.outScore = a->out_score; p.outEndQ = a->out_end_query; p.outEndT = a->out_end_target;  /* (SW score only: NULL) */

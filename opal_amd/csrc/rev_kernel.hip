@@ -37,8 +37,8 @@ struct RevParams {
     const unsigned char* query;
     int Q, A, Go, Ge, mode;
     const int* matrix;
-    const uint16_t* tokens;
-    const uint64_t* pairOff;
+    const unsigned char* res;   // residues, one byte per column (item order)
+    const uint64_t* seqOff;     // [items] start of each sequence
     const int* seqItem;   // caller index -> pair*2 + half
     const int* items;     // caller indices to process (NULL: 0..numItems-1)
     int numItems;
@@ -84,8 +84,7 @@ __global__ void __launch_bounds__(REV_WAVES_PER_BLOCK * 64) opal_rev_kernel(cons
         return;
     }
     const int item = p.seqItem[seq];
-    const uint16_t* tok = p.tokens + p.pairOff[item >> 1];
-    const int hiHalf = item & 1;
+    const unsigned char* tok = p.res + p.seqOff[item];
 
     const int r0 = lane * S;  // my first row of the reversed prefix
     int Hp[S], En[S], qoff[S];
@@ -114,7 +113,7 @@ __global__ void __launch_bounds__(REV_WAVES_PER_BLOCK * 64) opal_rev_kernel(cons
         int fresh = 0;
         if (s < at) {
             const unsigned t = tok[eT - s];
-            fresh = hiHalf ? (int)((t >> 8) & 0xffu) : (int)(t & 0xffu);
+            fresh = (int)t;
         }
         const int shifted = rev_shr1(tLetter);
         tLetter = lane == 0 ? fresh : shifted;
@@ -233,7 +232,7 @@ extern "C" int opal_hip_rev_launch(const OpalHipRevLaunch* a) {
     if (lds > 64 * 1024) return 2;
     RevParams p;
     p.query = a->query; p.Q = a->query_length; p.A = a->alphabet_length; p.Go = a->gap_open; p.Ge = a->gap_ext; p.mode = a->mode;
-    p.matrix = a->score_matrix; p.tokens = a->tokens; p.pairOff = a->pair_token_offset; p.seqItem = a->seq_item;
+    p.matrix = a->score_matrix; p.res = a->residues; p.seqOff = a->seq_offset; p.seqItem = a->seq_item;
     p.items = a->items; p.numItems = a->num_items;
     p.score = a->score; p.endQ = a->end_query; p.endT = a->end_target;
     p.startQ = a->start_query; p.startT = a->start_target; p.flags = a->flags; p.redo = a->redo; p.exactRow = a->exact_row;

@@ -64,7 +64,7 @@ struct SlotStream {
     int coveredEnd = 0;   // stream position where it ends (INT_MAX once the item range is exhausted)
     int lastEnd = 0;      // end of the last real entry
     bool done = false;
-    unsigned tokNext = 0, shiftNext = 0;  // token (or letter) of the position fetched last, and the shift that selects its byte
+    unsigned tokNext = 0;  // letter of the position fetched last
 };
 
 // Token of stream position x for lane k of a slot (x - k is a multiple of G; called by all lanes of the wave together):
@@ -73,7 +73,7 @@ struct SlotStream {
 // issues the token load, which is consumed a batch later. SEPS separator columns (letters PAD+1 .. PAD+SEPS) follow every
 // sequence; an entry spans at least 2G positions (pad columns after short sequences), which is what bounds the look-up
 // to two descriptors and the ring to four.
-// Descriptor: {start, len, caller index, byte shift, token offset lo, hi, item, running maximum (SW with end locations)}.
+// Descriptor: {start, len, caller index, -, residue offset lo, hi, item, running maximum (SW with end locations)}.
 template <int SEPS>
 __device__ __forceinline__ void stream_fetch(SlotStream& st, const KParams& p, int* next, int* ring, const int x, const int k,
                                              const int G, const int slotLane0, const int PAD) {
@@ -86,15 +86,14 @@ __device__ __forceinline__ void stream_fetch(SlotStream& st, const KParams& p, i
         if (need) {
             if (idx < p.numItems) {
                 const int item = p.firstItem + idx;
-                const int pairIdx = item >> 1, half = item & 1;
                 int len = p.pairLen[item];
                 const int seq = p.pairSeq[item];
                 if (seq < 0) len = 0;
-                const uint64_t tb = p.pairOff[pairIdx];
+                const uint64_t tb = p.seqOff[item];
                 const int span = max(len + SEPS, 2 * G);
                 if (k == 0) {
                     int* e = ring + (st.nEntries & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4);
-                    e[0] = st.coveredEnd; e[1] = len; e[2] = seq; e[3] = half * 8;
+                    e[0] = st.coveredEnd; e[1] = len; e[2] = seq; e[3] = 0;
                     e[4] = (int)(unsigned)(tb & 0xffffffffu); e[5] = (int)(unsigned)(tb >> 32); e[6] = item; e[7] = 0;
                 }
                 st.curStart = st.coveredEnd;
@@ -111,7 +110,7 @@ __device__ __forceinline__ void stream_fetch(SlotStream& st, const KParams& p, i
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    unsigned tok = (unsigned)PAD, sh = 0;
+    unsigned tok = (unsigned)PAD;
     if (st.nEntries > 0 && x < st.lastEnd) {
         const int e = (x >= st.curStart) ? (st.nEntries - 1) : (st.nEntries - 2);
         const int* d = ring + (e & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4);
@@ -119,13 +118,11 @@ __device__ __forceinline__ void stream_fetch(SlotStream& st, const KParams& p, i
         const int col = x - d0.x;
         if (col < d0.y) {
             const uint64_t tb = (uint64_t)(unsigned)d[4] | ((uint64_t)(unsigned)d[5] << 32);
-            tok = p.tokens[tb + (uint64_t)col];
-            sh = (unsigned)d0.w;
+            tok = p.res[tb + (uint64_t)col];
         } else if (SEPS >= 1 && col == d0.y) tok = (unsigned)(PAD + 1);
         else if (SEPS >= 2 && col == d0.y + 1) tok = (unsigned)(PAD + 2);
     }
     st.tokNext = tok;
-    st.shiftNext = sh;
 }
 
 template <int WIDTH, int S, bool SWEND = false>
@@ -192,7 +189,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     const int k = lane & (G - 1);
     const int slot = lane >> log2G;
     const int slots = 64 >> log2G;
-    // this slot's descriptor ring: {start, len, caller index, byte shift, token offset lo, hi, item, running maximum (SWEND)}
+    // this slot's descriptor ring: {start, len, caller index, -, residue offset lo, hi, item, running maximum (SWEND)}
     int* const ring = reinterpret_cast<int*>(lds + (size_t)(A + 3) * stride + (size_t)((wave * slots + slot) * STREAM_RING) * STREAM_DESC_BYTES);
     const int slotLane0 = lane & ~(G - 1);
 
@@ -222,7 +219,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
 
     for (int s = 0;; s++) {
         if ((s & (G - 1)) == 0) {  // wave-uniform: refill the queue with columns s .. s+G-1, fetch those of the next batch
-            const unsigned letter = (st.tokNext >> st.shiftNext) & 0xffu;
+            const unsigned letter = st.tokNext;
             fetch(s + G + k);
             tokq = ldsBase + letter * (unsigned)stride;
             // every slot has run dry and its last separator has left the last lane
@@ -517,7 +514,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
 
     for (int s = 0;; s++) {
         if ((s & (G - 1)) == 0) {
-            const unsigned letter = (st.tokNext >> st.shiftNext) & 0xffu;
+            const unsigned letter = st.tokNext;
             fetch(s + G + k);
             tokq = ldsBase + letter * (unsigned)stride;
             if (__ballot(!(st.done && s >= st.lastEnd + G)) == 0ull) break;

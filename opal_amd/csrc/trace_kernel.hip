@@ -28,8 +28,8 @@ struct TraceParams {
     const unsigned char* query;
     int A, Go, Ge;
     const int* matrix;
-    const uint16_t* tokens;
-    const uint64_t* pairOff;
+    const unsigned char* res;   // residues, one byte per column (item order)
+    const uint64_t* seqOff;     // [items] start of each sequence
     const int* seqItem;          // caller index -> pair*2 + half
     const int* items;            // caller indices of this batch
     int numItems;
@@ -62,8 +62,7 @@ __global__ void __launch_bounds__(TR_WAVES_PER_BLOCK * 64) opal_trace_kernel(con
     const int ld = (bq + 3) & ~3;
     const int Go = p.Go, Ge = p.Ge;
     const int item = p.seqItem[seq];
-    const uint16_t* tok = p.tokens + p.pairOff[item >> 1];
-    const int hiHalf = item & 1;
+    const unsigned char* tok = p.res + p.seqOff[item];
     unsigned char* const dirs = p.dirs + p.dirOff[w];
 
     const int r0 = lane * S;
@@ -86,7 +85,7 @@ __global__ void __launch_bounds__(TR_WAVES_PER_BLOCK * 64) opal_trace_kernel(con
         int fresh = 0;
         if (s < bt) {
             const unsigned t = tok[eT - s];
-            fresh = hiHalf ? (int)((t >> 8) & 0xffu) : (int)(t & 0xffu);
+            fresh = (int)t;
         }
         const int shifted = tr_shr1(tLetter);
         tLetter = lane == 0 ? fresh : shifted;
@@ -150,8 +149,7 @@ __global__ void __launch_bounds__(256) opal_walk_kernel(const TraceParams p) {
     const int bq = eQ - p.startQ[seq] + 1, bt = eT - p.startT[seq] + 1;
     const int ld = (bq + 3) & ~3;
     const int item = p.seqItem[seq];
-    const uint16_t* tok = p.tokens + p.pairOff[item >> 1];
-    const int hiHalf = item & 1;
+    const unsigned char* tok = p.res + p.seqOff[item];
     const unsigned char* const dirs = p.dirs + p.dirOff[w];
     unsigned char* const out = p.ops + p.opsOff[w];
     int ri = bq - 1, ci = bt - 1, n = 0;
@@ -164,7 +162,7 @@ __global__ void __launch_bounds__(256) opal_walk_kernel(const TraceParams p) {
             else if (src == 1u) state = 2;
             else {
                 const unsigned t = tok[eT - ci];
-                const unsigned tl = hiHalf ? ((t >> 8) & 0xffu) : (t & 0xffu);
+                const unsigned tl = t;
                 out[n++] = (unsigned)p.query[eQ - ri] == tl ? OPAL_ALIGN_MATCH : OPAL_ALIGN_MISMATCH;
                 ri--; ci--;
             }
@@ -209,7 +207,7 @@ extern "C" int opal_hip_trace_launch(const OpalHipTraceLaunch* a) {
     if (lds > 64 * 1024) return 2;
     TraceParams p;
     p.query = a->query; p.A = a->alphabet_length; p.Go = a->gap_open; p.Ge = a->gap_ext;
-    p.matrix = a->score_matrix; p.tokens = a->tokens; p.pairOff = a->pair_token_offset; p.seqItem = a->seq_item;
+    p.matrix = a->score_matrix; p.res = a->residues; p.seqOff = a->seq_offset; p.seqItem = a->seq_item;
     p.items = a->items; p.numItems = a->num_items;
     p.endQ = a->end_query; p.endT = a->end_target; p.startQ = a->start_query; p.startT = a->start_target;
     p.dirOff = a->dir_offset; p.dirs = a->dirs; p.opsOff = a->ops_offset; p.ops = a->ops; p.opsLen = a->ops_length;
