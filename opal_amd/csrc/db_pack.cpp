@@ -8,44 +8,82 @@ namespace opal_host {
 
 std::atomic<long long> g_counters[CNT_COUNT];
 
-// Order and pairing (no residue is touched): stable sort by length, longest first.
-void pack_order(int n, const int* lens, HostPack& out) {
-    out.numSeqs = n;
+// Order and pairing (no residue is touched): stable counting sort by length, longest first, spread over the pool's
+// threads (per-thread histograms; a thread places the sequences of its own caller range). Fills db->pairLen / pairSeq /
+// seqOff (item order) and db->emptySeqs. The byte offset of an item follows from its bucket alone: all sequences of a
+// bucket have the same length.
+static bool order_sequences(OpalxDb* db, int n, const int* lens) {
+    db->numSeqs = n;
+    db->emptySeqs.clear();
     int maxLen = 0;
     for (int i = 0; i < n; i++) maxLen = std::max(maxLen, lens[i]);
-    std::vector<int> order;
-    if (maxLen <= (1 << 22)) {  // counting sort
-        std::vector<int> start((size_t)maxLen + 2, 0);
-        for (int i = 0; i < n; i++) if (lens[i] > 0) start[(size_t)maxLen - lens[i] + 1]++;
-        for (size_t b = 1; b < start.size(); b++) start[b] += start[b - 1];
-        order.resize((size_t)start[(size_t)maxLen]);
-        for (int i = 0; i < n; i++) {
-            if (lens[i] > 0) order[(size_t)start[(size_t)maxLen - lens[i]]++] = i;
-            else out.emptySeqs.push_back(i);
-        }
-    } else {
+    const double slack = db->cached ? 1.15 : 1.0;
+    if (maxLen > (1 << 22)) {  // (absurd lengths: comparison sort)
+        std::vector<int> order;
         for (int i = 0; i < n; i++) {
             if (lens[i] > 0) order.push_back(i);
-            else out.emptySeqs.push_back(i);
+            else db->emptySeqs.push_back(i);
         }
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lens[a] > lens[b]; });
+        const size_t m = order.size(), items = (m + 1) / 2 * 2;
+        if (!db->pairLen.resize(items, slack) || !db->pairSeq.resize(items, slack) || !db->seqOff.resize(items, slack)) return false;
+        uint64_t total = 0;
+        for (size_t k = 0; k < items; k++) {
+            const bool have = k < m;
+            db->pairLen[k] = have ? lens[order[k]] : 0;
+            db->pairSeq[k] = have ? order[k] : -1;
+            db->seqOff[k] = total;
+            total += (uint64_t)db->pairLen[k];
+        }
+        db->residues = (int64_t)total;
+        db->numPairs = (int)(items / 2);
+        return true;
     }
-    const int m = (int)order.size();
-    const int P = (m + 1) / 2;
-    out.pairOff.resize((size_t)P);
-    out.pairLen.assign(2 * (size_t)P, 0);
-    out.pairSeq.assign(2 * (size_t)P, -1);
-    uint64_t total = 0;
-    for (int p = 0; p < P; p++) {
-        const int a = order[2 * (size_t)p];
-        const int b = (2 * p + 1 < m) ? order[2 * (size_t)p + 1] : -1;
-        out.pairSeq[2 * (size_t)p] = a; out.pairLen[2 * (size_t)p] = lens[a];
-        out.pairSeq[2 * (size_t)p + 1] = b; out.pairLen[2 * (size_t)p + 1] = b >= 0 ? lens[b] : 0;
-        out.pairOff[p] = total;
-        total += (uint64_t)lens[a];  // A is the longer one
-        out.residues += lens[a] + (b >= 0 ? lens[b] : 0);
+    HostPool& pool = HostPool::get();
+    const size_t B = (size_t)maxLen + 1;  // bucket b holds the sequences of length maxLen - b; length 0 is not placed
+    int T = n >= (1 << 16) ? std::min(pool.width(), 16) : 1;
+    while (T > 1 && (size_t)T * B > (4u << 20)) T /= 2;
+    std::vector<int> hist((size_t)T * B, 0);
+    auto range = [&](int t, int& i0, int& i1) { i0 = (int)((long long)n * t / T); i1 = (int)((long long)n * (t + 1) / T); };
+    pool.parallel_for(T, [&](int t) {
+        int i0, i1; range(t, i0, i1);
+        int* h = hist.data() + (size_t)t * B;
+        for (int i = i0; i < i1; i++) if (lens[i] > 0) h[(size_t)maxLen - lens[i]]++;
+    });
+    // bucket starts (item position and byte offset), and where every thread starts inside every bucket
+    std::vector<int> bucketPos(B + 1, 0);
+    std::vector<uint64_t> bucketByte(B + 1, 0);
+    int pos = 0;
+    uint64_t byte = 0;
+    for (size_t b = 0; b < B; b++) {
+        bucketPos[b] = pos; bucketByte[b] = byte;
+        const int before = pos;
+        for (int t = 0; t < T; t++) { int& h = hist[(size_t)t * B + b]; const int c = h; h = pos; pos += c; }
+        byte += (uint64_t)(pos - before) * (uint64_t)(maxLen - (int)b);
+        if ((int)b == maxLen - 1) break;  // (bucket maxLen = length 0: not placed)
     }
-    out.numTokens = total;
+    const int m = pos;
+    const size_t items = ((size_t)m + 1) / 2 * 2;
+    if (!db->pairLen.resize(items, slack) || !db->pairSeq.resize(items, slack) || !db->seqOff.resize(items, slack)) return false;
+    std::vector<std::vector<int>> empties((size_t)T);
+    int* const pl = db->pairLen.data(); int* const ps = db->pairSeq.data(); uint64_t* const so = db->seqOff.data();
+    pool.parallel_for(T, [&](int t) {
+        int i0, i1; range(t, i0, i1);
+        int* h = hist.data() + (size_t)t * B;
+        for (int i = i0; i < i1; i++) {
+            const int len = lens[i];
+            if (len <= 0) { empties[(size_t)t].push_back(i); continue; }
+            const size_t b = (size_t)maxLen - len;
+            const int at = h[b]++;
+            pl[at] = len; ps[at] = i;
+            so[at] = bucketByte[b] + (uint64_t)(at - bucketPos[b]) * (uint64_t)len;
+        }
+    });
+    for (auto& v : empties) db->emptySeqs.insert(db->emptySeqs.end(), v.begin(), v.end());
+    if ((size_t)m < items) { pl[m] = 0; ps[m] = -1; so[m] = byte; }
+    db->residues = (int64_t)byte;
+    db->numPairs = (int)(items / 2);
+    return true;
 }
 
 // The HIP "current device" is a per-thread setting, so the check (and the optional OPAL_HIP_DEVICE
@@ -68,132 +106,152 @@ bool device_ok() {
 }
 
 void db_release(OpalxDb* db) {
-    db->tokens.release(); db->pairOff.release(); db->dPairLen.release(); db->dPairSeq.release();
+    db->res.release(); db->dSeqOff.release(); db->dPairLen.release(); db->dPairSeq.release();
+    db->pairLen.release(); db->pairSeq.release(); db->seqOff.release();
+    db->tokens.release(); db->pairOff.release(); db->hPairOff.release();
     db->header.release(); db->hHeader.release(); db->ovfItems.release(); db->boundary.release(); db->scratch.release();
     db->results.release(); db->quads.release();
     db->ovfCount.p = nullptr; db->matrix.p = nullptr; db->query.p = nullptr;
     db->seqItem.release(); db->revFlags.release(); db->redo.release();
     db->trDirs.release(); db->trOps.release(); db->trOff.release(); db->trItems.release(); db->trOut.release();
-    db->raw.release(); db->rawOff.release(); db->hRaw.release(); db->hResults.release();
+    db->raw.release(); db->rawOff.release(); db->hRawOff.release(); db->hRaw.release(); db->hResults.release();
     for (void*& st : db->streams) { opal_hip_stream_destroy(st); st = nullptr; }
     opal_hip_stream_destroy(db->mainStream); db->mainStream = nullptr;
+    opal_hip_stream_destroy(db->copyStream); db->copyStream = nullptr;
+    opal_hip_stream_destroy(db->auxStream); db->auxStream = nullptr;
     for (void*& ev : db->events) { opal_hip_event_destroy(ev); ev = nullptr; }
+    for (void*& ev : db->gate.events) { opal_hip_event_destroy(ev); ev = nullptr; }
+    db->gate.events.clear();
 }
 
-/*
- * (Re)fill `db` with the packed form of `hp`. Residues come from
- *   RAW_POINTERS     getSeq(i): N separate host allocations -> gathered into pinned memory by the thread pool,
- *                    every ~2 MB chunk uploaded as soon as it is complete;
- *   RAW_HOST_FLAT    one contiguous host buffer (uploaded as it is, the device packer reads at hp.rawOff);
- *   RAW_DEVICE_FLAT  the same already in device memory (nothing is copied).
- * Buffers of a cached context are reused when large enough.
- */
-bool db_fill(OpalxDb* db, HostPack& hp, RawKind kind, const std::function<const unsigned char*(int)>& getSeq,
-                    const unsigned char* flat, const int* orderLens, int orderN) {
+bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::function<const unsigned char*(int)>& getSeq,
+             const unsigned char* flatDevice, const std::function<uint64_t(int)>& flatOff, bool async) {
     db->device = opal_hip_get_device();
-    const double slack0 = db->cached ? 1.15 : 1.0;
-    const unsigned char* dRawEarly = nullptr;
-    if (kind == RAW_POINTERS && orderLens) {
-        // `hp` is not ordered yet: the residues are gathered in CALLER order (that needs the lengths only) while one pool
-        // task sorts and pairs the sequences (pack_order, ~0.3 ms for 100 000 sequences, used to run before the gather);
-        // the device packer finds every sequence through rawOff, whatever the order of the raw buffer.
-        void* st0 = db->main();
-        if (!st0) return false;
-        std::vector<uint64_t> callerOff((size_t)orderN + 1, 0);
-        for (int i = 0; i < orderN; i++) callerOff[(size_t)i + 1] = callerOff[(size_t)i] + (uint64_t)std::max(orderLens[i], 0);
-        const uint64_t total = callerOff[(size_t)orderN];
-        if (!db->raw.ensure(total + 16, slack0) || !db->hRaw.ensure(total + 16, slack0)) return false;
-        const uint64_t chunkBytes = 2u << 20;
-        std::vector<int> cut{0};
-        for (int i = 0; i < orderN; i++)
-            if (callerOff[(size_t)i] - callerOff[(size_t)cut.back()] >= chunkBytes) cut.push_back(i);
-        cut.push_back(orderN);
-        std::atomic<int> bad{0};
-        unsigned char* h = db->hRaw.p;
-        unsigned char* d = db->raw.p;
-        const int dev = db->device;
-        HostPool::get().parallel_for((int)cut.size(), [&](int t) {
-            if (t == 0) { pack_order(orderN, orderLens, hp); return; }
-            static thread_local int myDevice = -1;  // pool threads start on device 0: the copy below names a stream of `dev`
-            if (myDevice != dev) { opal_hip_set_device(dev); myDevice = dev; }
-            const int i0 = cut[(size_t)t - 1], i1 = cut[(size_t)t];
-            for (int i = i0; i < i1; i++)
-                if (orderLens[i] > 0) memcpy(h + callerOff[(size_t)i], getSeq(i), (size_t)orderLens[i]);
-            const uint64_t b0 = callerOff[(size_t)i0], b1 = callerOff[(size_t)i1];
-            if (b1 > b0 && opal_hip_memcpy_h2d(d + b0, h + b0, b1 - b0, st0)) bad.fetch_add(1);
-        });
-        if (bad.load()) return false;
-        hp.rawOff.resize(hp.pairSeq.size());
-        for (size_t i = 0; i < hp.pairSeq.size(); i++) hp.rawOff[i] = hp.pairSeq[i] >= 0 ? callerOff[(size_t)hp.pairSeq[i]] : 0;
-        hp.rawBytes = total;
-        dRawEarly = d;
-    }
-    const size_t P = hp.pairOff.size();
-    db->numSeqs = hp.numSeqs;
-    db->numPairs = (int)P;
-    db->residues = hp.residues;
-    db->pairLen.swap(hp.pairLen);
-    db->pairSeq.swap(hp.pairSeq);
-    db->emptySeqs.swap(hp.emptySeqs);
-    db->numTokens = hp.numTokens + 8;
+    db->gate.active = false;
     db->seqItemValid = false;
+    db->tokensValid = false;
     db->planCache.clear();
+    if (!order_sequences(db, n, lens)) return false;
+    const size_t items = db->pairLen.size();
     const double slack = db->cached ? 1.15 : 1.0;
     void* st = db->main();
-    bool ok = st && db->tokens.ensure(db->numTokens, slack) && db->pairOff.ensure(P, slack) && db->dPairLen.ensure(2 * P, slack) &&
-              db->dPairSeq.ensure(2 * P, slack) && db->ovfItems.ensure(2 * P, slack) &&
-              db->rawOff.ensure(2 * P, slack);
+    const uint64_t total = (uint64_t)db->residues;
+    bool ok = st && db->res.ensure(total + 16, slack) && db->dSeqOff.ensure(items, slack) && db->dPairLen.ensure(items, slack) &&
+              db->dPairSeq.ensure(items, slack) && db->ovfItems.ensure(items, slack);
     if (!ok) return false;
-    if (!P) return true;
-    const unsigned char* dRaw = nullptr;
-    if (dRawEarly) {
-        dRaw = dRawEarly;
-    } else if (kind == RAW_POINTERS) {
-        // rawOff = prefix sums of the lengths in pair order
-        hp.rawOff.resize(2 * P);
-        uint64_t total = 0;
-        for (size_t i = 0; i < 2 * P; i++) { hp.rawOff[i] = total; total += (uint64_t)db->pairLen[i]; }
-        hp.rawBytes = total;
-        if (!db->raw.ensure(total + 16, slack) || !db->hRaw.ensure(total + 16, slack)) return false;
-        // chunk boundaries: ~2 MB of residues each
-        const uint64_t chunkBytes = 2u << 20;
-        std::vector<size_t> cut{0};
-        for (size_t i = 0; i < 2 * P; i++)
-            if (hp.rawOff[i] - hp.rawOff[cut.back()] >= chunkBytes) cut.push_back(i);
-        cut.push_back(2 * P);
-        std::atomic<int> bad{0};
-        unsigned char* h = db->hRaw.p;
-        unsigned char* d = db->raw.p;
-        const std::vector<int>& seq = db->pairSeq;
-        const std::vector<int>& len = db->pairLen;
-        const int dev = db->device;
-        HostPool::get().parallel_for((int)cut.size() - 1, [&](int t) {
-            static thread_local int myDevice = -1;  // pool threads start on device 0: the copy below names a stream of `dev`
-            if (myDevice != dev) { opal_hip_set_device(dev); myDevice = dev; }
-            const size_t i0 = cut[(size_t)t], i1 = cut[(size_t)t + 1];
-            for (size_t i = i0; i < i1; i++)
-                if (seq[i] >= 0 && len[i] > 0) memcpy(h + hp.rawOff[i], getSeq(seq[i]), (size_t)len[i]);
-            const uint64_t b0 = hp.rawOff[i0], b1 = i1 < 2 * P ? hp.rawOff[i1] : total;
-            if (b1 > b0 && opal_hip_memcpy_h2d(d + b0, h + b0, b1 - b0, st)) bad.fetch_add(1);
-        });
-        if (bad.load()) return false;
-        dRaw = d;
-    } else if (kind == RAW_HOST_FLAT) {
-        if (!db->raw.ensure(hp.rawBytes + 16, slack)) return false;
-        if (hp.rawBytes && opal_hip_memcpy_h2d(db->raw.p, flat, hp.rawBytes, st)) return false;
-        dRaw = db->raw.p;
-    } else {
-        dRaw = flat;
+    if (!items) return true;
+    // (pinned sources: the copies need no wait on the host side)
+    ok = !opal_hip_memcpy_h2d(db->dSeqOff.p, db->seqOff.data(), items * sizeof(uint64_t), st) &&
+         !opal_hip_memcpy_h2d(db->dPairLen.p, db->pairLen.data(), items * sizeof(int), st) &&
+         !opal_hip_memcpy_h2d(db->dPairSeq.p, db->pairSeq.data(), items * sizeof(int), st);
+    if (!ok) return false;
+    if (kind == RAW_DEVICE_FLAT) {
+        // one flat device buffer in caller order -> item order, on the device
+        if (!db->hRawOff.resize(items, slack) || !db->rawOff.ensure(items, slack)) return false;
+        for (size_t i = 0; i < items; i++) db->hRawOff[i] = db->pairSeq[i] >= 0 ? flatOff(db->pairSeq[i]) : 0;
+        ok = !opal_hip_memcpy_h2d(db->rawOff.p, db->hRawOff.data(), items * sizeof(uint64_t), st) &&
+             !opal_hip_reorder_residues(flatDevice, db->rawOff.p, db->dSeqOff.p, db->dPairLen.p, (int)items, db->res.p, st);
+        if (opal_hip_stream_sync(st)) ok = false;  // the caller's buffer is only read during the call
+        if (ok && !db->cached) { db->rawOff.release(); db->hRawOff.release(); }
+        return ok;
     }
-    ok = !opal_hip_memcpy_h2d(db->rawOff.p, hp.rawOff.data(), 2 * P * sizeof(uint64_t), st) &&
-         !opal_hip_memcpy_h2d(db->pairOff.p, hp.pairOff.data(), P * sizeof(uint64_t), st) &&
-         !opal_hip_memcpy_h2d(db->dPairLen.p, db->pairLen.data(), 2 * P * sizeof(int), st) &&
-         !opal_hip_memcpy_h2d(db->dPairSeq.p, db->pairSeq.data(), 2 * P * sizeof(int), st) &&
-         !opal_hip_pack_tokens(dRaw, db->rawOff.p, db->pairOff.p, db->dPairLen.p, (int)P, db->tokens.p, db->numTokens, st);
-    // hp's vectors are pageable host memory read by the async copies above: wait before they go away
-    if (opal_hip_stream_sync(st)) ok = false;
-    if (ok && !db->cached) { db->raw.release(); db->rawOff.release(); db->hRaw.release(); }
+    // Host residues: gathered in ITEM order into pinned memory, chunk by chunk (~2 MB, fewer and larger chunks for
+    // gigabyte databases), every chunk uploaded on the copy stream as soon as it is complete.
+    if (!db->hRaw.ensure(total + 16, slack) || !db->copy()) return false;
+    UploadGate& g = db->gate;
+    const uint64_t chunkBytes = std::max<uint64_t>(2u << 20, total / 96);
+    g.cutItem.assign(1, 0);
+    for (size_t i = 0; i < items; i++)
+        if (db->seqOff[i] - db->seqOff[(size_t)g.cutItem.back()] >= chunkBytes) g.cutItem.push_back((int)i);
+    g.cutItem.push_back((int)items);
+    const int nchunks = (int)g.cutItem.size() - 1;
+    while ((int)g.events.size() < nchunks) {
+        void* ev = opal_hip_event_create();
+        if (!ev) return false;
+        g.events.push_back(ev);
+    }
+    if (g.stateCap < (size_t)nchunks) { g.state.reset(new std::atomic<int>[(size_t)nchunks]); g.stateCap = (size_t)nchunks; }
+    for (int c = 0; c < nchunks; c++) g.state[(size_t)c].store(0, std::memory_order_relaxed);
+    const int dev = db->device;
+    db->gatherFn = [db, getSeq, dev, total, items](int c) {
+        static thread_local int myDevice = -1;  // pool threads start on device 0: the copy below names a stream of `dev`
+        if (myDevice != dev) { opal_hip_set_device(dev); myDevice = dev; }
+        UploadGate& gg = db->gate;
+        const size_t i0 = (size_t)gg.cutItem[(size_t)c], i1 = (size_t)gg.cutItem[(size_t)c + 1];
+        unsigned char* h = db->hRaw.p;
+        const int* len = db->pairLen.data(); const int* seq = db->pairSeq.data(); const uint64_t* off = db->seqOff.data();
+        for (size_t i = i0; i < i1; i++)
+            if (seq[i] >= 0 && len[i] > 0) memcpy(h + off[i], getSeq(seq[i]), (size_t)len[i]);
+        const uint64_t b0 = off[i0], b1 = i1 < items ? off[i1] : total;
+        bool good = true;
+        if (b1 > b0 && opal_hip_memcpy_h2d(db->res.p + b0, h + b0, b1 - b0, db->copyStream)) good = false;
+        if (good && opal_hip_event_record(gg.events[(size_t)c], db->copyStream)) good = false;
+        gg.state[(size_t)c].store(good ? 1 : -1, std::memory_order_release);
+    };
+    g.active = true;
+    HostPool& pool = HostPool::get();
+    if (async) {
+        pool.begin(nchunks, db->gatherFn);
+        db->gatherPending = true;
+        return true;
+    }
+    pool.parallel_for(nchunks, db->gatherFn);
+    ok = gate_items(db, st, 0, (int)items);  // everything on `main` from here on comes after the last chunk
+    g.active = false;
+    db->gatherFn = nullptr;
+    if (ok && !db->cached) {
+        if (opal_hip_stream_sync(st)) ok = false;
+        db->hRaw.release();
+    }
     return ok;
+}
+
+bool db_fill_finish(OpalxDb* db) {
+    bool ok = true;
+    if (db->gatherPending) {
+        HostPool::get().end();
+        db->gatherPending = false;
+        for (int c = 0; c < db->gate.chunks(); c++)
+            if (db->gate.state[(size_t)c].load(std::memory_order_acquire) < 0) ok = false;
+        db->gatherFn = nullptr;
+    }
+    db->gate.active = false;
+    return ok;
+}
+
+bool gate_items(OpalxDb* db, void* stream, int firstItem, int count) {
+    UploadGate& g = db->gate;
+    if (!g.active || count <= 0) return true;
+    const int last = firstItem + count - 1;
+    const int c0 = (int)(std::upper_bound(g.cutItem.begin(), g.cutItem.end(), firstItem) - g.cutItem.begin()) - 1;
+    const int c1 = (int)(std::upper_bound(g.cutItem.begin(), g.cutItem.end(), last) - g.cutItem.begin()) - 1;
+    for (int c = std::max(c0, 0); c <= c1 && c < g.chunks(); c++) {
+        int s, spins = 0;
+        while ((s = g.state[(size_t)c].load(std::memory_order_acquire)) == 0) {
+            if (++spins < 2000) __builtin_ia32_pause();
+            else std::this_thread::yield();
+        }
+        if (s < 0 || opal_hip_stream_wait_event(stream, g.events[(size_t)c])) return false;
+    }
+    return true;
+}
+
+int ensure_pair_tokens(OpalxDb* db) {
+    if (db->tokensValid) return 0;
+    const size_t P = (size_t)db->numPairs;
+    const double slack = db->cached ? 1.15 : 1.0;
+    if (!db->hPairOff.resize(P, slack)) return 1;
+    uint64_t total = 0;
+    for (size_t p = 0; p < P; p++) { db->hPairOff[p] = total; total += (uint64_t)db->pairLen[2 * p]; }  // A is the longer one
+    db->numTokens = (size_t)total + 8;
+    void* st = db->main();
+    if (!db->tokens.ensure(db->numTokens, slack) || !db->pairOff.ensure(std::max<size_t>(P, 1), slack)) return 1;
+    if (!gate_items(db, st, 0, (int)(2 * P))) return 1;
+    if (P && (opal_hip_memcpy_h2d(db->pairOff.p, db->hPairOff.data(), P * sizeof(uint64_t), st) ||
+              opal_hip_pack_tokens(db->res.p, db->dSeqOff.p, db->pairOff.p, db->dPairLen.p, (int)P, db->tokens.p, db->numTokens, st)))
+        return 1;
+    db->tokensValid = true;
+    return 0;
 }
 
 }  // namespace opal_host
@@ -201,43 +259,35 @@ bool db_fill(OpalxDb* db, HostPack& hp, RawKind kind, const std::function<const 
 using namespace opal_host;
 
 // ------------------------------------------------------------------------------------ opalx_* API
-static OpalxDb* create_from(HostPack& hp, RawKind kind, const std::function<const unsigned char*(int)>& getSeq,
-                            const unsigned char* flat) {
+static OpalxDb* create_from(int n, const int* lens, RawKind kind, const std::function<const unsigned char*(int)>& getSeq,
+                            const unsigned char* flatDevice, const std::function<uint64_t(int)>& flatOff) {
     OpalxDb* db = new (std::nothrow) OpalxDb;
     if (!db) return nullptr;
-    if (!db_fill(db, hp, kind, getSeq, flat)) { opalx_db_destroy(db); return nullptr; }
+    if (!db_fill(db, n, lens, kind, getSeq, flatDevice, flatOff)) { opalx_db_destroy(db); return nullptr; }
     return db;
 }
 
 extern "C" OpalxDb* opalx_db_create(unsigned char* const db[], int db_length, const int db_seq_lengths[]) {
     if (!device_ok()) return nullptr;
-    HostPack hp;
-    pack_order(db_length, db_seq_lengths, hp);
-    return create_from(hp, RAW_POINTERS, [&](int i) { return (const unsigned char*)db[i]; }, nullptr);
+    return create_from(db_length, db_seq_lengths, RAW_POINTERS, [db](int i) { return (const unsigned char*)db[i]; }, nullptr, nullptr);
 }
 
-static void flat_offsets(const int64_t* offsets, int db_length, HostPack& hp) {
-    std::vector<int> lens((size_t)db_length);
+static std::vector<int> flat_lengths(const int64_t* offsets, int db_length) {
+    std::vector<int> lens((size_t)std::max(db_length, 0));
     for (int i = 0; i < db_length; i++) lens[(size_t)i] = (int)(offsets[i + 1] - offsets[i]);
-    pack_order(db_length, lens.data(), hp);
-    // already contiguous: the device packer reads each sequence at its offset
-    hp.rawOff.resize(hp.pairSeq.size());
-    for (size_t i = 0; i < hp.pairSeq.size(); i++) hp.rawOff[i] = hp.pairSeq[i] >= 0 ? (uint64_t)offsets[hp.pairSeq[i]] : 0;
-    hp.rawBytes = (uint64_t)offsets[db_length];
+    return lens;
 }
 
 extern "C" OpalxDb* opalx_db_create_flat(const unsigned char* residues, const int64_t* offsets, int db_length) {
     if (!device_ok()) return nullptr;
-    HostPack hp;
-    flat_offsets(offsets, db_length, hp);
-    return create_from(hp, RAW_HOST_FLAT, nullptr, residues);
+    const std::vector<int> lens = flat_lengths(offsets, db_length);
+    return create_from(db_length, lens.data(), RAW_POINTERS, [residues, offsets](int i) { return residues + offsets[i]; }, nullptr, nullptr);
 }
 
 extern "C" OpalxDb* opalx_db_create_flat_device(const unsigned char* d_residues, const int64_t* offsets, int db_length) {
     if (!device_ok()) return nullptr;
-    HostPack hp;
-    flat_offsets(offsets, db_length, hp);
-    return create_from(hp, RAW_DEVICE_FLAT, nullptr, d_residues);
+    const std::vector<int> lens = flat_lengths(offsets, db_length);
+    return create_from(db_length, lens.data(), RAW_DEVICE_FLAT, nullptr, d_residues, [offsets](int i) { return (uint64_t)offsets[i]; });
 }
 
 extern "C" void opalx_db_destroy(OpalxDb* db) {

@@ -13,7 +13,9 @@ static void fill_launch(OpalHipLaunch& a, const SearchCtx& c, int width, int swE
     a.width = width; a.mode = c.mode; a.want_end = swEndPass; a.detect_wrap = detectWrap;
     a.query = db->query.p; a.query_length = c.Q; a.score_matrix = db->matrix.p; a.alphabet_length = c.A;
     a.gap_open = c.Go; a.gap_ext = c.Ge;
-    a.tokens = db->tokens.p; a.pair_token_offset = db->pairOff.p; a.pair_len = db->dPairLen.p; a.pair_seq = db->dPairSeq.p;
+    a.residues = db->res.p; a.seq_offset = db->dSeqOff.p;
+    a.tokens = db->tokens.p; a.pair_token_offset = db->pairOff.p;  // (width 16 only: ensure_pair_tokens)
+    a.pair_len = db->dPairLen.p; a.pair_seq = db->dPairSeq.p;
     a.work = work;
     a.out_score = c.dScore; a.out_end_query = c.wantEnd ? c.dEndQ : nullptr; a.out_end_target = c.wantEnd ? c.dEndT : nullptr;
     a.overflow_count = ovfCounter; a.overflow_items = db->ovfItems.p;
@@ -45,7 +47,8 @@ static int launch_chunked(const SearchCtx& c, int width, int swEndPass, int dete
         return OPAL_ERR_NO_SIMD_SUPPORT;
     }
     OpalxDb* db = c.db;
-    if (!db->boundary.ensure(16 * (db->numTokens + 8)) || !db->scratch.ensure(2 * (size_t)std::max(db->numSeqs, 1)))
+    // (8 bytes per column of every item's -- width 16: every pair's -- residue stream)
+    if (!db->boundary.ensure(8 * ((size_t)db->residues + 16)) || !db->scratch.ensure(2 * (size_t)std::max(db->numSeqs, 1)))
         return OPAL_ERR_NO_SIMD_SUPPORT;
     int wpb = 4, ldsPad = 0;
     pick_occupancy(kernel_vgprs(width, c.mode, swEndPass, 1, 0, bestS), opal_hip_lds_bytes(width, bestG, bestS, c.A), &wpb, &ldsPad);
@@ -81,10 +84,41 @@ static int launch_chunked(const SearchCtx& c, int width, int swEndPass, int dete
     return 0;
 }
 
+// One class of a launch range on `stream` (a plain class launch). `side`: the launch belongs to a long-sequence class
+// beside the bulk (issue priority).
+static int launch_class(const SearchCtx& c, int width, int swEndPass, int detectWrap, const int* work, LaunchClass k, int skew,
+                        int* ovfCounter, void* stream, bool side) {
+    {   // the plan assumed the skewed kernels (every rows-per-lane value exists); a class that cannot use them
+        // takes the plain kernel's next instantiated value
+        const int rows = opal_hip_rows_supported(width, c.mode, swEndPass | (skew ? 4 : 0), k.rows);  // k.rows if it exists
+        if (rows && rows != k.rows && opal_hip_lds_bytes(width, k.G, rows, c.A) <= 160 * 1024) {
+            k.rows = rows;
+            pick_occupancy(kernel_vgprs(width, c.mode, swEndPass, 0, skew, rows), opal_hip_lds_bytes(width, k.G, rows, c.A), &k.wpb, &k.ldsPad,
+                           opal_hip_max_waves_per_block(width));
+        }
+    }
+    OpalHipLaunch a;
+    fill_launch(a, c, width, swEndPass, detectWrap, work, ovfCounter);
+    a.lanes_per_seq = k.G; a.rows_per_lane = k.rows; a.waves_per_block = k.wpb; a.lds_bytes_min = k.ldsPad;
+    a.first_item = k.first; a.num_items = k.count;
+    a.skew = skew;
+    a.stream = stream;
+    a.priority = side ? 1 : 0;
+    if (const char* pe = getenv("OPAL_HIP_SIDE_PRIO")) a.priority = side ? atoi(pe) : 0;  // tuning hook
+    if (debug_on())
+        fprintf(stderr, "[opal] launch width=%d mode=%d end=%d items=[%d,+%d) G=%d rows=%d waves/block=%d ldsPad=%d%s%s\n", width,
+                c.mode, swEndPass, k.first, k.count, k.G, k.rows, k.wpb, k.ldsPad, skew ? " skew" : "", side ? " (side)" : "");
+    if (opal_hip_launch(&a)) return 1;
+    count(CNT_CLASS_LAUNCHES);
+    if (width == 32) count(CNT_WIDTH32);
+    return 0;
+}
+
 static int launch_range(const SearchCtx& c, int width, int swEndPass, int detectWrap, const int* work, int firstItem,
                         int numItems, LenView lenOf, int* ovfCounter) {
     if (numItems <= 0) return 0;
     OpalxDb* db = c.db;
+    if (width == 16 && ensure_pair_tokens(db)) return OPAL_ERR_NO_SIMD_SUPPORT;
     // skewed kernels (width 17, NW/HW/OV) add up to (rows + steps) * Ge to every value: allowed for a class when
     // even its longest sequence stays inside the 16-bit range
     auto skew_ok = [&](int item) {
@@ -117,33 +151,95 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
             for (const LaunchClass& k : classes) v.insert(v.end(), {k.first, k.count, k.G, k.rows, k.wpb, k.ldsPad});
         }
     }
-    if (classes.empty() || getenv("OPAL_HIP_FORCE_CHUNKS"))
+    if (classes.empty() || getenv("OPAL_HIP_FORCE_CHUNKS")) {
+        if (!gate_items(db, db->main(), 0, 2 * db->numPairs)) return OPAL_ERR_NO_SIMD_SUPPORT;
         return launch_chunked(c, width, swEndPass, detectWrap, work, firstItem, numItems, ovfCounter);
-    if (uberEligible && classes.size() >= 2 && classes.size() <= 3) {
-        const LaunchClass& bulk = classes.back();
-        const int skewBulk = maySkew && skew_ok(bulk.first);
-        bool ok = bulk.wpb == 4 && bulk.ldsPad == 0 && opal_hip_uber_supported(c.mode, swEndPass, skewBulk, bulk.rows);
+    }
+    // Can the classes run as one grid? (bulk on G0 lanes, the others on 2*G0 and 4*G0, all on the same arithmetic)
+    const LaunchClass& bulk = classes.back();
+    const int skewBulk = maySkew && skew_ok(bulk.first);
+    bool oneGrid = uberEligible && classes.size() <= 3 && bulk.wpb == 4 && bulk.ldsPad == 0 &&
+                   opal_hip_uber_supported(c.mode, swEndPass, skewBulk, bulk.rows);
+    for (size_t ki = 0; oneGrid && ki + 1 < classes.size(); ki++) {
+        const LaunchClass& k = classes[ki];
+        if ((maySkew && skew_ok(k.first)) != skewBulk) oneGrid = false;  // a class that cannot use the skewed kernels: separate launches
+        else if (k.G != 2 * bulk.G && k.G != 4 * bulk.G) oneGrid = false;
+    }
+    // items [i0, i1) of the classes as ONE grid on `stream` (any class may be empty there)
+    auto launch_grid = [&](int i0, int i1, void* stream) -> int {
         OpalHipUberLaunch u;
         memset(&u, 0, sizeof u);
-        for (size_t ki = 0; ok && ki + 1 < classes.size(); ki++) {
-            const LaunchClass& k = classes[ki];
-            if ((maySkew && skew_ok(k.first)) != skewBulk) ok = false;  // a class that cannot use the skewed kernels: separate launches
-            else if (k.G == 2 * bulk.G) { u.long_first_item = k.first; u.long_num_items = k.count; u.long_priority = 1; }
-            else if (k.G == 4 * bulk.G) { u.longest_first_item = k.first; u.longest_num_items = k.count; u.longest_priority = 1; }
-            else ok = false;
+        fill_launch(u.base, c, width, swEndPass, detectWrap, nullptr, ovfCounter);
+        u.base.stream = stream;
+        u.base.lanes_per_seq = bulk.G; u.base.rows_per_lane = bulk.rows; u.base.waves_per_block = 4; u.base.skew = skewBulk;
+        for (const LaunchClass& k : classes) {
+            const int a = std::max(k.first, i0), b = std::min(k.first + k.count, i1);
+            const int n = std::max(0, b - a);
+            if (k.G == bulk.G) { u.base.first_item = a; u.base.num_items = n; }
+            else if (k.G == 2 * bulk.G) { u.long_first_item = a; u.long_num_items = n; u.long_priority = 1; }
+            else { u.longest_first_item = a; u.longest_num_items = n; u.longest_priority = 1; }
         }
-        if (ok) {
-            fill_launch(u.base, c, width, swEndPass, detectWrap, nullptr, ovfCounter);
-            u.base.lanes_per_seq = bulk.G; u.base.rows_per_lane = bulk.rows; u.base.waves_per_block = 4;
-            u.base.first_item = bulk.first; u.base.num_items = bulk.count; u.base.skew = skewBulk;
-            if (debug_on())
-                fprintf(stderr, "[opal] one launch width=%d mode=%d end=%d G0=%d rows=%d%s: bulk [%d,+%d) long [%d,+%d) longest [%d,+%d)\n", width,
-                        c.mode, swEndPass, bulk.G, bulk.rows, skewBulk ? " skew" : "", bulk.first, bulk.count, u.long_first_item,
-                        u.long_num_items, u.longest_first_item, u.longest_num_items);
-            if (opal_hip_launch_uber(&u)) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
-            count(CNT_ONE_LAUNCH);
-            return 0;
+        if (debug_on())
+            fprintf(stderr, "[opal] one launch width=%d mode=%d end=%d G0=%d rows=%d%s: bulk [%d,+%d) long [%d,+%d) longest [%d,+%d)\n", width,
+                    c.mode, swEndPass, bulk.G, bulk.rows, skewBulk ? " skew" : "", u.base.first_item, u.base.num_items, u.long_first_item,
+                    u.long_num_items, u.longest_first_item, u.longest_num_items);
+        if (opal_hip_launch_uber(&u)) return 1;
+        count(CNT_ONE_LAUNCH);
+        return 0;
+    };
+
+    // ---- the residues are still arriving (opalSearchDatabase: gather and upload overlap the search): the range is cut into
+    // SLICES of whole upload chunks, every slice launched as soon as its chunks have been enqueued, on two streams in turn
+    // (`main` and `aux`) so that a slice starts while the previous one drains. Sequences are sorted longest first, so
+    // the first slice holds the long classes.
+    if (db->gate.active && !work && (width == 17 || width == 18) && db->gate.chunks() >= 4 && !getenv("OPAL_HIP_NO_SLICES")) {
+        const UploadGate& g = db->gate;
+        std::vector<int> pattern{2, 3, 5};  // chunks per slice, the rest in the last one (C2: 17 chunks of 2 MB)
+        if (const char* e = getenv("OPAL_HIP_SLICES")) {
+            pattern.clear();
+            for (const char* q = e; *q;) { char* endp = nullptr; const long v = strtol(q, &endp, 10); if (endp == q) break; if (v > 0) pattern.push_back((int)v); q = *endp ? endp + 1 : endp; }
         }
+        std::vector<int> cut{firstItem};
+        int chunk = 0;
+        for (int want : pattern) {
+            chunk += want;
+            if (chunk >= g.chunks()) break;
+            const int at = g.cutItem[(size_t)chunk];
+            if (at > cut.back() && at < firstItem + numItems) cut.push_back(at);
+        }
+        cut.push_back(firstItem + numItems);
+        void* fork = db->event(0);
+        void* aux = db->aux();
+        if (!fork || !aux || opal_hip_event_record(fork, db->main()) || opal_hip_stream_wait_event(aux, fork)) return OPAL_ERR_NO_SIMD_SUPPORT;
+        int err = 0;
+        bool auxUsed = false;
+        for (size_t j = 0; j + 1 < cut.size() && !err; j++) {
+            void* stream = (j & 1) ? aux : db->main();
+            auxUsed |= (j & 1) != 0;
+            if (!gate_items(db, stream, cut[j], cut[j + 1] - cut[j])) { err = 1; break; }
+            if (oneGrid) err = launch_grid(cut[j], cut[j + 1], stream);
+            else
+                for (size_t ki = 0; ki < classes.size() && !err; ki++) {
+                    LaunchClass k = classes[ki];
+                    const int a = std::max(k.first, cut[j]), b = std::min(k.first + k.count, cut[j + 1]);
+                    if (b <= a) continue;
+                    k.first = a; k.count = b - a;
+                    err = launch_class(c, width, swEndPass, detectWrap, nullptr, k, maySkew && skew_ok(classes[ki].first), ovfCounter, stream, ki + 1 < classes.size());
+                }
+        }
+        if (!err && auxUsed) {
+            void* join = db->event(6);
+            if (!join || opal_hip_event_record(join, aux) || opal_hip_stream_wait_event(db->main(), join)) err = 1;
+        }
+        if (err) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
+        return 0;
+    }
+    // everything this range reads must have landed (no-op unless a fill is still in flight)
+    if (!gate_items(db, db->main(), 0, 2 * db->numPairs)) return OPAL_ERR_NO_SIMD_SUPPORT;
+
+    if (oneGrid && classes.size() >= 2) {
+        if (launch_grid(firstItem, firstItem + numItems, db->main())) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
+        return 0;
     }
     // The last class (the bulk of the database) runs on the main stream; the classes of long
     // sequences run beside it on up to three side streams (one hardware queue each), forked from and
@@ -159,36 +255,13 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
     // Submission order matters: the side launches (long sequences) go first. Submitting the bulk launch first was
     // measured at 2.2 ms instead of 1.55 ms on C2: its workgroups fill every CU and the long sequences start late.
     for (size_t ki = 0; ki < classes.size() && !err; ki++) {
-        LaunchClass k = classes[ki];
-        const int skew = maySkew && skew_ok(k.first);
-        {   // the plan assumed the skewed kernels (every rows-per-lane value exists); a class that cannot use them
-            // takes the plain kernel's next instantiated value
-            const int rows = opal_hip_rows_supported(width, c.mode, swEndPass | (skew ? 4 : 0), k.rows);  // k.rows if it exists
-            if (rows && rows != k.rows && opal_hip_lds_bytes(width, k.G, rows, c.A) <= 160 * 1024) {
-                k.rows = rows;
-                pick_occupancy(kernel_vgprs(width, c.mode, swEndPass, 0, skew, rows), opal_hip_lds_bytes(width, k.G, rows, c.A), &k.wpb, &k.ldsPad,
-                               opal_hip_max_waves_per_block(width));
-            }
-        }
-        OpalHipLaunch a;
-        fill_launch(a, c, width, swEndPass, detectWrap, work, ovfCounter);
-        a.lanes_per_seq = k.G; a.rows_per_lane = k.rows; a.waves_per_block = k.wpb; a.lds_bytes_min = k.ldsPad;
-        a.first_item = k.first; a.num_items = k.count;
-        a.skew = skew;
         const bool side = (int)ki < nside;
-        if (side) a.stream = db->stream((int)ki);
-        a.priority = side ? 1 : 0;
-        if (const char* pe = getenv("OPAL_HIP_SIDE_PRIO")) a.priority = side ? atoi(pe) : 0;  // tuning hook
-        if (debug_on())
-            fprintf(stderr, "[opal] launch width=%d mode=%d end=%d items=[%d,+%d) G=%d rows=%d waves/block=%d ldsPad=%d%s%s\n", width,
-                    c.mode, swEndPass, k.first, k.count, k.G, k.rows, k.wpb, k.ldsPad, skew ? " skew" : "", side ? " (side stream)" : "");
-        if (side && (!a.stream || opal_hip_stream_wait_event(a.stream, fork))) { err = 1; break; }
-        if (opal_hip_launch(&a)) { err = 1; break; }
-        count(CNT_CLASS_LAUNCHES);
-        if (width == 32) count(CNT_WIDTH32);
+        void* stream = side ? db->stream((int)ki) : db->main();
+        if (side && (!stream || opal_hip_stream_wait_event(stream, fork))) { err = 1; break; }
+        if (launch_class(c, width, swEndPass, detectWrap, work, classes[ki], maySkew && skew_ok(classes[ki].first), ovfCounter, stream, side)) { err = 1; break; }
         if (side) {
             void* done = db->event(1 + (int)ki);
-            if (!done || opal_hip_event_record(done, a.stream)) { err = 1; break; }
+            if (!done || opal_hip_event_record(done, stream)) { err = 1; break; }
             recorded[ki] = true;
         }
     }
@@ -354,7 +427,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                 a.first_item = 0; a.num_items = 2 * P;
                 if (debug_on())
                     fprintf(stderr, "[opal] streaming launch width=%d G=%d rows=%d end=%d items=%d\n", splan.width, splan.G, splan.rows, wantEnd, 2 * P);
-                rc = opal_hip_launch_stream(&a, db->ovfCount.p + 2) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
+                rc = (!gate_items(db, st, 0, 2 * P) || opal_hip_launch_stream(&a, db->ovfCount.p + 2)) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
                 count(CNT_STREAM_SW);
             }
             else if (narrow == 16) rc = launch_range(c, 16, wantEnd, 0, nullptr, 0, nNarrow, pairLenOf, db->ovfCount.p);
@@ -446,7 +519,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                 fprintf(stderr, "[opal] streaming launch mode=%d width=%d G=%d rows=%d items=[%d,+%d)\n", mode, gplan.width, gplan.G, gplan.rows,
                         a.first_item, a.num_items);
             count(CNT_STREAM_GLOBAL);
-            return opal_hip_launch_stream(&a, db->ovfCount.p + 2);
+            return (!gate_items(db, st, 0, 2 * P) || opal_hip_launch_stream(&a, db->ovfCount.p + 2)) ? 1 : 0;
         };
         // 32-bit safety (our definition where the reference is undefined, see oracle/opal_oracle.c):
         // sequences whose bound leaves [-2^30, 2^30] are not computed and the call returns OVERFLOW.

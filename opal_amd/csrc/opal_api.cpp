@@ -11,8 +11,9 @@
 // milliseconds for 10^10 cells), so the boundary is built for that:
 //   * device buffers, pinned staging memory, streams and events live in cached CONTEXTS that calls
 //     borrow and give back (db_pack.cpp; no hipMalloc/hipFree, stream or event creation in the steady state);
-//   * the N separate host allocations are gathered into pinned memory by a persistent thread pool,
-//     each chunk going to the device as soon as it is complete; the interleaving into tokens is a kernel;
+//   * the N separate host allocations are gathered into pinned memory by a persistent thread pool, in the order the
+//     kernels work through them (longest first), each chunk going to the device as soon as it is complete -- and the
+//     search of a slice of the database is launched as soon as ITS chunks are on their way (run_shard, gate_items);
 //   * results come back through pinned memory and are scattered into the N result structs by the pool;
 //   * with OPAL_HIP_DEVICES set, the call shards the database over several GPUs (multi_gpu.cpp), one host thread per GPU.
 #include "opal_internal.hpp"
@@ -22,9 +23,11 @@ using namespace opal_host;
 namespace {
 
 /*
- * One shard of an opalSearchDatabase call on the calling thread's current device: pack, upload, search,
+ * One shard of an opalSearchDatabase call on the calling thread's current device: order, gather + upload, search,
  * download. `ids` (may be null = identity) maps shard position -> caller index; results land in
  * score/endQ/endT at SHARD positions (INT_MIN = not written by the search).
+ * The gather of the residues (pool threads, item order = longest first, chunk by chunk onto the copy stream) runs BESIDE
+ * the search: search_core launches every slice of the database as soon as its chunks have been enqueued (gate_items).
  */
 static int run_shard(int device, const unsigned char* query, int Q, unsigned char* const* db, const int* dbLens, const int* ids,
                      int n, int Go, int Ge, const int* M, int A, int searchType, int mode, int* score, int* endQ, int* endT,
@@ -33,7 +36,6 @@ static int run_shard(int device, const unsigned char* query, int Q, unsigned cha
     OpalxDb* pdb = ctx.db;
     if (!pdb) return OPAL_ERR_NO_SIMD_SUPPORT;
     const double t0 = now_ms();
-    HostPack hp;
     std::vector<int> lensBuf;
     const int* lens = dbLens;
     if (ids) {
@@ -42,9 +44,13 @@ static int run_shard(int device, const unsigned char* query, int Q, unsigned cha
         lens = lensBuf.data();
     }
     const double t1 = now_ms();
-    auto getSeq = [&](int i) { return (const unsigned char*)db[ids ? ids[i] : i]; };
-    // (ordering and pairing run as one task beside the gather of the residues: see db_fill)
-    if (!db_fill(pdb, hp, RAW_POINTERS, getSeq, nullptr, lens, n)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    struct FillGuard {  // the pool job of the fill must be over before anything else uses the pool or the context goes back
+        OpalxDb* db;
+        ~FillGuard() { db_fill_finish(db); }
+    } guard{pdb};
+    const bool async = !getenv("OPAL_HIP_SYNC_FILL");
+    if (!db_fill(pdb, n, lens, RAW_POINTERS, [db, ids](int i) { return (const unsigned char*)db[ids ? ids[i] : i]; }, nullptr, nullptr, async))
+        return OPAL_ERR_NO_SIMD_SUPPORT;
     const double t2 = now_ms();
     const size_t nn = (size_t)std::max(n, 1);
     const int wantEnd = searchType != OPAL_SEARCH_SCORE;
@@ -55,6 +61,7 @@ static int run_shard(int device, const unsigned char* query, int Q, unsigned cha
     if (opal_hip_memset32(dS, INT_MIN, nn, st) || (wantEnd && opal_hip_memset32(dQ, -1, 2 * nn, st))) return OPAL_ERR_NO_SIMD_SUPPORT;
     int rc = search_core(pdb, query, Q, Go, Ge, M, A, searchType, mode, dS, wantEnd ? dQ : nullptr, wantEnd ? dT : nullptr, nullptr,
                          /*finalSync=*/false);
+    if (!db_fill_finish(pdb)) return OPAL_ERR_NO_SIMD_SUPPORT;
     const double t3 = now_ms();
     if (rc == OPAL_ERR_NO_SIMD_SUPPORT || rc == OPAL_ERR_INVALID_MODE) return rc;
     int* h = pdb->hResults.p;

@@ -88,43 +88,62 @@ template <typename T> struct PinBuf {
     void release() { opal_hip_host_free(p); p = nullptr; cap = 0; }
 };
 
-// ------------------------------------------------------------------------------------ packed db
-// Sequences sorted by length (descending), paired up neighbour with neighbour. A pair is the unit a
-// wave slot works on at width 16 (two sequences packed in one register); its residues are stored
-// column by column as 16-bit tokens (low byte A, high byte B) so one 2-byte load feeds both.
-// The host only decides the order and gathers the residues into one buffer; the interleaving into
-// tokens is done on the device (opal_hip_pack_tokens) at HBM speed.
-struct HostPack {
-    std::vector<uint64_t> pairOff;  // [P] start of each pair's token stream
-    std::vector<int> pairLen;       // [2P]
-    std::vector<int> pairSeq;       // [2P] caller index, -1 = absent
-    std::vector<uint64_t> rawOff;   // [2P] where each sequence's residues start in the raw buffer
-    std::vector<int> emptySeqs;     // caller indices of zero-length sequences (answered on the host)
-    uint64_t rawBytes = 0;
-    uint64_t numTokens = 0;
-    int64_t residues = 0;
-    int numSeqs = 0;
+// Pinned host memory with the little of std::vector the scheduler uses: what it holds can be handed to an asynchronous
+// copy and read by the host at the same time (pageable vectors would have to outlive copies that may still be staging them).
+template <typename T> struct PinVec {
+    PinBuf<T> buf;
+    size_t n = 0;
+    bool resize(size_t k, double slack = 1.0) { if (!buf.ensure(std::max<size_t>(k, 1), slack)) { n = 0; return false; } n = k; return true; }
+    T& operator[](size_t i) { return buf.p[i]; }
+    const T& operator[](size_t i) const { return buf.p[i]; }
+    T* data() { return buf.p; }
+    const T* data() const { return buf.p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    void release() { buf.release(); n = 0; }
 };
 
-void pack_order(int n, const int* lens, HostPack& out);
+// Residues on their way to the device, chunk by chunk, while the search of the sequences that have landed is being
+// launched (opalSearchDatabase: the gather of N host allocations and their upload overlap the search instead of preceding
+// it). Chunk c holds the items [cutItem[c], cutItem[c+1]); a pool thread gathers it into pinned memory, enqueues its copy on
+// the context's copy stream, records events[c] behind it and sets state[c] (1 enqueued, -1 failed).
+struct UploadGate {
+    bool active = false;
+    std::vector<int> cutItem;
+    std::vector<void*> events;  // (owned by the context: kept across calls)
+    std::unique_ptr<std::atomic<int>[]> state;
+    size_t stateCap = 0;
+    int chunks() const { return active ? (int)cutItem.size() - 1 : 0; }
+};
 
 }  // namespace opal_host
 
+// ------------------------------------------------------------------------------------ packed db
+// The sequences sorted by length (descending; stable), residues back to back in that order, one byte each: ITEM i is the
+// i-th of them. A wave slot works on one item (widths 17, 18, 32) or, at width 16, on a PAIR of neighbours (items 2p and
+// 2p+1 packed in one register), whose residues the packed kernels read as 16-bit tokens (low byte A, high byte B): those
+// token streams are built on the device, on first use (ensure_pair_tokens).
 struct OpalxDb {
     int device = 0;
     bool cached = false;  // a context of the opalSearchDatabase cache (returned to the free list, not destroyed)
     int numSeqs = 0;
-    int numPairs = 0;
+    int numPairs = 0;     // items = 2 * numPairs (the last one absent when the number of non-empty sequences is odd)
     int64_t residues = 0;
-    size_t numTokens = 0;
-    // host copies the scheduler needs
-    std::vector<int> pairLen;  // [2P], pairs sorted by length of A descending
-    std::vector<int> pairSeq;
-    std::vector<int> emptySeqs;
+    // host copies the scheduler needs (pinned: they are also the source of the uploads)
+    opal_host::PinVec<int> pairLen;       // [items] lengths
+    opal_host::PinVec<int> pairSeq;       // [items] caller indices, -1 = absent
+    opal_host::PinVec<uint64_t> seqOff;   // [items] start of each sequence in `res`
+    std::vector<int> emptySeqs;           // caller indices of zero-length sequences (answered on the host)
     // device: the packed database
+    opal_host::DevBuf<unsigned char> res;
+    opal_host::DevBuf<uint64_t> dSeqOff;
+    opal_host::DevBuf<int> dPairLen, dPairSeq;
+    // width 16 only, built on first use: pair token streams
     opal_host::DevBuf<uint16_t> tokens;
     opal_host::DevBuf<uint64_t> pairOff;
-    opal_host::DevBuf<int> dPairLen, dPairSeq;
+    opal_host::PinVec<uint64_t> hPairOff;
+    size_t numTokens = 0;
+    bool tokensValid = false;
     bool clockProbe = false;   // opalx_db_clock_probe
     double lastClockGhz = 0;
     // One "search header" per search, uploaded with a single copy: {counters[4], clock probe[2 x u64], score matrix, query}. ovfCount[0] =
@@ -133,13 +152,13 @@ struct OpalxDb {
     opal_host::PinBuf<unsigned char> hHeader;
     struct View32 { int* p = nullptr; } ovfCount, matrix;
     struct View8 { unsigned char* p = nullptr; } query;
-    opal_host::DevBuf<int> ovfItems;  // [2P]
+    opal_host::DevBuf<int> ovfItems;  // [items]
     // device: per-search scratch
-    opal_host::DevBuf<unsigned char> boundary;  // 16 B per token: chunk-boundary rows of long queries (allocated on first use)
+    opal_host::DevBuf<unsigned char> boundary;  // 8 B per residue: chunk-boundary rows of long queries (allocated on first use)
     opal_host::DevBuf<int> scratch;             // [2N] per-sequence values carried across query chunks
     opal_host::DevBuf<int> results;             // [3N] device staging of host-array searches
     opal_host::DevBuf<int> quads;               // degenerate results on their way to the scatter kernel
-    // start-location pass (rev_kernel.hip): caller index -> pair*2+half, flags and the host-redo list
+    // start-location pass (rev_kernel.hip): caller index -> item, flags and the host-redo list
     opal_host::DevBuf<int> seqItem;
     bool seqItemValid = false;
     opal_host::DevBuf<int> revFlags;
@@ -152,19 +171,34 @@ struct OpalxDb {
     // with the same query length, alphabet and mode re-uses the class split instead of recomputing it with the GPU idle
     std::map<std::string, std::vector<int>> planCache;
     // staging used while (re)filling the database
-    opal_host::DevBuf<unsigned char> raw;
+    opal_host::DevBuf<unsigned char> raw;    // a flat device database in caller order is reordered from here / from the caller's buffer
     opal_host::DevBuf<uint64_t> rawOff;
-    opal_host::PinBuf<unsigned char> hRaw;
+    opal_host::PinVec<uint64_t> hRawOff;
+    opal_host::PinBuf<unsigned char> hRaw;   // the gathered residues in item order, chunk by chunk on their way to `res`
     opal_host::PinBuf<int> hResults;
+    opal_host::UploadGate gate;
+    std::function<void(int)> gatherFn;  // the pool job of a (re)fill in flight (alive until db_fill_finish)
+    bool gatherPending = false;
     // Streams: everything of one search runs on `main` (a non-blocking stream: no implicit ordering
     // against the legacy null stream or against other contexts); long-sequence classes run on up to three
     // HIGH-priority side streams (hardware queues of their own), forked from and joined back into `main` with events.
+    // `copy` carries the residue chunks of a (re)fill, `aux` every second slice of a search launched while they arrive.
     void* mainStream = nullptr;
+    void* copyStream = nullptr;
+    void* auxStream = nullptr;
     void* streams[3] = {nullptr, nullptr, nullptr};
-    void* events[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // 0 fork, 1-3 joins, 4-5 timing
+    void* events[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // 0 fork, 1-3 joins, 4-5 timing, 6 aux join, 7 fill
     void* main() {
         if (!mainStream) mainStream = opal_hip_stream_create();
         return mainStream;
+    }
+    void* copy() {
+        if (!copyStream) copyStream = opal_hip_stream_create();
+        return copyStream;
+    }
+    void* aux() {
+        if (!auxStream) auxStream = opal_hip_stream_create();
+        return auxStream;
     }
     void* stream(int i) {
         if (!streams[i]) { const char* e = getenv("OPAL_HIP_SIDE_STREAM_PRIO"); streams[i] = (e && *e == '0') ? opal_hip_stream_create() : opal_hip_stream_create_high(); }
@@ -177,6 +211,8 @@ struct OpalxDb {
     // Wait for everything this handle may have in flight (used on error paths before buffers are reused).
     void quiesce() {
         for (void* st : streams) if (st) opal_hip_stream_sync(st);
+        if (copyStream) opal_hip_stream_sync(copyStream);
+        if (auxStream) opal_hip_stream_sync(auxStream);
         if (mainStream) opal_hip_stream_sync(mainStream);
     }
 };
@@ -186,9 +222,24 @@ namespace opal_host {
 bool device_ok();
 void db_release(OpalxDb* db);
 
-enum RawKind { RAW_POINTERS, RAW_HOST_FLAT, RAW_DEVICE_FLAT };
-bool db_fill(OpalxDb* db, HostPack& hp, RawKind kind, const std::function<const unsigned char*(int)>& getSeq,
-             const unsigned char* flat, const int* orderLens = nullptr, int orderN = 0);
+/*
+ * (Re)fill `db` with `n` sequences of lengths `lens`. Residues come from
+ *   RAW_POINTERS     getSeq(i): separate host allocations (or slices of one host buffer), gathered in ITEM order into
+ *                    pinned memory by the thread pool, every chunk uploaded as soon as it is complete;
+ *   RAW_DEVICE_FLAT  one flat device buffer, sequence i at flatOff(i): reordered on the device.
+ * With `async` (RAW_POINTERS only) the call returns while the pool is still gathering: launches must pass through
+ * gate_items() for the items they read, and the caller must call db_fill_finish() before it uses the pool again or
+ * gives the context back. Buffers of a cached context are reused when large enough.
+ */
+enum RawKind { RAW_POINTERS, RAW_DEVICE_FLAT };
+bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::function<const unsigned char*(int)>& getSeq,
+             const unsigned char* flatDevice, const std::function<uint64_t(int)>& flatOff, bool async = false);
+bool db_fill_finish(OpalxDb* db);  // waits for the pool; false if a chunk failed
+// Make `stream` wait for the residues of items [firstItem, firstItem + count) (host-waits until their chunks have been
+// enqueued, then one hipStreamWaitEvent per chunk). No-op without an active gate. False if a chunk failed.
+bool gate_items(OpalxDb* db, void* stream, int firstItem, int count);
+// The 16-bit pair token streams of the width-16 kernels (built on the device on first use). 0 on success.
+int ensure_pair_tokens(OpalxDb* db);
 
 // ------------------------------------------------------------------------------------ context cache
 // Contexts borrowed by opalSearchDatabase / opalSearchDatabaseCharSW: per device, a free list. A call takes one

@@ -31,7 +31,7 @@ int search_starts(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge
     memset(&a, 0, sizeof a);
     a.mode = mode; a.query = db->query.p; a.query_length = Q; a.score_matrix = db->matrix.p; a.alphabet_length = A;
     a.gap_open = Go; a.gap_ext = Ge;
-    a.tokens = db->tokens.p; a.pair_token_offset = db->pairOff.p; a.seq_item = db->seqItem.p;
+    a.residues = db->res.p; a.seq_offset = db->dSeqOff.p; a.seq_item = db->seqItem.p;
     a.items = nullptr; a.num_items = n;
     a.score = dScore; a.end_query = dEndQ; a.end_target = dEndT;
     a.start_query = dStartQ; a.start_target = dStartT; a.flags = db->revFlags.p; a.redo = db->redo.p;
@@ -125,7 +125,7 @@ void device_traceback(OpalxDb* db, int Q, int Go, int Ge, int A, int mode, int n
             OpalHipTraceLaunch a;
             memset(&a, 0, sizeof a);
             a.query = db->query.p; a.alphabet_length = A; a.score_matrix = db->matrix.p; a.gap_open = Go; a.gap_ext = Ge;
-            a.tokens = db->tokens.p; a.pair_token_offset = db->pairOff.p; a.seq_item = db->seqItem.p;
+            a.residues = db->res.p; a.seq_offset = db->dSeqOff.p; a.seq_item = db->seqItem.p;
             a.items = db->trItems.p; a.num_items = (int)m; a.max_rows = maxRows;
             a.end_query = dEndQ; a.end_target = dEndT; a.start_query = dStartQ; a.start_target = dStartT;
             a.dir_offset = db->trOff.p; a.dirs = db->trDirs.p; a.ops_offset = db->trOff.p + m; a.ops = db->trOps.p;
