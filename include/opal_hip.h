@@ -99,6 +99,9 @@ typedef struct OpalHipLaunch {
        ticks (opal_hip_wall_clock_hz per second) of its lifetime to [0] / [1] -- their ratio is the clock the chip held
        under this kernel. */
     unsigned long long* clock_probe;
+    /* Timeline probe (NULL: off): every workgroup b of the launch writes the constant-rate ticks at its start and end to
+       timeline[2b], timeline[2b+1] (capacity: 2 x the grid size). */
+    unsigned long long* timeline;
 } OpalHipLaunch;
 
 /* ONE launch for up to three length classes of a search (plain 16-bit kernels): the bulk of the database on
@@ -138,8 +141,11 @@ void opal_hip_host_free(void* p);
 int opal_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
 int opal_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
 int opal_hip_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
-/* Device-to-device across GPUs (xGMI peer DMA): the gather step of the in-library multi-GPU search. */
+/* Device-to-device across GPUs (xGMI peer DMA): the gather step of the multi-GPU search (opalx_multi_search_device). */
 int opal_hip_memcpy_peer(void* dst, int dst_device, const void* src, int src_device, size_t bytes, void* stream);
+int opal_hip_enable_peer(int peer);   /* direct access from the current device to `peer` (0: enabled or same device) */
+/* out[perm[i]] = in[i] for i < count, on the device */
+int opal_hip_permute(const int* in, const int* perm, int count, int* out, void* stream);
 int opal_hip_memset(void* dst, int value, size_t bytes, void* stream);
 int opal_hip_memset32(void* dst, int value, size_t count, void* stream);   /* `count` 32-bit words */
 /* score[quads[4i]] = quads[4i+1], end_query[..] = quads[4i+2], end_target[..] = quads[4i+3]; `quads` on the device. */
@@ -173,6 +179,7 @@ size_t opal_hip_lds_bytes(int width, int lanes_per_seq, int rows_per_lane, int a
 const char* opal_hip_last_error(void);
 /* Timing helpers for bench.py: HIP events on the stream the kernels run on. */
 void* opal_hip_event_create(void);
+void* opal_hip_event_create_untimed(void);   /* ordering only (hipEventDisableTiming) */
 void opal_hip_event_destroy(void* ev);
 int opal_hip_event_record(void* ev, void* stream);
 float opal_hip_event_elapsed_ms(void* start, void* stop); /* synchronises on `stop` */
@@ -235,10 +242,13 @@ OpalxDb* opalx_db_create(unsigned char* const db[], int db_length, const int db_
 /* Same, from one contiguous residue buffer: sequence j is residues[offsets[j] .. offsets[j+1]). */
 OpalxDb* opalx_db_create_flat(const unsigned char* residues, const int64_t* offsets, int db_length);
 /* Same with the residue buffer already in DEVICE memory of the current device (offsets stay on the host);
-   the buffer is only read during the call. */
+   the buffer is only read during the call. The library works on a private non-blocking stream: whatever produced
+   the buffer (a kernel or copy on another stream, e.g. torch's) must be COMPLETE before the call -- synchronise that
+   stream first. The same holds for the result buffers handed to opalx_search_device / opalx_search_starts. */
 OpalxDb* opalx_db_create_flat_device(const unsigned char* d_residues, const int64_t* offsets, int db_length);
 /* opalSearchDatabase keeps its device buffers, pinned staging memory and streams in cached contexts between
-   calls; this frees them (optional: call it when no search is running, e.g. before unloading the library). */
+   calls; this frees them (optional: call it when no search is running). The library's host threads are never
+   stopped: do not dlclose() it. */
 void opalx_release_cached(void);
 /* Number of searches of this process that ran on the streaming SW kernel (diagnostics and tests). */
 long long opalx_stream_launch_count(void);
@@ -254,13 +264,17 @@ void opalx_db_destroy(OpalxDb* db);
    of the last probed search, 0 if none. */
 void opalx_db_clock_probe(OpalxDb* db, int enable);
 double opalx_db_last_clock_ghz(const OpalxDb* db);
+/* enable == 2 also records, per workgroup of the LAST DP launch of a search, the constant-rate ticks
+   (opal_hip_wall_clock_hz per second) at its start and end; opalx_db_last_timeline copies them out
+   ({start, end} per workgroup, in grid order; returns the number of workgroups, at most capacity / 2). */
+int opalx_db_last_timeline(OpalxDb* db, unsigned long long* out, int capacity);
 int opalx_db_num_sequences(const OpalxDb* db);
 int64_t opalx_db_num_residues(const OpalxDb* db);
 
 /*
  * Search the whole packed database. Results go to DEVICE buffers of db_length ints each, in
- * caller order (d_end_query/d_end_target may be NULL for OPAL_SEARCH_SCORE). The call enqueues
- * the kernels and waits for them. Returns 0 or an OPAL_ERR_* code. `kernel_ms`, if not NULL,
+ * caller order (d_end_query/d_end_target may be NULL for OPAL_SEARCH_SCORE; whatever last wrote them on another
+ * stream must be complete, see opalx_db_create_flat_device). The call enqueues the kernels and waits for them. Returns 0 or an OPAL_ERR_* code. `kernel_ms`, if not NULL,
  * receives the device time of all DP kernels (HIP events on the launch stream).
  * search_type is OPAL_SEARCH_SCORE or OPAL_SEARCH_SCORE_END.
  */
@@ -274,6 +288,24 @@ int opalx_search_host(OpalxDb* db, const unsigned char* query, int query_length,
                       int gap_open, int gap_ext, const int* score_matrix, int alphabet_length,
                       int search_type, int mode, int overflow_method,
                       int* score, int* end_query, int* end_target);
+
+/*
+ * One database over SEVERAL GPUs of this process (the counterpart of bench.py's one-process-per-GPU
+ * path for a single-process caller): the sequences are dealt to `num_devices` GPUs in 64-sequence groups balancing the
+ * residue count, every GPU keeps its shard packed in its own memory, a search runs on all of them at once (one host thread
+ * per GPU), every shard's {score[, endQ, endT]} block travels to devices[0] by peer DMA (xGMI) and a permutation kernel
+ * there writes the three result vectors in DATABASE order into the caller's buffers on devices[0] -- no result touches
+ * the host. A device may be listed more than once (how the path is tested on a one-GPU box).
+ */
+typedef struct OpalxMultiDb OpalxMultiDb;
+OpalxMultiDb* opalx_multi_create_flat(const unsigned char* residues, const int64_t* offsets, int db_length,
+                                      const int* devices, int num_devices);
+void opalx_multi_destroy(OpalxMultiDb* mdb);
+/* d_score / d_end_query / d_end_target: device buffers on devices[0], db_length ints each (end buffers may be NULL for
+   OPAL_SEARCH_SCORE). `kernel_ms`: the longest DP time over the shards. Returns 0 or an OPAL_ERR_* code. */
+int opalx_multi_search_device(OpalxMultiDb* mdb, const unsigned char* query, int query_length, int gap_open, int gap_ext,
+                              const int* score_matrix, int alphabet_length, int search_type, int mode,
+                              int* d_score, int* d_end_query, int* d_end_target, float* kernel_ms);
 
 /*
  * Host traceback (no device work): for every result that holds a score and an end location, fill

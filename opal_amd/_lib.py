@@ -52,6 +52,15 @@ def lib():
         L.opalx_search_host.restype = C.c_int
         L.opalx_search_host.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_int, i32p, C.c_int, C.c_int, C.c_int,
                                         C.c_int, i32p, i32p, i32p]
+        L.opalx_multi_create_flat.restype = C.c_void_p
+        L.opalx_multi_create_flat.argtypes = [u8p, C.POINTER(C.c_int64), C.c_int, i32p, C.c_int]
+        L.opalx_multi_destroy.restype = None
+        L.opalx_multi_destroy.argtypes = [C.c_void_p]
+        L.opalx_multi_search_device.restype = C.c_int
+        L.opalx_multi_search_device.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_int, i32p, C.c_int, C.c_int, C.c_int,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+        L.opalx_counters.restype = C.c_int
+        L.opalx_counters.argtypes = [C.POINTER(C.c_longlong), C.c_int]
         L.opal_hip_device_count.restype = C.c_int
         L.opal_hip_set_device.restype = C.c_int
         L.opal_hip_set_device.argtypes = [C.c_int]

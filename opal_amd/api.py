@@ -165,3 +165,41 @@ class PreparedDb:
                                           int(gap_ext), ip(m), int(m.shape[0]), int(search_type), int(mode),
                                           int(overflow_method), ip(s), ip(eq), ip(et))
         return rc, s, eq, et
+
+
+class PreparedMultiDb:
+    """One database over several GPUs of this process (opalx_multi_* in include/opal_hip.h): residue-balanced shards, one
+    search on all GPUs at once, the result blocks gathered on devices[0] by peer DMA and written there in database order."""
+
+    def __init__(self, residues, offsets, devices):
+        L = _lib.lib()
+        self._res = _u8(residues)
+        self._off = np.ascontiguousarray(offsets, dtype=np.int64)
+        self.num_sequences = len(self._off) - 1
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        self.devices = [int(d) for d in dev]
+        self._h = L.opalx_multi_create_flat(self._res.ctypes.data_as(C.POINTER(C.c_ubyte)), self._off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                            self.num_sequences, dev.ctypes.data_as(C.POINTER(C.c_int)), len(dev))
+        if not self._h:
+            raise RuntimeError("opalx_multi_create_flat failed: " + (L.opal_hip_last_error() or b"").decode())
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None and _lib._lib is not None:
+            _lib._lib.opalx_multi_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
+
+    def search_device(self, query, gap_open, gap_ext, score_matrix, search_type, mode, d_score, d_end_q=0, d_end_t=0):
+        """Results into device buffers on devices[0] (raw pointers), database order. Returns (rc, kernel_ms)."""
+        q = _u8(query)
+        m = np.ascontiguousarray(score_matrix, dtype=np.int32)
+        ms = C.c_float(0)
+        rc = _lib.lib().opalx_multi_search_device(self._h, q.ctypes.data_as(C.POINTER(C.c_ubyte)), len(q), int(gap_open), int(gap_ext),
+                                                  m.ctypes.data_as(C.POINTER(C.c_int)), int(m.shape[0]), int(search_type), int(mode),
+                                                  C.c_void_p(d_score), C.c_void_p(d_end_q or None), C.c_void_p(d_end_t or None), C.byref(ms))
+        return rc, ms.value

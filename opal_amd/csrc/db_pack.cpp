@@ -15,6 +15,7 @@ std::atomic<long long> g_counters[CNT_COUNT];
 static bool order_sequences(OpalxDb* db, int n, const int* lens) {
     db->numSeqs = n;
     db->emptySeqs.clear();
+    const double to0 = now_ms();
     int maxLen = 0;
     for (int i = 0; i < n; i++) maxLen = std::max(maxLen, lens[i]);
     const double slack = db->cached ? 1.15 : 1.0;
@@ -41,18 +42,22 @@ static bool order_sequences(OpalxDb* db, int n, const int* lens) {
     }
     HostPool& pool = HostPool::get();
     const size_t B = (size_t)maxLen + 1;  // bucket b holds the sequences of length maxLen - b; length 0 is not placed
-    int T = n >= (1 << 16) ? std::min(pool.width(), 16) : 1;
+    int T = n >= (1 << 16) ? std::min(pool.width(), 8) : 1;
     while (T > 1 && (size_t)T * B > (4u << 20)) T /= 2;
-    std::vector<int> hist((size_t)T * B, 0);
+    std::vector<int>& hist = db->ordHist;  // (kept in the context: no fresh pages per call)
+    hist.assign((size_t)T * B, 0);
     auto range = [&](int t, int& i0, int& i1) { i0 = (int)((long long)n * t / T); i1 = (int)((long long)n * (t + 1) / T); };
     pool.parallel_for(T, [&](int t) {
         int i0, i1; range(t, i0, i1);
         int* h = hist.data() + (size_t)t * B;
         for (int i = i0; i < i1; i++) if (lens[i] > 0) h[(size_t)maxLen - lens[i]]++;
     });
+    const double to1 = now_ms();
     // bucket starts (item position and byte offset), and where every thread starts inside every bucket
-    std::vector<int> bucketPos(B + 1, 0);
-    std::vector<uint64_t> bucketByte(B + 1, 0);
+    std::vector<int>& bucketPos = db->ordPos;
+    std::vector<uint64_t>& bucketByte = db->ordByte;
+    bucketPos.assign(B + 1, 0);
+    bucketByte.assign(B + 1, 0);
     int pos = 0;
     uint64_t byte = 0;
     for (size_t b = 0; b < B; b++) {
@@ -66,6 +71,7 @@ static bool order_sequences(OpalxDb* db, int n, const int* lens) {
     const size_t items = ((size_t)m + 1) / 2 * 2;
     if (!db->pairLen.resize(items, slack) || !db->pairSeq.resize(items, slack) || !db->seqOff.resize(items, slack)) return false;
     std::vector<std::vector<int>> empties((size_t)T);
+    const double to2 = now_ms();
     int* const pl = db->pairLen.data(); int* const ps = db->pairSeq.data(); uint64_t* const so = db->seqOff.data();
     pool.parallel_for(T, [&](int t) {
         int i0, i1; range(t, i0, i1);
@@ -80,6 +86,7 @@ static bool order_sequences(OpalxDb* db, int n, const int* lens) {
         }
     });
     for (auto& v : empties) db->emptySeqs.insert(db->emptySeqs.end(), v.begin(), v.end());
+    if (debug_on()) fprintf(stderr, "[opal] order: max + histogram %.3f ms (%d threads), prefix %.3f, placement %.3f\n", to1 - to0, T, to2 - to1, now_ms() - to2);
     if ((size_t)m < items) { pl[m] = 0; ps[m] = -1; so[m] = byte; }
     db->residues = (int64_t)byte;
     db->numPairs = (int)(items / 2);
@@ -109,6 +116,7 @@ void db_release(OpalxDb* db) {
     db->res.release(); db->dSeqOff.release(); db->dPairLen.release(); db->dPairSeq.release();
     db->pairLen.release(); db->pairSeq.release(); db->seqOff.release();
     db->tokens.release(); db->pairOff.release(); db->hPairOff.release();
+    db->timeline.release();
     db->header.release(); db->hHeader.release(); db->ovfItems.release(); db->boundary.release(); db->scratch.release();
     db->results.release(); db->quads.release();
     db->ovfCount.p = nullptr; db->matrix.p = nullptr; db->query.p = nullptr;
@@ -131,7 +139,9 @@ bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::funct
     db->seqItemValid = false;
     db->tokensValid = false;
     db->planCache.clear();
+    const double tf0 = now_ms();
     if (!order_sequences(db, n, lens)) return false;
+    const double tf1 = now_ms();
     const size_t items = db->pairLen.size();
     const double slack = db->cached ? 1.15 : 1.0;
     void* st = db->main();
@@ -155,47 +165,75 @@ bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::funct
         if (ok && !db->cached) { db->rawOff.release(); db->hRawOff.release(); }
         return ok;
     }
-    // Host residues: gathered in ITEM order into pinned memory, chunk by chunk (~2 MB, fewer and larger chunks for
-    // gigabyte databases), every chunk uploaded on the copy stream as soon as it is complete.
+    // Host residues: gathered in ITEM order into pinned memory. A CHUNK (~2 MB, fewer and larger ones for gigabyte
+    // databases) is what one copy moves; it is gathered by many threads at a time -- the pool's tasks are PIECES of ~128 KB,
+    // handed out in item order, and the thread that completes the last piece of a chunk enqueues its copy on the copy
+    // stream -- so the chunks reach the device in the order the kernels work through them (longest sequences first), the
+    // first one a few tens of microseconds after the gather began.
     if (!db->hRaw.ensure(total + 16, slack) || !db->copy()) return false;
     UploadGate& g = db->gate;
     const uint64_t chunkBytes = std::max<uint64_t>(2u << 20, total / 96);
+    const uint64_t pieceBytes = std::max<uint64_t>(128u << 10, chunkBytes / 16);
     g.cutItem.assign(1, 0);
-    for (size_t i = 0; i < items; i++)
-        if (db->seqOff[i] - db->seqOff[(size_t)g.cutItem.back()] >= chunkBytes) g.cutItem.push_back((int)i);
+    g.pieceCut.assign(1, 0);
+    g.pieceChunk.clear();
+    for (size_t i = 0; i < items; i++) {
+        if (db->seqOff[i] - db->seqOff[(size_t)g.cutItem.back()] >= chunkBytes) { g.cutItem.push_back((int)i); if (g.pieceCut.back() != (int)i) { g.pieceChunk.push_back((int)g.cutItem.size() - 2); g.pieceCut.push_back((int)i); } }
+        else if (db->seqOff[i] - db->seqOff[(size_t)g.pieceCut.back()] >= pieceBytes) { g.pieceChunk.push_back((int)g.cutItem.size() - 1); g.pieceCut.push_back((int)i); }
+    }
     g.cutItem.push_back((int)items);
+    if (g.pieceCut.back() != (int)items) { g.pieceChunk.push_back((int)g.cutItem.size() - 2); g.pieceCut.push_back((int)items); }
     const int nchunks = (int)g.cutItem.size() - 1;
+    const int npieces = (int)g.pieceCut.size() - 1;
+    if (debug_on() && !g.timed) {  // (debug: timed chunk events, to print when each chunk's copy completed)
+        for (void*& ev : g.events) opal_hip_event_destroy(ev);
+        g.events.clear();
+        g.timed = true;
+    }
     while ((int)g.events.size() < nchunks) {
-        void* ev = opal_hip_event_create();
+        void* ev = g.timed ? opal_hip_event_create() : opal_hip_event_create_untimed();
         if (!ev) return false;
         g.events.push_back(ev);
     }
-    if (g.stateCap < (size_t)nchunks) { g.state.reset(new std::atomic<int>[(size_t)nchunks]); g.stateCap = (size_t)nchunks; }
-    for (int c = 0; c < nchunks; c++) g.state[(size_t)c].store(0, std::memory_order_relaxed);
+    if (g.stateCap < (size_t)nchunks) {
+        g.state.reset(new std::atomic<int>[(size_t)nchunks]);
+        g.left.reset(new std::atomic<int>[(size_t)nchunks]);
+        g.stateCap = (size_t)nchunks;
+    }
+    for (int c = 0; c < nchunks; c++) { g.state[(size_t)c].store(0, std::memory_order_relaxed); g.left[(size_t)c].store(0, std::memory_order_relaxed); }
+    for (int p = 0; p < npieces; p++) g.left[(size_t)g.pieceChunk[(size_t)p]].fetch_add(1, std::memory_order_relaxed);
     const int dev = db->device;
-    db->gatherFn = [db, getSeq, dev, total, items](int c) {
+    db->gatherFn = [db, getSeq, dev, total, items](int p) {
         static thread_local int myDevice = -1;  // pool threads start on device 0: the copy below names a stream of `dev`
         if (myDevice != dev) { opal_hip_set_device(dev); myDevice = dev; }
         UploadGate& gg = db->gate;
-        const size_t i0 = (size_t)gg.cutItem[(size_t)c], i1 = (size_t)gg.cutItem[(size_t)c + 1];
         unsigned char* h = db->hRaw.p;
         const int* len = db->pairLen.data(); const int* seq = db->pairSeq.data(); const uint64_t* off = db->seqOff.data();
-        for (size_t i = i0; i < i1; i++)
+        for (size_t i = (size_t)gg.pieceCut[(size_t)p], i1 = (size_t)gg.pieceCut[(size_t)p + 1]; i < i1; i++)
             if (seq[i] >= 0 && len[i] > 0) memcpy(h + off[i], getSeq(seq[i]), (size_t)len[i]);
+        const int c = gg.pieceChunk[(size_t)p];
+        if (gg.left[(size_t)c].fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+        // the last piece of chunk c: its copy, and the event the launches wait for
+        const size_t i0 = (size_t)gg.cutItem[(size_t)c], i1 = (size_t)gg.cutItem[(size_t)c + 1];
         const uint64_t b0 = off[i0], b1 = i1 < items ? off[i1] : total;
         bool good = true;
         if (b1 > b0 && opal_hip_memcpy_h2d(db->res.p + b0, h + b0, b1 - b0, db->copyStream)) good = false;
         if (good && opal_hip_event_record(gg.events[(size_t)c], db->copyStream)) good = false;
         gg.state[(size_t)c].store(good ? 1 : -1, std::memory_order_release);
+        if (debug_on() && (c == 0 || c + 1 == gg.chunks() || c == gg.chunks() / 2))
+            fprintf(stderr, "[opal] fill: chunk %d of %d enqueued %.3f ms after the gather began\n", c, gg.chunks(), now_ms() - db->fillT0);
     };
     g.active = true;
     HostPool& pool = HostPool::get();
+    if (g.timed) opal_hip_event_record(db->event(7), db->copyStream);  // (debug reference: the copy stream when the gather begins)
+    db->fillT0 = now_ms();
+    if (debug_on()) fprintf(stderr, "[opal] fill: order %.3f ms, metadata + chunk plan %.3f ms, %d chunks of ~%.1f MB in %d pieces\n", tf1 - tf0, db->fillT0 - tf1, nchunks, (double)chunkBytes / 1048576.0, npieces);
     if (async) {
-        pool.begin(nchunks, db->gatherFn);
+        pool.begin(npieces, db->gatherFn);
         db->gatherPending = true;
         return true;
     }
-    pool.parallel_for(nchunks, db->gatherFn);
+    pool.parallel_for(npieces, db->gatherFn);
     ok = gate_items(db, st, 0, (int)items);  // everything on `main` from here on comes after the last chunk
     g.active = false;
     db->gatherFn = nullptr;
@@ -213,6 +251,13 @@ bool db_fill_finish(OpalxDb* db) {
         db->gatherPending = false;
         for (int c = 0; c < db->gate.chunks(); c++)
             if (db->gate.state[(size_t)c].load(std::memory_order_acquire) < 0) ok = false;
+        if (ok && db->gate.timed && debug_on() && db->gate.chunks() > 0) {  // (debug only: waits for the copies)
+            opal_hip_stream_sync(db->copyStream);
+            const int nc = db->gate.chunks();
+            for (int c : {0, nc / 4, nc / 2, 3 * nc / 4, nc - 1})
+                fprintf(stderr, "[opal] fill: chunk %d of %d on the device %.3f ms after the gather began\n", c, nc,
+                        opal_hip_event_elapsed_ms(db->events[7], db->gate.events[(size_t)c]));
+        }
         db->gatherFn = nullptr;
     }
     db->gate.active = false;
@@ -317,7 +362,16 @@ extern "C" void opalx_release_cached(void) {
     if (cur >= 0) opal_hip_set_device(cur);
 }
 
-extern "C" void opalx_db_clock_probe(OpalxDb* db, int enable) { if (db) db->clockProbe = enable != 0; }
+extern "C" void opalx_db_clock_probe(OpalxDb* db, int enable) { if (db) { db->clockProbe = enable != 0; db->timelineProbe = enable == 2; } }
+extern "C" int opalx_db_last_timeline(OpalxDb* db, unsigned long long* out, int capacity) {
+    if (!db || !db->timeline.p || capacity < 2) return 0;
+    const int blocks = std::min(capacity / 2, 65536);
+    void* st = db->main();
+    if (opal_hip_memcpy_d2h(out, db->timeline.p, (size_t)blocks * 2 * sizeof(unsigned long long), st) || opal_hip_stream_sync(st)) return 0;
+    int n = blocks;
+    while (n > 0 && out[2 * (size_t)n - 1] == 0) n--;
+    return n;
+}
 extern "C" double opalx_db_last_clock_ghz(const OpalxDb* db) { return db ? db->lastClockGhz : 0.0; }
 extern "C" int opalx_db_num_sequences(const OpalxDb* db) { return db ? db->numSeqs : 0; }
 extern "C" int64_t opalx_db_num_residues(const OpalxDb* db) { return db ? db->residues : 0; }

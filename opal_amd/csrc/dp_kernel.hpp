@@ -79,15 +79,19 @@ struct KParams {
     // constant-rate ticks (s_memrealtime) of its own lifetime to clk[0] / clk[1]; their ratio is the clock the chip
     // sustained under THIS kernel (it clocks to its power budget: MI355X_MICROARCH.md, DVFS).
     unsigned long long* clk;
+    // Timeline probe (off = nullptr): every workgroup writes the constant-rate ticks at its start and end to
+    // tl[2 * blockIdx.x], tl[2 * blockIdx.x + 1] (scripts/gpu_timeline.py: where the time of a launch goes).
+    unsigned long long* tl;
 };
 
 // The two start stamps -- and the pointer itself -- wait in 32 bytes behind the workgroup's LDS data, so that nothing of
 // the probe is live in a register across the column loop (the 40-row kernels sit at 128 VGPRs).
-__device__ __forceinline__ void clk_begin(unsigned long long* clk, unsigned char* slot) {
+__device__ __forceinline__ void clk_begin(unsigned long long* clk, unsigned long long* tl, unsigned char* slot) {
     if (threadIdx.x == 0) {
         unsigned long long* s = reinterpret_cast<unsigned long long*>(slot);
         s[2] = (unsigned long long)(uintptr_t)clk;
-        if (clk) { s[0] = (unsigned long long)clock64(); s[1] = (unsigned long long)wall_clock64(); }
+        s[3] = (unsigned long long)(uintptr_t)tl;
+        if (clk || tl) { s[0] = (unsigned long long)clock64(); s[1] = (unsigned long long)wall_clock64(); }
     }
 }
 __device__ __forceinline__ void clk_end(const unsigned char* slot) {
@@ -98,6 +102,8 @@ __device__ __forceinline__ void clk_end(const unsigned char* slot) {
             atomicAdd(clk, (unsigned long long)clock64() - s[0]);
             atomicAdd(clk + 1, (unsigned long long)wall_clock64() - s[1]);
         }
+        unsigned long long* tl = reinterpret_cast<unsigned long long*>((uintptr_t)s[3]);
+        if (tl && blockIdx.x < 65536u) { tl[2 * (size_t)blockIdx.x] = s[1]; tl[2 * (size_t)blockIdx.x + 1] = (unsigned long long)wall_clock64(); }
     }
 }
 
@@ -338,20 +344,31 @@ __host__ __device__ inline int opal_profile_stride(int es, int G, int S, int pad
     return stride;
 }
 
-// OV, last column of a sequence: the maximum over a lane's rows in the skewed frame. The running best moves from the frame
-// of row J+1 to that of row J with one subtraction; a row that reaches it takes over (ties: the smaller row). Four
-// full-rate 16-bit instructions per row (and the wait between a compare and the selects that read its mask).
-template <typename V, int S, int J> struct OvColumnScan {
-    static __device__ __forceinline__ void run(const typename V::reg (&Hp)[S], typename V::reg Rv, typename V::reg& bf, int& bj) {
-        unsigned long long m;
+// OV, last column of a sequence: the maximum over a lane's rows in the skewed frame, and the smallest row attaining it.
+// Two parts: the VALUE alone costs two full-rate instructions per row (best = max(best - Ge, H[J])
+// walks the running best from the frame of row J+1 into that of row J); the ROW holding it -- the smallest one -- is looked
+// for only when the value beats what the lanes above have found, which it rarely does (three instructions per row then:
+// the target moves from the frame of row J+1 to that of row J with one subtraction).
+template <typename V, int S, int J> struct OvColumnMax {
+    static __device__ __forceinline__ void run(const typename V::reg (&Hp)[S], typename V::reg Rv, typename V::reg& bf) {
         asm("v_sub_u16_e32 %[bf], %[bf], %[rv]\n\t"
-            "v_cmp_ge_i16_e64 %[m], %[h], %[bf]\n\t"
-            "s_nop 1\n\t"
-            "v_cndmask_b32_e64 %[bf], %[bf], %[h], %[m]\n\t"
+            "v_max_i16_e32 %[bf], %[bf], %[h]"
+            : [bf] "+v"(bf)
+            : [h] "v"(Hp[J]), [rv] "v"(Rv));
+        if constexpr (J > 0) OvColumnMax<V, S, J - 1>::run(Hp, Rv, bf);
+    }
+};
+template <typename V, int S, int J> struct OvColumnRow {
+    // t: the column maximum in the frame of row J on entry, of row J-1 on exit
+    static __device__ __forceinline__ void run(const typename V::reg (&Hp)[S], typename V::reg Rv, typename V::reg& t, int& bj) {
+        unsigned long long m;
+        asm("v_cmp_eq_u16_e64 %[m], %[h], %[t]\n\t"
+            "v_sub_u16_e32 %[t], %[t], %[rv]\n\t"
+            "s_nop 0\n\t"
             "v_cndmask_b32_e64 %[bj], %[bj], %[j], %[m]"
-            : [bf] "+v"(bf), [bj] "+v"(bj), [m] "=&s"(m)
+            : [t] "+v"(t), [bj] "+v"(bj), [m] "=&s"(m)
             : [h] "v"(Hp[J]), [rv] "v"(Rv), [j] "n"(J));
-        if constexpr (J > 0) OvColumnScan<V, S, J - 1>::run(Hp, Rv, bf, bj);
+        if constexpr (J > 0) OvColumnRow<V, S, J - 1>::run(Hp, Rv, t, bj);
     }
 };
 
@@ -396,7 +413,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
     const bool hasPrev = MULTI && (p.chunkFlags & 1), hasNext = MULTI && (p.chunkFlags & 2);
     const int padTop = (MODE == MODE_NW || hasPrev) ? 0 : (G * S - CR);
     unsigned char* const clkSlot = lds + (size_t)(A + 1) * stride;  // (the launch reserves 32 bytes behind the profile)
-    clk_begin(p.clk, clkSlot);
+    clk_begin(p.clk, p.tl, clkSlot);
 
     // ---- stage the query profile in LDS: QP[letter][k][j] = M[query[k*S+j-padTop]][letter]; letter A = padding.
     // A thread owns (lane k, row j) positions and walks the letters: one query byte per position, then matrix reads
@@ -528,7 +545,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
     int wrapped = 0;
 #pragma unroll
     for (int h = 0; h < NH; h++) {
-        best[h] = INT_MIN; bestCol[h] = -1; prevBest[h] = INT_MIN; lcMax[h] = INT_MIN; lcRow[h] = -1;
+        best[h] = INT_MIN; bestCol[h] = -1; prevBest[h] = INT_MIN; lcMax[h] = (SKEW && MODE == MODE_OV) ? 0 : INT_MIN; lcRow[h] = -1;  // (skewed OV: lcMax is a key, see the loop)
         endCol[h] = INT_MAX; endRow[h] = -1;
     }
     // where query row Q-1 lives: NW: lane kLast, register jLast; otherwise last register of lane G-1
@@ -580,6 +597,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
     int4 pfirst = make_int4(0, 0, 0, 0);  // PF_TOP: first row block of the profile column of the coming step
     if constexpr (PF_TOP) { advance(0); pfirst = lds_ld16(offv[0]); }
 
+    reg bestF = V::splat(-32768);            // SKEW, HW/OV: last-row maximum so far, in the skewed frame of the step at hand
     int slotMax = 0;                         // SW end location: slot-wide running maximum (see the scan filter)
     int topHv = V::clampv(-(long long)Go);  // NW: H[-1][0]
     reg sRv = 0;                             // SKEW: s*Ge as a 16-bit value
@@ -780,7 +798,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
                         if (c == len[hh] - 1) best[hh] = V::half(SKEW ? V::subs(hl, V::splat((jLast + s) * Ge)) : hl, hh);
                 }
             }
-            if ((MODE == MODE_HW || MODE == MODE_OV) && k == kLast && !hasNext) {
+            if ((MODE == MODE_HW || MODE == MODE_OV) && !SKEW && k == kLast && !hasNext) {
                 // last query row = last register of the last lane = this column's outH
 #pragma unroll
                 for (int hh = 0; hh < NH; hh++) {
@@ -795,30 +813,71 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
                 bool lastc = false;
 #pragma unroll
                 for (int hh = 0; hh < NH; hh++) lastc |= (c == len[hh] - 1);
+                if constexpr (!SKEW) {
                 if (lastc) {
 #pragma unroll
                     for (int hh = 0; hh < NH; hh++) {
                         if (c == len[hh] - 1) {
                             int bv = lcMax[hh], bj = -1;
-                            if constexpr (SKEW) {  // (SKEW: single launch, one sequence per lane, lcMax still at its start value)
-                                if (jlo == 0 && jhi == S) {  // all my rows are query rows: the scan in the skewed frame
-                                    reg bf = Hp[S - 1];
-                                    bj = S - 1;
-                                    if constexpr (S > 1) OvColumnScan<V, S, S - 2>::run(Hp, Rv, bf, bj);
-                                    bv = V::half(V::subs(bf, V::splat(s * Ge)), hh);
-                                    lcMax[hh] = bv; lcRow[hh] = r0 + bj;
-                                    continue;
-                                }
-                            }
 #pragma unroll
                             for (int j = S - 1; j >= 0; j--) {
-                                const int v = V::half(SKEW ? V::subs(Hp[j], V::splat((j + s) * Ge)) : Hp[j], hh);
+                                const int v = V::half(Hp[j], hh);
                                 if (j >= jlo && j < jhi && v >= bv) { bv = v; bj = j; }
                                 asm volatile("" : "+v"(bv), "+v"(bj));  // keep the scan a short serial chain (register pressure)
                             }
                             if (bj >= 0) { lcMax[hh] = bv; lcRow[hh] = r0 + bj; }
                         }
                     }
+                }
+                }
+            }
+        }
+        if constexpr ((MODE == MODE_HW || MODE == MODE_OV) && SKEW) {
+            // Last-row maximum and its first column (last query row = last register of the last lane = this column's outH),
+            // tracked by EVERY lane in the skewed frame with full-rate 16-bit instructions -- no branch, no unskewing per
+            // step: the running best moves into the next step's frame with one addition (only the lane holding row Q-1 is
+            // read at the end). HW: over all columns; OV: over columns 0 .. L-2 -- the last column is covered by the
+            // last-column maximum below, which includes row Q-1. (Columns before my first one and beyond the sequence fail
+            // the one unsigned comparison.)
+            const unsigned limit = (unsigned)(MODE == MODE_OV ? len[0] - 1 : len[0]);
+            const bool better = (unsigned)c < limit && (short)outH > (short)bestF;  // strict >: first column wins (opal.cpp:824-834)
+            bestF = better ? outH : bestF;
+            bestCol[0] = better ? c : bestCol[0];
+            bestF = V::adds(bestF, Rv);
+        }
+        if constexpr (MODE == MODE_OV && SKEW) {
+            // The last column of a sequence (single launch, one sequence per lane): lane k reaches it one step after lane
+            // k-1, so the maximum over the rows above travels down the lanes with it (one DPP move per such step, all lanes
+            // active: the branch is wave-uniform) as ONE key: (value + 32768) << 16 | (65535 - row) -- the larger key is the
+            // larger value, then the smaller row. The lane holding query row Q-1 ends up with the column's maximum and the
+            // smallest row attaining it.
+            const bool lastc = c >= 0 && c == len[0] - 1;
+            if (__ballot(lastc) != 0ull) {
+                unsigned inKey = shr1((unsigned)lcMax[0]);
+                if (k == 0) inKey = 0u;
+                if (lastc) {
+                    unsigned myKey = 0u;
+                    if (jlo == 0 && jhi == S) {  // all my rows are query rows: the value first, in the skewed frame
+                        reg bf = Hp[S - 1];
+                        if constexpr (S > 1) OvColumnMax<V, S, S - 2>::run(Hp, Rv, bf);
+                        const unsigned bv = (unsigned)(V::half(V::subs(bf, V::splat(s * Ge)), 0) + 32768);
+                        if (bv > (inKey >> 16)) {  // (rare) ... then the smallest row holding it
+                            reg t = V::adds(bf, SR1v);
+                            int bj = 0;
+                            OvColumnRow<V, S, S - 1>::run(Hp, Rv, t, bj);
+                            myKey = (bv << 16) | (unsigned)(65535 - (r0 + bj));
+                        }
+                    } else {
+                        int bv = INT_MIN, bj = -1;
+#pragma unroll
+                        for (int j = S - 1; j >= 0; j--) {
+                            const int v = V::half(V::subs(Hp[j], V::splat((j + s) * Ge)), 0);
+                            if (j >= jlo && j < jhi && v >= bv) { bv = v; bj = j; }
+                            asm volatile("" : "+v"(bv), "+v"(bj));
+                        }
+                        if (bj >= 0) myKey = ((unsigned)(bv + 32768) << 16) | (unsigned)(65535 - (r0 + bj));
+                    }
+                    lcMax[0] = (int)(myKey > inKey ? myKey : inKey);
                 }
             }
         }
@@ -883,12 +942,21 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
         }
     }
     if (MODE != MODE_SW) {
+        if constexpr ((MODE == MODE_HW || MODE == MODE_OV) && SKEW) {  // out of the frame of the step after the last one
+            best[0] = bestCol[0] >= 0 ? V::half(V::subs(bestF, V::adds(sRv, SR1v)), 0) : INT_MIN;
+            prevBest[0] = best[0];  // (OV: the maximum over columns 0 .. L-2, see the loop)
+        }
 #pragma unroll
         for (int hh = 0; hh < NH; hh++) {
             int sc = best[hh], eq = Q - 1, et = (MODE == MODE_NW) ? len[hh] - 1 : bestCol[hh];
             if (MODE == MODE_OV) {
                 // last-column maximum over all lanes of the slot (value, then smallest row) (opal.cpp:881-904)
                 int v = lcMax[hh], r = lcRow[hh];
+                if constexpr (SKEW) {  // the lane holding row Q-1 has the whole column's key (see the loop)
+                    const unsigned key = (unsigned)lcMax[hh];
+                    v = key ? (int)(key >> 16) - 32768 : INT_MIN;
+                    r = key ? 65535 - (int)(key & 0xffffu) : -1;
+                } else
                 for (int d = 1; d < G; d <<= 1) {
                     const int ov = __shfl_xor(v, d, 64), orow = __shfl_xor(r, d, 64);
                     if (ov > v || (ov == v && orow >= 0 && (r < 0 || orow < r))) { v = ov; r = orow; }

@@ -3,16 +3,25 @@
 // host allocations and N result structs per call, and walking them is what an MI355X call is made of
 // once the DP itself takes under two milliseconds).
 //
-// One job at a time (submissions from several caller threads queue up); the submitting thread works
-// too (parallel_for) or goes on with its own work while the workers run the job (begin / end: opalSearchDatabase
+// One job at a time (submissions from several caller threads queue up). The submitting thread works too
+// (parallel_for) or goes on with its own work while the workers run the job (begin / end: opalSearchDatabase
 // launches the search of the sequences that have reached the device while the workers are still gathering the rest).
+// Tasks are handed out in increasing order.
+//
+// A job costs what its tasks cost: only as many sleeping workers are woken as there are tasks, the submitter waits for
+// the TASKS (a counter), not for every worker to check in and out (with 63 workers that alone took 0.15 ms per job, on a
+// call whose whole budget is 2 ms), and the first few workers keep polling for ~100 us after a job, so that the five
+// jobs of one opalSearchDatabase call find them awake.
+//
 // The pool is created on first use and intentionally never destroyed: joining threads from a
 // static destructor, after the HIP runtime has begun to shut down, is a known way to hang at exit.
 // After fork() the child has no worker threads (only the forking thread survives): the pool notices the new pid and
 // runs jobs inline there instead of waiting for workers that do not exist.
 #pragma once
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <cstdint>
 #include <cstdlib>
 #include <functional>
 #include <mutex>
@@ -40,58 +49,40 @@ public:
         return *pool;
     }
     // number of threads a job can run on (workers + the submitting thread)
-    int width() const { return (int)workers_.size() + 1; }
+    int width() const { return nworkers_ + 1; }
 
     // fn(task) for task in [0, ntasks); returns when every task has finished.
     void parallel_for(int ntasks, const std::function<void(int)>& fn) {
         if (ntasks <= 0) return;
-        if (ntasks == 1 || workers_.empty() || getpid() != pid_) {
+        if (ntasks == 1 || nworkers_ == 0 || getpid() != pid_) {
             for (int t = 0; t < ntasks; t++) fn(t);
             return;
         }
         std::lock_guard<std::mutex> submit(submit_);
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            job_ = &fn;
-            ntasks_ = ntasks;
-            next_.store(0, std::memory_order_relaxed);
-            active_ = (int)workers_.size();
-            gen_++;
-        }
-        cvWork_.notify_all();
-        run_tasks(fn, ntasks);
-        std::unique_lock<std::mutex> lk(m_);
-        cvDone_.wait(lk, [&] { return active_ == 0; });
-        job_ = nullptr;
+        const uint32_t gen = publish(ntasks, fn, ntasks - 1);
+        run_tasks(gen, fn, ntasks);
+        wait_done(ntasks);
+        retire();
     }
 
     // The same job run by the WORKERS ONLY: begin() returns at once, the caller does something else and calls end()
-    // (exactly once) to wait for the last task. Tasks are handed out in increasing order. `fn` must stay alive until
-    // end() returns. With no workers (one hardware thread, or a forked child) the tasks run inside begin().
+    // (exactly once) to wait for the last task. `fn` must stay alive until end() returns. The caller must not use the
+    // pool in between. With no workers (one hardware thread, or a forked child) the tasks run inside begin().
     void begin(int ntasks, const std::function<void(int)>& fn) {
         submit_.lock();  // held until end(): one job at a time
-        if (ntasks <= 0 || workers_.empty() || getpid() != pid_) {
+        asyncTasks_ = 0;
+        if (ntasks <= 0 || nworkers_ == 0 || getpid() != pid_) {
             for (int t = 0; t < ntasks; t++) fn(t);
-            asyncActive_ = false;
             return;
         }
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            job_ = &fn;
-            ntasks_ = ntasks;
-            next_.store(0, std::memory_order_relaxed);
-            active_ = (int)workers_.size();
-            gen_++;
-        }
-        asyncActive_ = true;
-        cvWork_.notify_all();
+        publish(ntasks, fn, ntasks);
+        asyncTasks_ = ntasks;
     }
     void end() {
-        if (asyncActive_) {
-            std::unique_lock<std::mutex> lk(m_);
-            cvDone_.wait(lk, [&] { return active_ == 0; });
-            job_ = nullptr;
-            asyncActive_ = false;
+        if (asyncTasks_ > 0) {
+            wait_done(asyncTasks_);
+            retire();
+            asyncTasks_ = 0;
         }
         submit_.unlock();
     }
@@ -108,47 +99,97 @@ public:
     }
 
 private:
-    explicit HostPool(int threads) : pid_(getpid()) {
-        for (int i = 1; i < threads; i++) {
-            workers_.emplace_back([this] { worker(); });
-            workers_.back().detach();
-        }
+    static constexpr int SPINNERS = 15;        // workers that keep polling for a while after a job
+    static constexpr int SPIN_MICROSECONDS = 120;
+
+    explicit HostPool(int threads) : nworkers_(threads > 1 ? threads - 1 : 0), pid_(getpid()) {
+        for (int i = 0; i < nworkers_; i++) std::thread([this, i] { worker(i); }).detach();
     }
-    void run_tasks(const std::function<void(int)>& fn, int ntasks) {
+    // Make a job visible: the ticket carries the job's generation in its high half, so a worker that still holds an
+    // older job can never claim a task of this one. Wakes at most `helpers` sleeping workers.
+    uint32_t publish(int ntasks, const std::function<void(int)>& fn, int helpers) {
+        uint32_t gen;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &fn;
+            ntasks_ = ntasks;
+            gen = ++gen_;
+            done_.store(0, std::memory_order_relaxed);
+            ticket_.store((uint64_t)gen << 32, std::memory_order_release);
+            genSeen_.store(gen, std::memory_order_release);
+        }
+        const int wake = helpers < nworkers_ ? helpers : nworkers_;
+        if (wake >= nworkers_) cvWork_.notify_all();
+        else for (int i = 0; i < wake; i++) cvWork_.notify_one();
+        return gen;
+    }
+    void retire() {
+        std::lock_guard<std::mutex> lk(m_);
+        job_ = nullptr;
+    }
+    void run_tasks(uint32_t gen, const std::function<void(int)>& fn, int ntasks) {
         for (;;) {
-            const int t = next_.fetch_add(1, std::memory_order_relaxed);
-            if (t >= ntasks) break;
-            fn(t);
+            uint64_t cur = ticket_.load(std::memory_order_acquire);
+            for (;;) {
+                if ((uint32_t)(cur >> 32) != gen || (int)(uint32_t)cur >= ntasks) return;
+                if (ticket_.compare_exchange_weak(cur, cur + 1, std::memory_order_acq_rel)) break;
+            }
+            fn((int)(uint32_t)cur);
+            if (done_.fetch_add(1, std::memory_order_acq_rel) + 1 == ntasks) {
+                std::lock_guard<std::mutex> lk(m_);
+                cvDone_.notify_all();
+            }
         }
     }
-    void worker() {
-        uint64_t seen = 0;
+    void wait_done(int ntasks) {
+        for (int spin = 0; spin < 4000; spin++) {
+            if (done_.load(std::memory_order_acquire) >= ntasks) return;
+            __builtin_ia32_pause();
+        }
+        std::unique_lock<std::mutex> lk(m_);
+        cvDone_.wait(lk, [&] { return done_.load(std::memory_order_acquire) >= ntasks; });
+    }
+    void worker(int index) {
+        uint32_t seen = 0;
         for (;;) {
             const std::function<void(int)>* fn;
             int n;
+            uint32_t gen;
             {
                 std::unique_lock<std::mutex> lk(m_);
                 cvWork_.wait(lk, [&] { return gen_ != seen; });
-                seen = gen_;
+                seen = gen = gen_;
                 fn = job_;
                 n = ntasks_;
             }
-            if (fn) run_tasks(*fn, n);
-            {
+            for (;;) {
+                if (fn) run_tasks(gen, *fn, n);
+                if (index >= SPINNERS) break;
+                // keep polling for the next job for a little while (the jobs of one API call follow each other closely)
+                const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(SPIN_MICROSECONDS);
+                bool found = false;
+                while (std::chrono::steady_clock::now() < until) {
+                    if (genSeen_.load(std::memory_order_acquire) != seen) { found = true; break; }
+                    for (int i = 0; i < 64; i++) __builtin_ia32_pause();
+                }
+                if (!found) break;
                 std::lock_guard<std::mutex> lk(m_);
-                if (--active_ == 0) cvDone_.notify_all();
+                seen = gen = gen_;
+                fn = job_;
+                n = ntasks_;
             }
         }
     }
 
-    std::vector<std::thread> workers_;
-    const pid_t pid_;           // the process that owns the worker threads
-    bool asyncActive_ = false;  // between begin() and end(), protected by submit_
+    const int nworkers_;
+    const pid_t pid_;     // the process that owns the worker threads
+    int asyncTasks_ = 0;  // tasks of the job between begin() and end(), protected by submit_
     std::mutex m_, submit_;
     std::condition_variable cvWork_, cvDone_;
-    const std::function<void(int)>* job_ = nullptr;
+    const std::function<void(int)>* job_ = nullptr;  // protected by m_, together with ntasks_ and gen_
     int ntasks_ = 0;
-    std::atomic<int> next_{0};
-    int active_ = 0;
-    uint64_t gen_ = 0;
+    uint32_t gen_ = 0;
+    std::atomic<uint32_t> genSeen_{0};   // gen_ again, for the polling workers
+    std::atomic<uint64_t> ticket_{0};    // (generation << 32) | next task
+    std::atomic<int> done_{0};
 };

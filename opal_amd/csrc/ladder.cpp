@@ -22,6 +22,7 @@ static void fill_launch(OpalHipLaunch& a, const SearchCtx& c, int width, int swE
     a.sat_limit = c.satLimit; a.neg_pad = c.negPad;
     a.stream = db->main();
     a.clock_probe = db->clockProbe ? (unsigned long long*)(db->header.p + 16) : nullptr;
+    a.timeline = (db->clockProbe && db->timelineProbe) ? db->timeline.p : nullptr;
 }
 
 // Queries that no single wave geometry can hold (more than 64 lanes x 40 rows, or a query profile
@@ -194,7 +195,11 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
     // the first slice holds the long classes.
     if (db->gate.active && !work && (width == 17 || width == 18) && db->gate.chunks() >= 4 && !getenv("OPAL_HIP_NO_SLICES")) {
         const UploadGate& g = db->gate;
-        std::vector<int> pattern{2, 3, 5};  // chunks per slice, the rest in the last one (C2: 17 chunks of 2 MB)
+        // chunks per slice, the rest in the last one (C2: 17 chunks of 2 MB). The FIRST slice holds the long classes: its
+        // longest sequence is the critical path of the whole search, so it is as small as it can be (it starts as soon as
+        // one chunk has landed) and runs on a high-priority side stream of its own; the others take `main` and `aux` in
+        // turn, so that a slice starts while the previous one drains.
+        std::vector<int> pattern{1, 4};  // (measured on C2, 17 chunks: 1,4 | 1,3,5 | 1,2,4 | 1,3,5,4 all within 0.1 ms; 1,16 and one launch 0.3 ms slower)
         if (const char* e = getenv("OPAL_HIP_SLICES")) {
             pattern.clear();
             for (const char* q = e; *q;) { char* endp = nullptr; const long v = strtol(q, &endp, 10); if (endp == q) break; if (v > 0) pattern.push_back((int)v); q = *endp ? endp + 1 : endp; }
@@ -204,19 +209,34 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
         for (int want : pattern) {
             chunk += want;
             if (chunk >= g.chunks()) break;
-            const int at = g.cutItem[(size_t)chunk];
+            int at = g.cutItem[(size_t)chunk];
+            if (cut.size() == 1 && classes.size() > 1) at = std::max(at, bulk.first);  // every long class inside the first slice
             if (at > cut.back() && at < firstItem + numItems) cut.push_back(at);
         }
         cut.push_back(firstItem + numItems);
         void* fork = db->event(0);
         void* aux = db->aux();
-        if (!fork || !aux || opal_hip_event_record(fork, db->main()) || opal_hip_stream_wait_event(aux, fork)) return OPAL_ERR_NO_SIMD_SUPPORT;
+        void* side = db->stream(0);
+        if (!fork || !aux || !side || !db->stream(1) || !db->stream(2) || opal_hip_event_record(fork, db->main()) ||
+            opal_hip_stream_wait_event(aux, fork) || opal_hip_stream_wait_event(side, fork) || opal_hip_stream_wait_event(db->stream(1), fork) ||
+            opal_hip_stream_wait_event(db->stream(2), fork))
+            return OPAL_ERR_NO_SIMD_SUPPORT;
         int err = 0;
         bool auxUsed = false;
+        const bool dbg = debug_on();
+        std::vector<void*> marks;  // (debug: timed events around every slice)
         for (size_t j = 0; j + 1 < cut.size() && !err; j++) {
-            void* stream = (j & 1) ? aux : db->main();
-            auxUsed |= (j & 1) != 0;
+            // stream of slice j: 0 on the side stream; the others on main / aux in turn ("alternate", the default: a slice
+            // starts while the previous one drains), all on `main` ("serial": 0.3 ms slower on C2 -- a slice smaller than one
+            // resident round, 32 000 sequences, leaves every SIMD with one or two waves), or main, aux, side streams 1 and 2
+            // ("separate": no better than alternate)
+            static const int how = [] { const char* e = getenv("OPAL_HIP_SLICE_STREAMS"); return !e ? 1 : !strcmp(e, "serial") ? 0 : !strcmp(e, "separate") ? 2 : 1; }();
+            void* stream = j == 0 ? side : db->main();
+            if (j > 0 && how == 1) stream = (j & 1) ? db->main() : aux;
+            if (j > 0 && how == 2) stream = j == 1 ? db->main() : j == 2 ? aux : db->stream(1 + (int)(j & 1));
+            auxUsed |= stream != side && stream != db->main();
             if (!gate_items(db, stream, cut[j], cut[j + 1] - cut[j])) { err = 1; break; }
+            if (dbg) { void* ev = opal_hip_event_create(); marks.push_back(ev); if (ev) opal_hip_event_record(ev, stream); }
             if (oneGrid) err = launch_grid(cut[j], cut[j + 1], stream);
             else
                 for (size_t ki = 0; ki < classes.size() && !err; ki++) {
@@ -226,12 +246,27 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
                     k.first = a; k.count = b - a;
                     err = launch_class(c, width, swEndPass, detectWrap, nullptr, k, maySkew && skew_ok(classes[ki].first), ovfCounter, stream, ki + 1 < classes.size());
                 }
+            if (dbg) { void* ev = opal_hip_event_create(); marks.push_back(ev); if (ev) opal_hip_event_record(ev, stream); }
         }
-        if (!err && auxUsed) {
-            void* join = db->event(6);
-            if (!join || opal_hip_event_record(join, aux) || opal_hip_stream_wait_event(db->main(), join)) err = 1;
+        if (!err) {
+            void* join = db->event(1);
+            if (!join || opal_hip_event_record(join, side) || opal_hip_stream_wait_event(db->main(), join)) err = 1;
         }
+        if (!err && auxUsed)  // (whichever of them were used: joining an idle stream costs nothing)
+            for (int q = 0; q < 3 && !err; q++) {
+                void* other = q == 0 ? aux : db->stream(q);
+                void* join = db->event(q == 0 ? 6 : 1 + q);
+                if (!other || !join || opal_hip_event_record(join, other) || opal_hip_stream_wait_event(db->main(), join)) err = 1;
+            }
         if (err) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
+        if (dbg && !marks.empty() && marks[0]) {  // (debug only: waits for the search)
+            opal_hip_stream_sync(db->main());
+            for (size_t j = 0; 2 * j + 1 < marks.size(); j++)
+                if (marks[2 * j] && marks[2 * j + 1])
+                    fprintf(stderr, "[opal] slice %zu items [%d,%d): starts %.3f ms after slice 0 could, runs %.3f ms\n", j, cut[j], cut[j + 1],
+                            opal_hip_event_elapsed_ms(marks[0], marks[2 * j]), opal_hip_event_elapsed_ms(marks[2 * j], marks[2 * j + 1]));
+            for (void* ev : marks) opal_hip_event_destroy(ev);
+        }
         return 0;
     }
     // everything this range reads must have landed (no-op unless a fill is still in flight)
@@ -364,6 +399,8 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
     if (Q == 0 || P == 0) return opal_hip_stream_sync(st) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
 
     if (ensure_query_buffers(db, query, Q, M, A)) return OPAL_ERR_NO_SIMD_SUPPORT;  // (also zeroes the counters)
+    if (db->clockProbe && db->timelineProbe && (!db->timeline.ensure(2 * 65536) || opal_hip_memset(db->timeline.p, 0, 2 * 65536 * sizeof(unsigned long long), st)))
+        return OPAL_ERR_NO_SIMD_SUPPORT;
 
     long long maxS = 0, minS = 0;
     for (int i = 0; i < A * A; i++) { maxS = std::max<long long>(maxS, M[i]); minS = std::min<long long>(minS, M[i]); }

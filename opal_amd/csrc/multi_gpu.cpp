@@ -1,6 +1,6 @@
-// multi_gpu.cpp -- the devices of a call and the deal of sequences to them (the reference's natural shard
-// point is its per-chunk call, reference src/opal_aligner.cpp:125-160: sequences are independent, query and matrix are
-// broadcast constants).
+// multi_gpu.cpp -- the devices of a call, the deal of sequences to them, and the multi-GPU database handle with its
+// device-side gather (the reference's natural shard point is its per-chunk call, reference
+// src/opal_aligner.cpp:125-160: sequences are independent, query and matrix are broadcast constants).
 #include "opal_internal.hpp"
 
 namespace opal_host {
@@ -64,3 +64,142 @@ std::vector<std::vector<int>> deal_groups(const int* lens, int n, int parts) {
 }
 
 }  // namespace opal_host
+
+// ------------------------------------------------------------------------------------ one database over several GPUs
+struct OpalxMultiDb {
+    std::vector<int> devices;
+    std::vector<OpalxDb*> shard;             // one packed database per listed device
+    std::vector<int> count, first;           // sequences of each shard, its offset in the gathered block
+    std::vector<opal_host::DevBuf<int>> res; // per shard, on its device: {score, endQ, endT} x count
+    opal_host::DevBuf<int> gathered;         // root: [3][total] -- the shards' blocks side by side, per result vector
+    opal_host::DevBuf<int> perm;             // root: gathered position -> database index
+    std::vector<void*> done;                 // per shard: recorded behind its peer copy
+    void* rootStream = nullptr;
+    int total = 0;
+};
+
+using namespace opal_host;
+
+extern "C" void opalx_multi_destroy(OpalxMultiDb* m) {
+    if (!m) return;
+    const int cur = opal_hip_get_device();
+    for (size_t k = 0; k < m->shard.size(); k++) {
+        opal_hip_set_device(m->devices[k]);
+        if (m->shard[k]) opalx_db_destroy(m->shard[k]);
+        if (k < m->res.size()) m->res[k].release();
+        if (k < m->done.size()) opal_hip_event_destroy(m->done[k]);
+    }
+    if (!m->devices.empty()) {
+        opal_hip_set_device(m->devices[0]);
+        m->gathered.release(); m->perm.release();
+        opal_hip_stream_destroy(m->rootStream);
+    }
+    if (cur >= 0) opal_hip_set_device(cur);
+    delete m;
+}
+
+extern "C" OpalxMultiDb* opalx_multi_create_flat(const unsigned char* residues, const int64_t* offsets, int db_length,
+                                                 const int* devices, int num_devices) {
+    if (!device_ok() || num_devices < 1 || db_length < 0) return nullptr;
+    const int ndev = opal_hip_device_count();
+    for (int k = 0; k < num_devices; k++)
+        if (devices[k] < 0 || devices[k] >= ndev) return nullptr;
+    OpalxMultiDb* m = new (std::nothrow) OpalxMultiDb;
+    if (!m) return nullptr;
+    const int cur = opal_hip_get_device();
+    m->devices.assign(devices, devices + num_devices);
+    m->total = db_length;
+    std::vector<int> lens((size_t)db_length);
+    for (int i = 0; i < db_length; i++) lens[(size_t)i] = (int)(offsets[i + 1] - offsets[i]);
+    const std::vector<std::vector<int>> deal = deal_groups(lens.data(), db_length, num_devices);
+    m->shard.assign((size_t)num_devices, nullptr);
+    m->res.resize((size_t)num_devices);
+    m->done.assign((size_t)num_devices, nullptr);
+    std::vector<int> permHost;
+    permHost.reserve((size_t)db_length);
+    bool ok = true;
+    for (int k = 0; k < num_devices && ok; k++) {
+        const std::vector<int>& ids = deal[(size_t)k];
+        m->first.push_back((int)permHost.size());
+        m->count.push_back((int)ids.size());
+        permHost.insert(permHost.end(), ids.begin(), ids.end());
+        if (opal_hip_set_device(devices[k])) { ok = false; break; }
+        std::vector<int> slens(ids.size());
+        for (size_t i = 0; i < ids.size(); i++) slens[i] = lens[(size_t)ids[i]];
+        OpalxDb* db = new (std::nothrow) OpalxDb;
+        if (!db) { ok = false; break; }
+        m->shard[(size_t)k] = db;
+        ok = db_fill(db, (int)ids.size(), slens.data(), RAW_POINTERS,
+                     [residues, offsets, &ids](int i) { return residues + offsets[ids[(size_t)i]]; }, nullptr, nullptr) &&
+             m->res[(size_t)k].ensure(3 * std::max<size_t>(ids.size(), 1)) && (m->done[(size_t)k] = opal_hip_event_create_untimed()) != nullptr;
+        if (ok && devices[k] != devices[0]) opal_hip_enable_peer(devices[0]);  // (without it the copy is staged through the host)
+    }
+    if (ok) {
+        ok = !opal_hip_set_device(devices[0]) && m->gathered.ensure(3 * std::max<size_t>((size_t)db_length, 1)) &&
+             m->perm.ensure(std::max<size_t>((size_t)db_length, 1)) && (m->rootStream = opal_hip_stream_create()) != nullptr;
+        if (ok && db_length)
+            ok = !opal_hip_memcpy_h2d(m->perm.p, permHost.data(), (size_t)db_length * sizeof(int), m->rootStream) && !opal_hip_stream_sync(m->rootStream);
+    }
+    if (cur >= 0) opal_hip_set_device(cur);
+    if (!ok) { opalx_multi_destroy(m); return nullptr; }
+    return m;
+}
+
+extern "C" int opalx_multi_search_device(OpalxMultiDb* m, const unsigned char* query, int query_length, int gap_open, int gap_ext,
+                                         const int* score_matrix, int alphabet_length, int search_type, int mode,
+                                         int* d_score, int* d_end_query, int* d_end_target, float* kernel_ms) {
+    if (!m || !d_score) return OPAL_ERR_NO_SIMD_SUPPORT;
+    const int wantEnd = search_type != OPAL_SEARCH_SCORE;
+    if (wantEnd && (!d_end_query || !d_end_target)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (mode != OPAL_MODE_NW && mode != OPAL_MODE_HW && mode != OPAL_MODE_OV && mode != OPAL_MODE_SW) return OPAL_ERR_INVALID_MODE;
+    const size_t K = m->shard.size();
+    const int nres = wantEnd ? 3 : 1;
+    const size_t total = (size_t)m->total;
+    std::vector<int> rcs(K, 0);
+    std::vector<float> kms(K, 0.f);
+    std::vector<std::thread> threads;
+    const int cur = opal_hip_get_device();
+    for (size_t k = 0; k < K; k++) {
+        threads.emplace_back([&, k] {
+            const int n = m->count[k];
+            if (!n) return;
+            // device_ok() first: its once-per-thread OPAL_HIP_DEVICE selection must not override the shard's GPU
+            if (!device_ok() || opal_hip_set_device(m->devices[k])) { rcs[k] = OPAL_ERR_NO_SIMD_SUPPORT; return; }
+            OpalxDb* db = m->shard[k];
+            int* r = m->res[k].p;
+            rcs[k] = search_core(db, query, query_length, gap_open, gap_ext, score_matrix, alphabet_length, search_type, mode, r,
+                                 wantEnd ? r + n : nullptr, wantEnd ? r + 2 * (size_t)n : nullptr, kernel_ms ? &kms[k] : nullptr, /*finalSync=*/false);
+            if (rcs[k] == OPAL_ERR_NO_SIMD_SUPPORT || rcs[k] == OPAL_ERR_INVALID_MODE) return;
+            // the path's only exchange: this shard's block to the root GPU (peer DMA over xGMI), vector by vector into its
+            // place in the gathered block, on the shard's own stream behind its kernels
+            void* st = db->main();
+            int e = 0;
+            for (int v = 0; v < nres; v++)
+                e |= opal_hip_memcpy_peer(m->gathered.p + (size_t)v * total + (size_t)m->first[k], m->devices[0], r + (size_t)v * n, m->devices[k],
+                                          (size_t)n * sizeof(int), st);
+            e |= opal_hip_event_record(m->done[k], st);
+            if (e) rcs[k] = OPAL_ERR_NO_SIMD_SUPPORT;
+        });
+    }
+    for (auto& th : threads) th.join();
+    int rc = 0;
+    for (size_t k = 0; k < K; k++) {
+        if (rcs[k] == OPAL_ERR_NO_SIMD_SUPPORT || rcs[k] == OPAL_ERR_INVALID_MODE) rc = rcs[k];
+        else if (rcs[k] && !rc) rc = rcs[k];
+    }
+    if (kernel_ms) { *kernel_ms = 0.f; for (size_t k = 0; k < K; k++) *kernel_ms = std::max(*kernel_ms, kms[k]); }
+    int e = opal_hip_set_device(m->devices[0]);
+    if (!e && rc != OPAL_ERR_NO_SIMD_SUPPORT && rc != OPAL_ERR_INVALID_MODE) {
+        // root: wait for every shard's copy, then the three vectors into database order
+        for (size_t k = 0; k < K; k++)
+            if (m->count[k]) e |= opal_hip_stream_wait_event(m->rootStream, m->done[k]);
+        int* outs[3] = {d_score, d_end_query, d_end_target};
+        for (int v = 0; v < nres; v++) e |= opal_hip_permute(m->gathered.p + (size_t)v * total, m->perm.p, m->total, outs[v], m->rootStream);
+        e |= opal_hip_stream_sync(m->rootStream);
+    }
+    // (an error on one shard: its stream may still hold work that reads the handle's buffers)
+    if (e || rc == OPAL_ERR_NO_SIMD_SUPPORT)
+        for (size_t k = 0; k < K; k++) { opal_hip_set_device(m->devices[k]); m->shard[k]->quiesce(); }
+    if (cur >= 0) opal_hip_set_device(cur);
+    return e ? OPAL_ERR_NO_SIMD_SUPPORT : rc;
+}

@@ -61,8 +61,10 @@ static int run_shard(int device, const unsigned char* query, int Q, unsigned cha
     if (opal_hip_memset32(dS, INT_MIN, nn, st) || (wantEnd && opal_hip_memset32(dQ, -1, 2 * nn, st))) return OPAL_ERR_NO_SIMD_SUPPORT;
     int rc = search_core(pdb, query, Q, Go, Ge, M, A, searchType, mode, dS, wantEnd ? dQ : nullptr, wantEnd ? dT : nullptr, nullptr,
                          /*finalSync=*/false);
+    const double t2b = now_ms();
     if (!db_fill_finish(pdb)) return OPAL_ERR_NO_SIMD_SUPPORT;
     const double t3 = now_ms();
+    if (debug_on()) fprintf(stderr, "[opal] shard: launches issued %.3f ms after the fill began, pool done at %.3f ms\n", t2b - t1, t3 - t1);
     if (rc == OPAL_ERR_NO_SIMD_SUPPORT || rc == OPAL_ERR_INVALID_MODE) return rc;
     int* h = pdb->hResults.p;
     // start cells for the alignment search, on the device while the end cells are still there (n4). Any failure
@@ -76,6 +78,7 @@ static int run_shard(int device, const unsigned char* query, int Q, unsigned cha
     }
     if (opal_hip_memcpy_d2h(h, dS, (haveStarts ? 5 : wantEnd ? 3 : 1) * nn * sizeof(int), st) || opal_hip_stream_sync(st))
         return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (debug_on()) fprintf(stderr, "[opal] shard: results on the host %.3f ms after the fill began\n", now_ms() - t1);
     memcpy(score, h, (size_t)n * sizeof(int));
     if (wantEnd) { memcpy(endQ, h + nn, (size_t)n * sizeof(int)); memcpy(endT, h + 2 * nn, (size_t)n * sizeof(int)); }
     if (startQ && startT) {

@@ -106,12 +106,16 @@ template <typename T> struct PinVec {
 // Residues on their way to the device, chunk by chunk, while the search of the sequences that have landed is being
 // launched (opalSearchDatabase: the gather of N host allocations and their upload overlap the search instead of preceding
 // it). Chunk c holds the items [cutItem[c], cutItem[c+1]); a pool thread gathers it into pinned memory, enqueues its copy on
-// the context's copy stream, records events[c] behind it and sets state[c] (1 enqueued, -1 failed).
+// the context's copy stream, records events[c] behind it and sets state[c] (1 enqueued, -1 failed). (The chunk is gathered
+// by several threads, piece by piece; the one that finishes its last piece does the copy.)
 struct UploadGate {
     bool active = false;
+    bool timed = false;  // (debug) the chunk events carry timestamps
     std::vector<int> cutItem;
+    std::vector<int> pieceCut, pieceChunk;  // the pool's tasks: piece p = items [pieceCut[p], pieceCut[p+1]) of chunk pieceChunk[p]
     std::vector<void*> events;  // (owned by the context: kept across calls)
     std::unique_ptr<std::atomic<int>[]> state;
+    std::unique_ptr<std::atomic<int>[]> left;  // pieces of chunk c still being gathered
     size_t stateCap = 0;
     int chunks() const { return active ? (int)cutItem.size() - 1 : 0; }
 };
@@ -134,6 +138,8 @@ struct OpalxDb {
     opal_host::PinVec<int> pairSeq;       // [items] caller indices, -1 = absent
     opal_host::PinVec<uint64_t> seqOff;   // [items] start of each sequence in `res`
     std::vector<int> emptySeqs;           // caller indices of zero-length sequences (answered on the host)
+    std::vector<int> ordHist, ordPos;     // scratch of the ordering (order_sequences)
+    std::vector<uint64_t> ordByte;
     // device: the packed database
     opal_host::DevBuf<unsigned char> res;
     opal_host::DevBuf<uint64_t> dSeqOff;
@@ -145,6 +151,8 @@ struct OpalxDb {
     size_t numTokens = 0;
     bool tokensValid = false;
     bool clockProbe = false;   // opalx_db_clock_probe
+    bool timelineProbe = false;
+    opal_host::DevBuf<unsigned long long> timeline;  // [2 x 65536 workgroups], zeroed before a probed search
     double lastClockGhz = 0;
     // One "search header" per search, uploaded with a single copy: {counters[4], clock probe[2 x u64], score matrix, query}. ovfCount[0] =
     // length of the 16-bit rung's re-run list, [1] = width-32 wrap count.
@@ -179,6 +187,7 @@ struct OpalxDb {
     opal_host::UploadGate gate;
     std::function<void(int)> gatherFn;  // the pool job of a (re)fill in flight (alive until db_fill_finish)
     bool gatherPending = false;
+    double fillT0 = 0;  // (debug timing)
     // Streams: everything of one search runs on `main` (a non-blocking stream: no implicit ordering
     // against the legacy null stream or against other contexts); long-sequence classes run on up to three
     // HIGH-priority side streams (hardware queues of their own), forked from and joined back into `main` with events.
@@ -205,7 +214,7 @@ struct OpalxDb {
         return streams[i];
     }
     void* event(int i) {
-        if (!events[i]) events[i] = opal_hip_event_create();
+        if (!events[i]) events[i] = (i == 4 || i == 5 || i == 7) ? opal_hip_event_create() : opal_hip_event_create_untimed();  // (4, 5: kernel timing)
         return events[i];
     }
     // Wait for everything this handle may have in flight (used on error paths before buffers are reused).

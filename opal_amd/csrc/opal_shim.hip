@@ -138,6 +138,12 @@ extern "C" void* opal_hip_event_create(void) {
     if (hipEventCreate(&ev) != hipSuccess) return nullptr;
     return (void*)ev;
 }
+// An event used for ordering only (no timestamps: cheaper to record and to wait for).
+extern "C" void* opal_hip_event_create_untimed(void) {
+    hipEvent_t ev;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return (void*)ev;
+}
 extern "C" void opal_hip_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
 extern "C" int opal_hip_event_record(void* ev, void* stream) {
     hipError_t e = hipEventRecord((hipEvent_t)ev, (hipStream_t)stream);
@@ -226,6 +232,30 @@ extern "C" int opal_hip_scatter_results(const int* quads, int count, int* score,
     return e == hipSuccess ? 0 : fail("scatter kernel launch", e);
 }
 
+// out[perm[i]] = in[i]: the gathered per-shard result blocks of a multi-GPU search back into database order (root GPU).
+__global__ void opal_permute_kernel(const int* __restrict__ in, const int* __restrict__ perm, int count, int* __restrict__ out) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < count) out[perm[i]] = in[i];
+}
+extern "C" int opal_hip_permute(const int* in, const int* perm, int count, int* out, void* stream) {
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(opal_permute_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, perm, count, out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("permute kernel launch", e);
+}
+
+// Let the calling thread's current device access `peer`'s memory directly (xGMI peer DMA for the gather of a multi-GPU
+// search). Already enabled, or the same device: fine.
+extern "C" int opal_hip_enable_peer(int peer) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1;
+    if (dev == peer) return 0;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, dev, peer) != hipSuccess || !can) return 1;
+    hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
+    if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); return 0; }
+    return e == hipSuccess ? 0 : fail("hipDeviceEnablePeerAccess", e);
+}
 
 // Kernels that need more than 64 KiB of dynamic LDS get the limit raised once per kernel and device (to the full 160 KiB):
 // hipFuncSetAttribute is not free while other kernels are running (it delayed a launch beside a running one by ~2 ms).
@@ -344,7 +374,7 @@ extern "C" int opal_hip_launch_uber(const OpalHipUberLaunch* u) {
     b.ovfCount = a->overflow_count; b.ovfItems = a->overflow_items;
     b.chunkRows = a->query_length;
     b.satLimit = a->sat_limit; b.negPad = a->neg_pad;
-    b.clk = a->clock_probe;
+    b.clk = a->clock_probe; b.tl = a->timeline;
     size_t lds = 0;
     int blocks = 0;
     for (int k = 0; k < 3; k++) {
@@ -403,7 +433,7 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
     p.scratch = a->scratch;
     p.satLimit = a->sat_limit;
     p.negPad = a->neg_pad;
-    p.clk = a->clock_probe;
+    p.clk = a->clock_probe; p.tl = a->timeline;
     const int slots = 64 / G;
     const int jobs = (a->num_items + slots - 1) / slots;
     const int maxWpb = opal_max_waves_per_block(a->width);
@@ -482,7 +512,7 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
     p.ovfCount = a->overflow_count; p.ovfItems = a->overflow_items;
     p.chunkRows = a->query_length;
     p.satLimit = a->sat_limit; p.negPad = a->neg_pad;
-    p.clk = a->clock_probe;
+    p.clk = a->clock_probe; p.tl = a->timeline;
     sp.next = next_counter;
     // persistent workgroups: one per CU (16 waves = 4 per SIMD), fewer when there are not enough sequences to go round
     const int perBlock = STREAM_WAVES * (64 / G);

@@ -62,6 +62,15 @@ struct Workspace {
     std::vector<int> Hp, Ep, Hc, Ec;
     std::vector<uint8_t> dirs;
     std::vector<unsigned char> rTarget;
+    // The workspace belongs to a pool thread that never exits: after a call it keeps only modest buffers (one search
+    // with 35 000-residue targets must not leave gigabytes of flag matrices resident for the life of the process).
+    void trim() {
+        constexpr size_t KEEP = 32u << 20;  // bytes of flags kept per thread
+        if (dirs.capacity() > KEEP) std::vector<uint8_t>().swap(dirs);
+        if (rTarget.capacity() > (1u << 20)) std::vector<unsigned char>().swap(rTarget);
+        for (std::vector<int>* v : {&Hp, &Ep, &Hc, &Ec})
+            if (v->capacity() > (1u << 18)) std::vector<int>().swap(*v);
+    }
 };
 
 // `prof` = the query profile of q: prof[letter * profStride + r] = M[q[r]][letter] (built once per call for the whole
@@ -247,6 +256,7 @@ extern "C" int opalx_find_alignments_masked(unsigned char query[], int queryLeng
                 failed.store(1);
             }
         }
+        ws.trim();
     });
     if (failed.load()) {
         fprintf(stderr, "[opal] traceback: out of host memory (a %d-row alignment matrix did not fit)\n", queryLength);

@@ -133,9 +133,6 @@ std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass, int sk
     size_t base = 0;
     for (size_t i = 1; i < cands.size(); i++)
         if (cands[i].eff > cands[base].eff * 1.02) base = i;
-    // one-launch kernels hold the bodies for G0, 2*G0 and 4*G0 lanes per sequence: keep the classes inside that chain
-    if (maxGFactor > 0)
-        while (cands.size() > base + 1 && cands.back().G > maxGFactor * cands[base].G) cands.pop_back();
     // time of the whole range at the base geometry if the machine were perfectly filled
     const double simds = 1024.0;
     const int slotsBase = 64 / cands[base].G;
@@ -143,7 +140,7 @@ std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass, int sk
     const char* budEnv = getenv("OPAL_HIP_TAIL_FRACTION");
     const double budget = std::max(totalClocks * (budEnv && *budEnv ? atof(budEnv) : 0.7), 20000.0);
     // walk from the longest item: the smallest geometry (>= base) whose lone-wave time fits the budget
-    size_t ci = cands.size() - 1;
+    size_t ci = 0;
     int start = first;
     // A class of long sequences is a handful of waves, each the oldest wave of its SIMD and therefore running at the
     // lone-wave rate: that is the time a boundary candidate is judged by. (Round 2, C2 database, 100 000 / 50 000
@@ -154,6 +151,16 @@ std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass, int sk
         const double per = pipeModel ? step_clocks(width, cands[c].rows) : lone_step_clocks(width, cands[c].rows);
         return (len + cands[c].G - 1) * per <= budget;
     };
+    // One-launch kernels hold the bodies for G0, 2*G0 and 4*G0 lanes per sequence: keep the classes inside that chain --
+    // unless the longest sequence would then outlast the whole search. A database with a real tail (Swiss-Prot: 35 213
+    // residues) searched with a short query (G0 = 4: at most 16 lanes) is such a case: 110 aa x 541 762 sequences took 6.9 ms
+    // with the chain against ~3 ms of DP work; the classes then go wider and are launched separately.
+    if (maxGFactor > 0) {
+        size_t keep = cands.size();
+        while (keep > base + 1 && cands[keep - 1].G > maxGFactor * cands[base].G) keep--;
+        const char* uo = getenv("OPAL_HIP_UBER_ONLY");
+        if (keep == cands.size() || fits(keep - 1, lenOf(first)) || (uo && *uo == '1')) cands.resize(keep);
+    }
     auto cls = [&](int s, int n, size_t c) { return LaunchClass{s, n, cands[c].G, cands[c].rows, cands[c].wpb, cands[c].ldsPad}; };
     int i = first;
     while (i < first + count) {

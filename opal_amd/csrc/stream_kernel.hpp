@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     const int padTop = G * S - Q;  // virtual rows above the query (profile 0: H, E, F stay 0 there)
     const int PAD = A, SEP1 = A + 1, SEP2 = A + 2;
     unsigned char* const clkSlot = lds + (size_t)(A + 3) * stride + (size_t)STREAM_WAVES * (64 >> log2G) * STREAM_RING * STREAM_DESC_BYTES;
-    clk_begin(p.clk, clkSlot);
+    clk_begin(p.clk, p.tl, clkSlot);
 
     // ---- stage the profile: QP[letter][k][j]; letters A (beyond a slot's last sequence), A+1, A+2 (separators)
     {
@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
     const int sk = 2 * Ge;  // the skewed diagonal: H'(j,s) = H'(j-1,s-1) + P + 2*Ge
     unsigned char* const initBase = lds + (size_t)(A + 1) * stride;
     unsigned char* const clkSlot = initBase + (size_t)G * INIT * 4 + (size_t)STREAM_WAVES * (64 >> log2G) * STREAM_RING * STREAM_DESC_BYTES;
-    clk_begin(p.clk, clkSlot);
+    clk_begin(p.clk, p.tl, clkSlot);
 
     // ---- stage the profile (+2*Ge) and every lane's boundary block
     {
@@ -619,12 +619,16 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
                     if (lastc) {
                         int bv = INT_MIN, bj = -1;
                         if (jlo == 0 && jhi == S) {
-                            // all my rows are query rows: compare in the skewed frame, moving the running best from the frame of
-                            // row j+1 to that of row j with one subtraction (4 full-rate instructions per row)
+                            // all my rows are query rows: the maximum in the skewed frame, the running best moving from the frame
+                            // of row j+1 to that of row j with one subtraction
                             reg bf = Hp[S - 1];
-                            bj = S - 1;
-                            if constexpr (S > 1) OvColumnScan<V, S, S - 2>::run(Hp, Rv, bf, bj);  // rows S-2 .. 0
+                            if constexpr (S > 1) OvColumnMax<V, S, S - 2>::run(Hp, Rv, bf);  // rows S-2 .. 0: the value, 2 instructions per row
                             bv = V::half(V::subs(bf, sRv), 0);
+                            if (bv > inV) {  // (rare: it beats the lanes above) ... then the smallest row holding it
+                                reg t = V::adds(bf, SR1v);
+                                bj = 0;
+                                OvColumnRow<V, S, S - 1>::run(Hp, Rv, t, bj);
+                            }
                         } else {
 #pragma unroll
                             for (int j = S - 1; j >= 0; j--) {

@@ -46,7 +46,8 @@ for k, cs in counters.items():
         e["effective_clock_ghz_raw"] = round(e["GRBM_GUI_ACTIVE"] / (stats[k]["avg_us"] * 1e3), 3)
     pk[k] = e
 out["per_kernel"] = pk
-steps = 7  # 5 timed + 2 warm-up (+ extras of the bench's `also` leg are separate launches of the same kernels)
+# searches per profiled bench run: 5 timed + 2 warm-up + the 5 of the clock probe (bench.py, after the timed region)
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 12
 valu = sum(e.get("SQ_INSTS_VALU", 0) * stats.get(k, {}).get("calls", 0) for k, e in pk.items())
 calls = {k: stats.get(k, {}).get("calls", 0) for k in pk}
 out["calls"] = calls

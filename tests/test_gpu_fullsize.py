@@ -353,6 +353,37 @@ def test_api_context_reuse_and_multi_device(oracle):
         del os.environ["OPAL_HIP_DEVICES"]
 
 
+def test_multi_gpu_handle_device_side_gather(c2):
+    """opalx_multi_*: one database dealt to several GPUs of one process (here three contexts on this box's one GPU), every
+    shard's result block gathered on the root GPU by peer copies and permuted into database order there -- no result
+    touches the host. All modes, score-only and with end locations, against the single-GPU handle on 40 000 sequences."""
+    import torch
+    from opal_amd.api import PreparedDb, PreparedMultiDb
+    n = 40000
+    res, offs = c2["res"][: c2["offs"][n]], c2["offs"][: n + 1]
+    q, m = c2["q"], c2["m"]
+    one = PreparedDb(res, offs)
+    multi = PreparedMultiDb(res, offs, [0, 0, 0])
+    out = torch.full((3 * n,), -12345, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for mode in ("SW", "NW", "HW", "OV"):
+        for st in (0, 1):
+            rc0, s0, eq0, et0 = one.search(q, 3, 1, m, st, oracle_lib.MODES[mode])
+            out.fill_(-12345)
+            torch.cuda.synchronize()
+            rc, kms = multi.search_device(q, 3, 1, m, st, oracle_lib.MODES[mode], out[:n].data_ptr(), out[n:2 * n].data_ptr() if st else 0,
+                                          out[2 * n:].data_ptr() if st else 0)
+            assert rc == rc0 == 0 and kms > 0
+            got = out.cpu().numpy().reshape(3, n)
+            np.testing.assert_array_equal(got[0], s0, err_msg=f"{mode} st={st} score")
+            if st:
+                np.testing.assert_array_equal(got[1], eq0, err_msg=f"{mode} endQ")
+                np.testing.assert_array_equal(got[2], et0, err_msg=f"{mode} endT")
+            else:
+                assert (got[1:] == -12345).all()
+    multi.close()
+
+
 @pytest.mark.parametrize("mode", ["SW", "NW", "HW", "OV"])
 def test_one_launch_kernels_equal_separate_launches(mode, c2, oracle, monkeypatch):
     """The one-launch ("uber") kernels -- all length classes of a search as ONE grid -- against the same search as
