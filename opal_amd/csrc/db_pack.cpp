@@ -126,6 +126,7 @@ void db_release(OpalxDb* db) {
     for (void*& st : db->streams) { opal_hip_stream_destroy(st); st = nullptr; }
     opal_hip_stream_destroy(db->mainStream); db->mainStream = nullptr;
     opal_hip_stream_destroy(db->copyStream); db->copyStream = nullptr;
+    opal_hip_stream_destroy(db->copyStream2); db->copyStream2 = nullptr;
     opal_hip_stream_destroy(db->auxStream); db->auxStream = nullptr;
     for (void*& ev : db->events) { opal_hip_event_destroy(ev); ev = nullptr; }
     for (void*& ev : db->gate.events) { opal_hip_event_destroy(ev); ev = nullptr; }
@@ -217,8 +218,10 @@ bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::funct
         const size_t i0 = (size_t)gg.cutItem[(size_t)c], i1 = (size_t)gg.cutItem[(size_t)c + 1];
         const uint64_t b0 = off[i0], b1 = i1 < items ? off[i1] : total;
         bool good = true;
-        if (b1 > b0 && opal_hip_memcpy_h2d(db->res.p + b0, h + b0, b1 - b0, db->copyStream)) good = false;
-        if (good && opal_hip_event_record(gg.events[(size_t)c], db->copyStream)) good = false;
+        static const bool two = [] { const char* e = getenv("OPAL_HIP_COPY_STREAMS"); return !(e && *e == '1'); }();
+        void* cs = (two && (c & 1)) ? db->copyStream2 : db->copyStream;
+        if (b1 > b0 && opal_hip_memcpy_h2d(db->res.p + b0, h + b0, b1 - b0, cs)) good = false;
+        if (good && opal_hip_event_record(gg.events[(size_t)c], cs)) good = false;
         gg.state[(size_t)c].store(good ? 1 : -1, std::memory_order_release);
         if (debug_on() && (c == 0 || c + 1 == gg.chunks() || c == gg.chunks() / 2))
             fprintf(stderr, "[opal] fill: chunk %d of %d enqueued %.3f ms after the gather began\n", c, gg.chunks(), now_ms() - db->fillT0);
@@ -252,7 +255,7 @@ bool db_fill_finish(OpalxDb* db) {
         for (int c = 0; c < db->gate.chunks(); c++)
             if (db->gate.state[(size_t)c].load(std::memory_order_acquire) < 0) ok = false;
         if (ok && db->gate.timed && debug_on() && db->gate.chunks() > 0) {  // (debug only: waits for the copies)
-            opal_hip_stream_sync(db->copyStream);
+            opal_hip_stream_sync(db->copyStream); opal_hip_stream_sync(db->copyStream2);
             const int nc = db->gate.chunks();
             for (int c : {0, nc / 4, nc / 2, 3 * nc / 4, nc - 1})
                 fprintf(stderr, "[opal] fill: chunk %d of %d on the device %.3f ms after the gather began\n", c, nc,

@@ -654,6 +654,10 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
             reg f = inF;
             reg h = 0;
             reg cm = 0;  // SW with end location: this column's maximum over my rows
+            // ... kept per HALF of the rows during the row blocks of the plain kernels (which accumulator a row block uses
+            // costs nothing), so that a row scan only visits the first half that holds the column maximum
+            constexpr int NBLK4H = (S + 3) / 4;
+            reg ch[2] = {0, 0};
             if constexpr (PLAIN) {
                 // Plain 16-bit path: one asm statement per block of 4 rows (one ds_read_b128 of profile entries), the
                 // profile read of the next block issued before the current block's arithmetic. Inside a block the
@@ -681,13 +685,14 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
                             constexpr int n = (S - j0) < 4 ? (S - j0) : 4;
                             constexpr bool last = j0 + n == S;
                             const reg* Pn = &Pv[j0 - rb * RB + 1];  // profile of the row BELOW each row
-                            reg& acc = SWEND ? cm : mx;
+                            reg& acc = SWEND ? ch[(j0 / 4) * 2 / NBLK4H] : mx;
                             V::template rows<KIND, n, last>(&Hp[j0], &En[j0], Pn, f, acc, d, t, SKEW ? GQs : Qs, Rs);
                         }
                     });
                     pc = pn;
                 });
                 h = Hp[S - 1];
+                if constexpr (SWEND) cm = V::maxs(ch[0], ch[1]);
             } else {
 #pragma unroll
             for (int rb = 0; rb < SPAD / RB; rb++) {
@@ -751,11 +756,20 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
                 auto scan = [&](int hh) {
                     int r = 0;
                     if constexpr (PLAIN) {
+                        // the first half whose maximum is the column's, then the smallest row in it
                         constexpr int NBLK4 = (S + 3) / 4;
-                        static_for<NBLK4>([&](auto bc) {  // highest block first: the smallest row holding it wins
-                            constexpr int b = NBLK4 - 1 - decltype(bc)::value;
-                            constexpr int n = (S - 4 * b) < 4 ? (S - 4 * b) : 4;
-                            V::template scan_rows<n, 4 * b>(&Hp[4 * b], cm, r);
+                        const int qsel = V::same(ch[0], cm, 0) ? 0 : 1;
+                        static_for<2>([&](auto qc) {
+                            constexpr int qi = decltype(qc)::value;
+                            if (qsel == qi) {
+                                static_for<NBLK4>([&](auto bc) {  // highest block first: the smallest row holding it wins
+                                    constexpr int b = NBLK4 - 1 - decltype(bc)::value;
+                                    if constexpr (b * 2 / NBLK4 == qi) {
+                                        constexpr int n = (S - 4 * b) < 4 ? (S - 4 * b) : 4;
+                                        V::template scan_rows<n, 4 * b>(&Hp[4 * b], cm, r);
+                                    }
+                                });
+                            }
                         });
                     } else {
 #pragma unroll

@@ -194,6 +194,7 @@ struct OpalxDb {
     // `copy` carries the residue chunks of a (re)fill, `aux` every second slice of a search launched while they arrive.
     void* mainStream = nullptr;
     void* copyStream = nullptr;
+    void* copyStream2 = nullptr;  // odd chunks (the per-copy set-up of one overlaps the transfer of the other)
     void* auxStream = nullptr;
     void* streams[3] = {nullptr, nullptr, nullptr};
     void* events[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // 0 fork, 1-3 joins, 4-5 timing, 6 aux join, 7 fill
@@ -203,7 +204,8 @@ struct OpalxDb {
     }
     void* copy() {
         if (!copyStream) copyStream = opal_hip_stream_create();
-        return copyStream;
+        if (!copyStream2) copyStream2 = opal_hip_stream_create();
+        return copyStream && copyStream2 ? copyStream : nullptr;
     }
     void* aux() {
         if (!auxStream) auxStream = opal_hip_stream_create();
@@ -221,6 +223,7 @@ struct OpalxDb {
     void quiesce() {
         for (void* st : streams) if (st) opal_hip_stream_sync(st);
         if (copyStream) opal_hip_stream_sync(copyStream);
+        if (copyStream2) opal_hip_stream_sync(copyStream2);
         if (auxStream) opal_hip_stream_sync(auxStream);
         if (mainStream) opal_hip_stream_sync(mainStream);
     }
