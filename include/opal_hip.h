@@ -257,6 +257,10 @@ long long opalx_stream_launch_count(void);
    [3] class kernels launched one class at a time, [4] row-chunk launches of queries beyond one wave, [5] launches of the
    32-bit rung, [6] alignments traced on the device, [7] alignments traced or started by the host. Returns 8. */
 int opalx_counters(long long* out, int capacity);
+/* Test hook, no device needed: the order the library gives `n` sequences of lengths `lens` (stable, longest first; zero
+   lengths left out; an absent last item when their number is odd: seq -1, len 0). Fills seq / len / off (byte offset in
+   the packed residue buffer), `capacity` entries each. Returns the number of items or -1 if capacity is too small. */
+int opalx_debug_order(const int* lens, int n, int* seq, int* len, unsigned long long* off, int capacity);
 void opalx_db_destroy(OpalxDb* db);
 /* Clock probe for measurements (bench.py): while enabled, every search on this handle also measures the shader clock
    its DP kernels ran at (cycle counter / constant-rate counter over the lifetime of one wave per workgroup) and reads it

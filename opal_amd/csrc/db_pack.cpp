@@ -12,39 +12,44 @@ std::atomic<long long> g_counters[CNT_COUNT];
 // threads (per-thread histograms; a thread places the sequences of its own caller range). Fills db->pairLen / pairSeq /
 // seqOff (item order) and db->emptySeqs. The byte offset of an item follows from its bucket alone: all sequences of a
 // bucket have the same length.
-static bool order_sequences(OpalxDb* db, int n, const int* lens) {
-    db->numSeqs = n;
-    db->emptySeqs.clear();
+namespace {
+struct OrderOut { int* len; int* seq; uint64_t* off; };
+}
+// `alloc(items, out)` provides the three output arrays once the number of items is known.
+static bool order_into(int n, const int* lens, OrderScratch& scratch, std::vector<int>& emptySeqs, int64_t* residues, size_t* itemsOut,
+                       const std::function<bool(size_t, OrderOut&)>& alloc) {
+    emptySeqs.clear();
+    OrderOut out{nullptr, nullptr, nullptr};
     const double to0 = now_ms();
     int maxLen = 0;
     for (int i = 0; i < n; i++) maxLen = std::max(maxLen, lens[i]);
-    const double slack = db->cached ? 1.15 : 1.0;
     if (maxLen > (1 << 22)) {  // (absurd lengths: comparison sort)
+        scratch.pos.clear(); scratch.byte.clear();
         std::vector<int> order;
         for (int i = 0; i < n; i++) {
             if (lens[i] > 0) order.push_back(i);
-            else db->emptySeqs.push_back(i);
+            else emptySeqs.push_back(i);
         }
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lens[a] > lens[b]; });
         const size_t m = order.size(), items = (m + 1) / 2 * 2;
-        if (!db->pairLen.resize(items, slack) || !db->pairSeq.resize(items, slack) || !db->seqOff.resize(items, slack)) return false;
+        if (!alloc(items, out)) return false;
         uint64_t total = 0;
         for (size_t k = 0; k < items; k++) {
             const bool have = k < m;
-            db->pairLen[k] = have ? lens[order[k]] : 0;
-            db->pairSeq[k] = have ? order[k] : -1;
-            db->seqOff[k] = total;
-            total += (uint64_t)db->pairLen[k];
+            out.len[k] = have ? lens[order[k]] : 0;
+            out.seq[k] = have ? order[k] : -1;
+            out.off[k] = total;
+            total += (uint64_t)out.len[k];
         }
-        db->residues = (int64_t)total;
-        db->numPairs = (int)(items / 2);
+        *residues = (int64_t)total;
+        *itemsOut = items;
         return true;
     }
     HostPool& pool = HostPool::get();
     const size_t B = (size_t)maxLen + 1;  // bucket b holds the sequences of length maxLen - b; length 0 is not placed
     int T = n >= (1 << 16) ? std::min(pool.width(), 8) : 1;
     while (T > 1 && (size_t)T * B > (4u << 20)) T /= 2;
-    std::vector<int>& hist = db->ordHist;  // (kept in the context: no fresh pages per call)
+    std::vector<int>& hist = scratch.hist;  // (kept in the context: no fresh pages per call)
     hist.assign((size_t)T * B, 0);
     auto range = [&](int t, int& i0, int& i1) { i0 = (int)((long long)n * t / T); i1 = (int)((long long)n * (t + 1) / T); };
     pool.parallel_for(T, [&](int t) {
@@ -54,8 +59,8 @@ static bool order_sequences(OpalxDb* db, int n, const int* lens) {
     });
     const double to1 = now_ms();
     // bucket starts (item position and byte offset), and where every thread starts inside every bucket
-    std::vector<int>& bucketPos = db->ordPos;
-    std::vector<uint64_t>& bucketByte = db->ordByte;
+    std::vector<int>& bucketPos = scratch.pos;
+    std::vector<uint64_t>& bucketByte = scratch.byte;
     bucketPos.assign(B + 1, 0);
     bucketByte.assign(B + 1, 0);
     int pos = 0;
@@ -68,29 +73,54 @@ static bool order_sequences(OpalxDb* db, int n, const int* lens) {
         if ((int)b == maxLen - 1) break;  // (bucket maxLen = length 0: not placed)
     }
     const int m = pos;
+    bucketPos[(size_t)maxLen] = m; bucketByte[(size_t)maxLen] = byte;  // (end of the last real bucket)
     const size_t items = ((size_t)m + 1) / 2 * 2;
-    if (!db->pairLen.resize(items, slack) || !db->pairSeq.resize(items, slack) || !db->seqOff.resize(items, slack)) return false;
+    if (!alloc(items, out)) return false;
     std::vector<std::vector<int>> empties((size_t)T);
     const double to2 = now_ms();
-    int* const pl = db->pairLen.data(); int* const ps = db->pairSeq.data(); uint64_t* const so = db->seqOff.data();
-    pool.parallel_for(T, [&](int t) {
-        int i0, i1; range(t, i0, i1);
-        int* h = hist.data() + (size_t)t * B;
-        for (int i = i0; i < i1; i++) {
-            const int len = lens[i];
-            if (len <= 0) { empties[(size_t)t].push_back(i); continue; }
-            const size_t b = (size_t)maxLen - len;
-            const int at = h[b]++;
-            pl[at] = len; ps[at] = i;
-            so[at] = bucketByte[b] + (uint64_t)(at - bucketPos[b]) * (uint64_t)len;
+    int* const pl = out.len; int* const ps = out.seq; uint64_t* const so = out.off;
+    // One job, two kinds of tasks: tasks [0, T) place the caller indices (ONE scattered write per sequence); tasks [T, 2T)
+    // fill lengths and byte offsets bucket range by bucket range (sequential writes: every sequence of a bucket has the
+    // same length, so both follow from the bucket table alone).
+    pool.parallel_for(2 * T, [&](int task) {
+        if (task < T) {
+            int i0, i1; range(task, i0, i1);
+            int* h = hist.data() + (size_t)task * B;
+            for (int i = i0; i < i1; i++) {
+                const int len = lens[i];
+                if (len <= 0) { empties[(size_t)task].push_back(i); continue; }
+                ps[h[(size_t)maxLen - len]++] = i;
+            }
+        } else {
+            const int t = task - T;
+            const size_t b0 = (size_t)((long long)maxLen * t / T), b1 = (size_t)((long long)maxLen * (t + 1) / T);  // my buckets
+            for (size_t b = b0; b < b1; b++) {
+                const int len = maxLen - (int)b;
+                uint64_t off = bucketByte[b];
+                for (int at = bucketPos[b], e = bucketPos[b + 1]; at < e; at++) { pl[at] = len; so[at] = off; off += (uint64_t)len; }
+            }
         }
     });
-    for (auto& v : empties) db->emptySeqs.insert(db->emptySeqs.end(), v.begin(), v.end());
+    for (auto& v : empties) emptySeqs.insert(emptySeqs.end(), v.begin(), v.end());
     if (debug_on()) fprintf(stderr, "[opal] order: max + histogram %.3f ms (%d threads), prefix %.3f, placement %.3f\n", to1 - to0, T, to2 - to1, now_ms() - to2);
     if ((size_t)m < items) { pl[m] = 0; ps[m] = -1; so[m] = byte; }
-    db->residues = (int64_t)byte;
-    db->numPairs = (int)(items / 2);
+    *residues = (int64_t)byte;
+    *itemsOut = items;
     return true;
+}
+
+static bool order_sequences(OpalxDb* db, int n, const int* lens) {
+    db->numSeqs = n;
+    const double slack = db->cached ? 1.15 : 1.0;
+    OrderScratch& scratch = db->ordScratch;
+    size_t items = 0;
+    const bool ok = order_into(n, lens, scratch, db->emptySeqs, &db->residues, &items, [&](size_t k, OrderOut& o) {
+        if (!db->pairLen.resize(k, slack) || !db->pairSeq.resize(k, slack) || !db->seqOff.resize(k, slack)) return false;
+        o = OrderOut{db->pairLen.data(), db->pairSeq.data(), db->seqOff.data()};
+        return true;
+    });
+    db->numPairs = (int)(items / 2);
+    return ok;
 }
 
 // The HIP "current device" is a per-thread setting, so the check (and the optional OPAL_HIP_DEVICE
@@ -178,12 +208,58 @@ bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::funct
     g.cutItem.assign(1, 0);
     g.pieceCut.assign(1, 0);
     g.pieceChunk.clear();
-    for (size_t i = 0; i < items; i++) {
-        if (db->seqOff[i] - db->seqOff[(size_t)g.cutItem.back()] >= chunkBytes) { g.cutItem.push_back((int)i); if (g.pieceCut.back() != (int)i) { g.pieceChunk.push_back((int)g.cutItem.size() - 2); g.pieceCut.push_back((int)i); } }
-        else if (db->seqOff[i] - db->seqOff[(size_t)g.pieceCut.back()] >= pieceBytes) { g.pieceChunk.push_back((int)g.cutItem.size() - 1); g.pieceCut.push_back((int)i); }
+    const OrderScratch& sc = db->ordScratch;
+    if (!sc.pos.empty() && sc.pos.size() == sc.byte.size()) {
+        // cuts from the bucket table (all sequences of a bucket have the same length): first item at or behind a byte
+        // offset = a binary search over the buckets and a division, instead of a walk over every item
+        const size_t nb = sc.pos.size() - 1;  // buckets [0, nb): lengths nb - b; pos/byte[nb] = the end
+        auto item_at = [&](uint64_t target) -> int {
+            size_t b = (size_t)(std::upper_bound(sc.byte.begin(), sc.byte.begin() + (long)nb + 1, target) - sc.byte.begin());
+            if (b == 0) return 0;
+            b--;
+            if (b >= nb) return sc.pos[nb];
+            const uint64_t len = (uint64_t)(nb - b);
+            return std::min<int>(sc.pos[b + 1], sc.pos[b] + (int)((target - sc.byte[b] + len - 1) / len));
+        };
+        const int mReal = sc.pos[nb];
+        for (uint64_t cb = 0; cb < total; cb += chunkBytes) {
+            const int c = (int)g.cutItem.size() - 1;
+            const uint64_t ce = std::min<uint64_t>(cb + chunkBytes, total);
+            for (uint64_t pb = cb + pieceBytes; pb < ce; pb += pieceBytes) {
+                const int at = item_at(pb);
+                if (at > g.pieceCut.back() && at < mReal) { g.pieceChunk.push_back(c); g.pieceCut.push_back(at); }
+            }
+            const int at = ce >= total ? (int)items : item_at(ce);
+            if (at > g.pieceCut.back()) { g.pieceChunk.push_back(c); g.pieceCut.push_back(at); }
+            if (at > g.cutItem.back()) g.cutItem.push_back(at);
+            if (at >= (int)items) break;
+        }
+        if (g.cutItem.back() != (int)items) {  // (rounding left a tail: it joins the last chunk)
+            if (g.cutItem.size() > 1) g.cutItem.back() = (int)items; else g.cutItem.push_back((int)items);
+            if (g.pieceCut.back() != (int)items) { g.pieceChunk.push_back((int)g.cutItem.size() - 2); g.pieceCut.push_back((int)items); }
+        }
     }
-    g.cutItem.push_back((int)items);
-    if (g.pieceCut.back() != (int)items) { g.pieceChunk.push_back((int)g.cutItem.size() - 2); g.pieceCut.push_back((int)items); }
+    // (the arithmetic above must give strictly increasing cuts, every piece inside one chunk; otherwise: the plain walk)
+    bool cutsOk = g.cutItem.size() >= 2 && g.cutItem.back() == (int)items && g.pieceCut.size() >= 2 && g.pieceCut.back() == (int)items &&
+                  g.pieceChunk.size() + 1 == g.pieceCut.size();
+    for (size_t c = 0; cutsOk && c + 1 < g.cutItem.size(); c++) cutsOk = g.cutItem[c] < g.cutItem[c + 1];
+    for (size_t q = 0; cutsOk && q + 1 < g.pieceCut.size(); q++) {
+        const int c = g.pieceChunk[q];
+        cutsOk = g.pieceCut[q] < g.pieceCut[q + 1] && c >= 0 && c + 1 < (int)g.cutItem.size() && g.cutItem[(size_t)c] <= g.pieceCut[q] &&
+                 g.pieceCut[q + 1] <= g.cutItem[(size_t)c + 1];
+    }
+    if (!cutsOk) {
+        if (debug_on()) fprintf(stderr, "[opal] fill: chunk cuts from the bucket table rejected, walking the items\n");
+        g.cutItem.assign(1, 0);
+        g.pieceCut.assign(1, 0);
+        g.pieceChunk.clear();
+        for (size_t i = 0; i < items; i++) {
+            if (db->seqOff[i] - db->seqOff[(size_t)g.cutItem.back()] >= chunkBytes) { g.cutItem.push_back((int)i); if (g.pieceCut.back() != (int)i) { g.pieceChunk.push_back((int)g.cutItem.size() - 2); g.pieceCut.push_back((int)i); } }
+            else if (db->seqOff[i] - db->seqOff[(size_t)g.pieceCut.back()] >= pieceBytes) { g.pieceChunk.push_back((int)g.cutItem.size() - 1); g.pieceCut.push_back((int)i); }
+        }
+        g.cutItem.push_back((int)items);
+        if (g.pieceCut.back() != (int)items) { g.pieceChunk.push_back((int)g.cutItem.size() - 2); g.pieceCut.push_back((int)items); }
+    }
     const int nchunks = (int)g.cutItem.size() - 1;
     const int npieces = (int)g.pieceCut.size() - 1;
     if (debug_on() && !g.timed) {  // (debug: timed chunk events, to print when each chunk's copy completed)
@@ -343,6 +419,23 @@ extern "C" void opalx_db_destroy(OpalxDb* db) {
     db->quiesce();
     db_release(db);
     delete db;
+}
+
+// Test hook (no device needed): the ordering of opalx_db_create* / opalSearchDatabase on plain host arrays. Fills
+// seq / len / off (capacity entries each) in item order; returns the number of items (sequences of length > 0, rounded up
+// to even), or -1 if capacity is too small.
+extern "C" int opalx_debug_order(const int* lens, int n, int* seq, int* len, unsigned long long* off, int capacity) {
+    OrderScratch scratch;
+    std::vector<int> empties;
+    int64_t residues = 0;
+    size_t items = 0;
+    bool fits = true;
+    order_into(n, lens, scratch, empties, &residues, &items, [&](size_t k, OrderOut& o) {
+        if (k > (size_t)capacity) { fits = false; return false; }
+        o = OrderOut{len, seq, reinterpret_cast<uint64_t*>(off)};
+        return true;
+    });
+    return fits ? (int)items : -1;
 }
 
 extern "C" long long opalx_stream_launch_count(void) { return g_counters[CNT_STREAM_SW].load() + g_counters[CNT_STREAM_GLOBAL].load(); }

@@ -103,6 +103,9 @@ template <typename T> struct PinVec {
     void release() { buf.release(); n = 0; }
 };
 
+// Scratch of the ordering (db_pack.cpp, order_into): per-thread histograms, bucket starts (item position, byte offset).
+struct OrderScratch { std::vector<int> hist, pos; std::vector<uint64_t> byte; };
+
 // Residues on their way to the device, chunk by chunk, while the search of the sequences that have landed is being
 // launched (opalSearchDatabase: the gather of N host allocations and their upload overlap the search instead of preceding
 // it). Chunk c holds the items [cutItem[c], cutItem[c+1]); a pool thread gathers it into pinned memory, enqueues its copy on
@@ -138,8 +141,7 @@ struct OpalxDb {
     opal_host::PinVec<int> pairSeq;       // [items] caller indices, -1 = absent
     opal_host::PinVec<uint64_t> seqOff;   // [items] start of each sequence in `res`
     std::vector<int> emptySeqs;           // caller indices of zero-length sequences (answered on the host)
-    std::vector<int> ordHist, ordPos;     // scratch of the ordering (order_sequences)
-    std::vector<uint64_t> ordByte;
+    opal_host::OrderScratch ordScratch;   // scratch of the ordering, kept across calls (no fresh pages per call)
     // device: the packed database
     opal_host::DevBuf<unsigned char> res;
     opal_host::DevBuf<uint64_t> dSeqOff;

@@ -202,3 +202,32 @@ def test_traceback_vs_live_reference(mode, oracle):
     np.testing.assert_array_equal(sq, rsq)
     np.testing.assert_array_equal(st, rst)
     assert ops == rops
+
+
+def test_ordering_is_a_stable_sort_by_length():
+    """The packed database's item order (db_pack.cpp, spread over the host pool's threads): stable by length, longest first,
+    zero lengths left out, byte offsets = running sum -- against numpy's stable argsort, on sizes below and above the
+    threshold at which the ordering runs on several threads, with a long tail and with duplicate-heavy lengths."""
+    import ctypes as C
+    from opal_amd import synth
+    L = C.CDLL(LIB)
+    L.opalx_debug_order.restype = C.c_int
+    rng = np.random.RandomState(5)
+    cases = [np.zeros(0, np.int32), np.array([0, 0], np.int32), np.array([7], np.int32),
+             rng.randint(0, 50, 1000).astype(np.int32), synth.lengths(42, 0, 100001, "sprot"),
+             rng.randint(1, 4, 70000).astype(np.int32), np.concatenate([synth.lengths(42, 0, 66000), [0, 0, 35213]]).astype(np.int32)]
+    for lens in cases:
+        n = len(lens)
+        cap = n + 2
+        seq = np.full(cap, -7, np.int32); ln = np.full(cap, -7, np.int32); off = np.zeros(cap, np.uint64)
+        items = L.opalx_debug_order(lens.ctypes.data_as(C.POINTER(C.c_int)), n, seq.ctypes.data_as(C.POINTER(C.c_int)),
+                                    ln.ctypes.data_as(C.POINTER(C.c_int)), off.ctypes.data_as(C.POINTER(C.c_ulonglong)), cap)
+        nz = np.nonzero(lens > 0)[0]
+        want = nz[np.argsort(-lens[nz].astype(np.int64), kind="stable")]
+        m = len(want)
+        assert items == (m + 1) // 2 * 2
+        np.testing.assert_array_equal(seq[:m], want)
+        np.testing.assert_array_equal(ln[:m], lens[want])
+        np.testing.assert_array_equal(off[:m], np.concatenate([[0], np.cumsum(lens[want].astype(np.int64))])[:m].astype(np.uint64))
+        if items > m:
+            assert (seq[m], ln[m], off[m]) == (-1, 0, int(lens[want].astype(np.int64).sum()))
