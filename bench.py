@@ -351,6 +351,7 @@ def main():
     # reading; a buffer is reused two steps later, after waiting on the event recorded behind its last reader.
     outs = [torch.zeros(nres * npad, dtype=torch.int32, device=dev) for _ in range(2 if world > 1 else 1)]
     done = [None, None]
+    done_ev = [torch.cuda.Event(), torch.cuda.Event()] if world > 1 else None  # (reused: no event creation per step)
     # position of every database sequence in the gathered [rank][value][npad] block: ONE index operation per step
     plan = shard.GatherPlan(owned_lists, nres, dev if backend == "nccl" else "cpu", root=rank == 0) if world > 1 else None
     torch.cuda.synchronize()  # (the zero fills above run on torch's stream, the searches on the library's)
@@ -373,7 +374,7 @@ def main():
             # the path's only exchange: ONE gather of the per-sequence result block to rank 0, which puts the
             # blocks back into database order with the deal's permutation (one index_select for all result vectors)
             plan.gather(out if backend == "nccl" else out.cpu(), rank)
-            done[b] = torch.cuda.Event()
+            done[b] = done_ev[b]
             done[b].record()
 
     def fence():
@@ -446,11 +447,10 @@ def main():
 
         instr_per_cell = 9.0 if args.mode == "SW" else 6.0
         peak = valu_peak_gcups(instr_per_cell)
-        # compulsory HBM bytes of THIS design per step: 2-byte tokens (one per pair column), 24 B of pair metadata
-        # per pair, 4 B per result value. The 4*w B/cell of a column-streaming design is kept only as a
+        # compulsory HBM bytes of THIS design per step: one byte per residue, 16 B of metadata per sequence (offset,
+        # length, database index), 4 B per result value. The 4*w B/cell of a column-streaming design is kept only as a
         # labelled comparison: this kernel keeps the DP column in VGPRs and never moves those bytes.
-        sl = np.sort(lens)[::-1].astype(np.int64)
-        alg_bytes = float(2 * sl[0::2].sum() + 24 * ((n + 1) // 2) + 4 * nres * n)
+        alg_bytes = float(lens.astype(np.int64).sum() + 16 * n + 4 * nres * n)
         traffic, traffic_src = None, None
         try:  # HBM bytes per step measured offline with rocprofv3 PMC passes on this same workload (never guessed for another)
             key = (args.workload, args.qlen, total if strong else args.seqs, args.mode, args.search_type, args.gap_open, world)

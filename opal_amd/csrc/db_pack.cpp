@@ -78,7 +78,11 @@ static bool order_into(int n, const int* lens, OrderScratch& scratch, std::vecto
     if (!alloc(items, out)) return false;
     std::vector<std::vector<int>> empties((size_t)T);
     const double to2 = now_ms();
-    int* const pl = out.len; int* const ps = out.seq; uint64_t* const so = out.off;
+    int* const pl = out.len; uint64_t* const so = out.off;
+    // (the scattered writes go to ordinary memory and are copied to the caller's -- pinned -- array in one sweep: scattered
+    // 4-byte stores to pinned memory measured 15 ns each)
+    scratch.seq.resize(items);
+    int* const ps = scratch.seq.data();
     // One job, two kinds of tasks: tasks [0, T) place the caller indices (ONE scattered write per sequence); tasks [T, 2T)
     // fill lengths and byte offsets bucket range by bucket range (sequential writes: every sequence of a bucket has the
     // same length, so both follow from the bucket table alone).
@@ -101,9 +105,11 @@ static bool order_into(int n, const int* lens, OrderScratch& scratch, std::vecto
             }
         }
     });
+    if ((size_t)m < items) ps[m] = -1;
+    memcpy(out.seq, ps, items * sizeof(int));
     for (auto& v : empties) emptySeqs.insert(emptySeqs.end(), v.begin(), v.end());
     if (debug_on()) fprintf(stderr, "[opal] order: max + histogram %.3f ms (%d threads), prefix %.3f, placement %.3f\n", to1 - to0, T, to2 - to1, now_ms() - to2);
-    if ((size_t)m < items) { pl[m] = 0; ps[m] = -1; so[m] = byte; }
+    if ((size_t)m < items) { pl[m] = 0; out.seq[m] = -1; so[m] = byte; }
     *residues = (int64_t)byte;
     *itemsOut = items;
     return true;
@@ -209,10 +215,10 @@ bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::funct
     g.pieceCut.assign(1, 0);
     g.pieceChunk.clear();
     const OrderScratch& sc = db->ordScratch;
-    if (!sc.pos.empty() && sc.pos.size() == sc.byte.size()) {
+    if (sc.pos.size() >= 2 && sc.pos.size() == sc.byte.size()) {
         // cuts from the bucket table (all sequences of a bucket have the same length): first item at or behind a byte
         // offset = a binary search over the buckets and a division, instead of a walk over every item
-        const size_t nb = sc.pos.size() - 1;  // buckets [0, nb): lengths nb - b; pos/byte[nb] = the end
+        const size_t nb = sc.pos.size() - 2;  // buckets [0, nb): lengths nb - b; pos/byte[nb] = the end (the tables hold one spare entry)
         auto item_at = [&](uint64_t target) -> int {
             size_t b = (size_t)(std::upper_bound(sc.byte.begin(), sc.byte.begin() + (long)nb + 1, target) - sc.byte.begin());
             if (b == 0) return 0;

@@ -393,7 +393,10 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
     // NW and OV read the first row block of the NEXT step's profile column at the top of the current step (measured on
     // the C3 workload: NW 1.183 -> 1.117 ms, OV 1.266 -> 1.248 ms; HW and SW gain nothing from it and the 4 extra live
     // registers push their 39/40-row shapes over 128, so they read it at the start of their own step)
-    constexpr bool PF_TOP = PLAIN && (MODE == MODE_NW || (MODE == MODE_OV && S <= 38));
+    // Shapes with FEW rows per lane (S <= 12: the 32- and 64-lane classes of the longest sequences, whose lone waves are the
+    // critical path of a search with a real length tail -- a 35 213-residue target at 2 rows per lane is 35 000 steps of
+    // pure latency) do it in every mode: with so few rows the LDS round trip is most of a step.
+    constexpr bool PF_TOP = PLAIN && (MODE == MODE_NW || (MODE == MODE_OV && S <= 38) || S <= 12);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int log2G = cls.log2G;

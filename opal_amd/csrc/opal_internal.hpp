@@ -104,7 +104,7 @@ template <typename T> struct PinVec {
 };
 
 // Scratch of the ordering (db_pack.cpp, order_into): per-thread histograms, bucket starts (item position, byte offset).
-struct OrderScratch { std::vector<int> hist, pos; std::vector<uint64_t> byte; };
+struct OrderScratch { std::vector<int> hist, pos, seq; std::vector<uint64_t> byte; };
 
 // Residues on their way to the device, chunk by chunk, while the search of the sequences that have landed is being
 // launched (opalSearchDatabase: the gather of N host allocations and their upload overlap the search instead of preceding
