@@ -249,7 +249,12 @@ def cpu_baseline(query, res, offs, matrix, gap_open, gap_ext, mode_code):
 
 def e2e_call(query, res_host, offs, matrix, gap_open, gap_ext, search_type, mode_code, want_scores, calls=6):
     """The call the reference's own timer brackets (opal_aligner.cpp:157-165): opalSearchDatabase with N separate
-    host pointers in and N result structs out, steady clock, best of `calls`. Returns (ms, scores_match)."""
+    host pointers in and N result structs out, steady clock, best of `calls`. Two figures:
+      cold  the context holds ANOTHER database of the same shape before every timed call (every sequence differs in its
+            first residue), so every chunk is gathered, uploaded and searched: the cost of a database seen for the first time;
+      same  the same database again (many queries against one database through the plain API): the library finds its
+            residues unchanged while gathering them and uploads nothing.
+    Returns (cold_ms, same_ms, scores_match)."""
     from opal_amd import _lib
     from opal_amd.api import OpalSearchResult
     L = _lib.lib()
@@ -257,26 +262,40 @@ def e2e_call(query, res_host, offs, matrix, gap_open, gap_ext, search_type, mode
     q = np.ascontiguousarray(query, np.uint8)
     m = np.ascontiguousarray(matrix, np.int32)
     lens = np.ascontiguousarray(np.diff(offs), np.int32)
-    base = res_host.ctypes.data
-    ptrs = np.ascontiguousarray(base + np.asarray(offs[:-1], dtype=np.uint64), dtype=np.uint64)
+    other = res_host.copy()
+    first = np.asarray(offs[:-1], dtype=np.int64)[lens > 0]
+    other[first] = (other[first] + 1) % 20
+
+    def pointers(buf):
+        return np.ascontiguousarray(buf.ctypes.data + np.asarray(offs[:-1], dtype=np.uint64), dtype=np.uint64)
+    ptrs, ptrs_other = pointers(res_host), pointers(other)
     arr = (OpalSearchResult * n)()
     words = np.frombuffer(arr, dtype=np.int32).reshape(n, 10)
     rptrs = np.ascontiguousarray(C.addressof(arr) + 40 * np.arange(n, dtype=np.uint64), dtype=np.uint64)
-    best = None
-    for _ in range(calls):
+
+    def call(p):
         words[:, 0] = 0            # scoreSet = 0 (opalInitSearchResult)
         words[:, 2:6] = -1
         t0 = time.perf_counter()
-        rc = L.opalSearchDatabase(q.ctypes.data_as(C.POINTER(C.c_ubyte)), len(q), C.c_void_p(ptrs.ctypes.data), n,
+        rc = L.opalSearchDatabase(q.ctypes.data_as(C.POINTER(C.c_ubyte)), len(q), C.c_void_p(p.ctypes.data), n,
                                   lens.ctypes.data_as(C.POINTER(C.c_int)), int(gap_open), int(gap_ext),
                                   m.ctypes.data_as(C.POINTER(C.c_int)), int(m.shape[0]), C.c_void_p(rptrs.ctypes.data),
                                   int(search_type), int(mode_code), 1)
         dt = (time.perf_counter() - t0) * 1e3
         if rc != 0:
             raise SystemExit(f"opalSearchDatabase failed rc={rc}")
-        best = dt if best is None else min(best, dt)
-    ok = bool((words[:, 0] == 1).all() and (words[:, 1] == want_scores).all())
-    return best, ok
+        return dt
+    cold, same, ok = None, None, True
+    for _ in range(calls):
+        call(ptrs_other)
+        dt = call(ptrs)
+        cold = dt if cold is None else min(cold, dt)
+        ok = ok and bool((words[:, 0] == 1).all() and (words[:, 1] == want_scores).all())
+    for _ in range(calls):
+        dt = call(ptrs)
+        same = dt if same is None else min(same, dt)
+        ok = ok and bool((words[:, 0] == 1).all() and (words[:, 1] == want_scores).all())
+    return cold, same, ok
 
 
 def main():
@@ -509,9 +528,14 @@ def main():
         res_host = None
         if world == 1 and not args.no_e2e and total <= 1000000:
             res_host = d_res.cpu().numpy()
-            e2e_ms, e2e_ok = e2e_call(query, res_host, offs, matrix, args.gap_open, args.gap_ext, args.search_type, mode, gscore)
+            e2e_ms, same_ms, e2e_ok = e2e_call(query, res_host, offs, matrix, args.gap_open, args.gap_ext, args.search_type, mode, gscore,
+                                               calls=6 if total <= 200000 else 3)
             res_line["e2e"] = {"ms": round(e2e_ms, 3), "gcups": round(cells / (e2e_ms * 1e-3) / 1e9, 1), "scores_match": e2e_ok,
-                               "what": "opalSearchDatabase (host pointers in, result structs out), steady clock, best of 6 calls"}
+                               "same_database_ms": round(same_ms, 3), "same_database_gcups": round(cells / (same_ms * 1e-3) / 1e9, 1),
+                               "what": "opalSearchDatabase (host pointers in, result structs out), steady clock, best of the timed calls. "
+                                       "ms: a database the library has not seen (before every timed call it is given another one of the "
+                                       "same shape); same_database_ms: the same database again (residues compared while gathered, "
+                                       "nothing uploaded)"}
             if not e2e_ok:
                 res_line["verified"] = False
                 status = 3

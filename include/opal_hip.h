@@ -252,10 +252,11 @@ OpalxDb* opalx_db_create_flat_device(const unsigned char* d_residues, const int6
 void opalx_release_cached(void);
 /* Number of searches of this process that ran on the streaming SW kernel (diagnostics and tests). */
 long long opalx_stream_launch_count(void);
-/* What the searches of this process ran on, cumulative (diagnostics and tests). Fills out[0 .. min(capacity, 8)):
+/* What the searches of this process ran on, cumulative (diagnostics and tests). Fills out[0 .. min(capacity, 9)):
    [0] searches on the streaming SW kernels, [1] on the streaming NW/HW/OV kernels, [2] one-launch class kernels,
    [3] class kernels launched one class at a time, [4] row-chunk launches of queries beyond one wave, [5] launches of the
-   32-bit rung, [6] alignments traced on the device, [7] alignments traced or started by the host. Returns 8. */
+   32-bit rung, [6] alignments traced on the device, [7] alignments traced or started by the host, [8] opalSearchDatabase
+   calls that found their database already on the device. Returns 9. */
 int opalx_counters(long long* out, int capacity);
 /* Test hook, no device needed: the order the library gives `n` sequences of lengths `lens` (stable, longest first; zero
    lengths left out; an absent last item when their number is odd: seq -1, len 0). Fills seq / len / off (byte offset in

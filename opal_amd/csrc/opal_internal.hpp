@@ -50,6 +50,7 @@ enum Counter {
     CNT_WIDTH32,         // launches of the 32-bit rung
     CNT_DEVICE_TRACED,   // alignments traced on the device
     CNT_HOST_TRACED,     // alignments traced (or started) by the host
+    CNT_REUSED_FILLS,    // opalSearchDatabase calls that found their database already on the device (same lengths; changed chunks re-uploaded)
     CNT_COUNT
 };
 extern std::atomic<long long> g_counters[CNT_COUNT];
@@ -119,6 +120,9 @@ struct UploadGate {
     std::vector<void*> events;  // (owned by the context: kept across calls)
     std::unique_ptr<std::atomic<int>[]> state;
     std::unique_ptr<std::atomic<int>[]> left;  // pieces of chunk c still being gathered
+    std::unique_ptr<std::atomic<int>[]> dirty; // chunk c must be uploaded (always, unless the device already holds the same bytes)
+    std::atomic<int> uploaded{0};              // chunks copied by this fill
+    bool reuse = false;                        // this fill found the database of the previous call (same lengths)
     size_t stateCap = 0;
     int chunks() const { return active ? (int)cutItem.size() - 1 : 0; }
 };
@@ -141,6 +145,8 @@ struct OpalxDb {
     opal_host::PinVec<int> pairSeq;       // [items] caller indices, -1 = absent
     opal_host::PinVec<uint64_t> seqOff;   // [items] start of each sequence in `res`
     std::vector<int> emptySeqs;           // caller indices of zero-length sequences (answered on the host)
+    std::vector<int> lastLens;            // cached contexts: the lengths of the database the context holds (caller order) ...
+    bool lastValid = false;               // ... if its fill completed: the next call may find the same database again
     opal_host::OrderScratch ordScratch;   // scratch of the ordering, kept across calls (no fresh pages per call)
     // device: the packed database
     opal_host::DevBuf<unsigned char> res;

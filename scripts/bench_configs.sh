@@ -6,7 +6,7 @@ run() {
   python3 bench.py "$@" --no-cpu-baseline --steps 30 --warmup 5 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; e=d.get('e2e')
-print('$*'.ljust(70), 'value', d['value'], 'ms/step', d['ms_per_step'], 'kernel', r['achieved'], 'frac', r['frac'], 'clock', r.get('clock_ghz'), 'frac@clock', r.get('frac_at_measured_clock'), 'verified', d['verified'], ('e2e ms %s gcups %s' % (e['ms'], e['gcups'])) if e else '')"
+print('$*'.ljust(70), 'value', d['value'], 'ms/step', d['ms_per_step'], 'kernel', r['achieved'], 'frac', r['frac'], 'clock', r.get('clock_ghz'), 'frac@clock', r.get('frac_at_measured_clock'), 'verified', d['verified'], ('e2e ms %s (same database again %s)' % (e['ms'], e.get('same_database_ms'))) if e else '')"
 }
 run --workload c2
 run --workload c2 --gap-open 3 --gap-ext 1 --no-e2e

@@ -353,6 +353,55 @@ def test_api_context_reuse_and_multi_device(oracle):
         del os.environ["OPAL_HIP_DEVICES"]
 
 
+def test_same_database_again_uploads_only_what_changed(oracle):
+    """A caller that sends query after query against ONE database through the plain opalSearchDatabase: the cached context
+    recognises the database (same lengths), compares the residues while gathering them and uploads only the chunks that
+    differ. Same database, another query; a few mutated sequences (same lengths); every sequence mutated; a database of
+    other lengths -- every answer must be the oracle's (stale device data would show as wrong scores)."""
+    import ctypes as C
+    import opal_amd
+    from opal_amd import _lib, synth
+    from opal_amd.score_matrix import blosum50
+
+    def reused():
+        buf = (C.c_longlong * 9)()
+        _lib.lib().opalx_counters(buf, 9)
+        return int(buf[8])
+    m = blosum50()[1]
+    n = 30000
+    res, offs, lens = synth.database(n, seed=42, first=200000)
+    db = [res[offs[i]:offs[i + 1]].copy() for i in range(n)]
+    pick = np.arange(0, n, 250)
+
+    def check(q, mode="SW"):
+        rc, results = opal_amd.search_database(q, db, 11, 1, m, opal_amd.OPAL_SEARCH_SCORE_END, opal_amd.MODES[mode])
+        assert rc == 0
+        got = opal_amd.result_fields(results, "score", "endLocationQuery", "endLocationTarget")
+        orc, so, oq, ot = oracle.search(q, [db[i] for i in pick], 11, 1, m, 1, opal_amd.MODES[mode])
+        np.testing.assert_array_equal(got[0][pick], so)
+        np.testing.assert_array_equal(got[1][pick], oq)
+        np.testing.assert_array_equal(got[2][pick], ot)
+        return got
+    q1, q2 = synth.query(150, seed=7), synth.query(220, seed=8)
+    r0 = reused()
+    check(q1)                      # first sight: full fill
+    assert reused() == r0
+    check(q2)                      # same database, another query
+    check(q1, "NW")
+    assert reused() == r0 + 2
+    for i in (0, 250, 7750, 29750):   # a few sequences change (same lengths): their chunks go up again
+        db[i][:] = synth._residues(99 + i, 0, len(db[i]))
+    check(q1)
+    assert reused() == r0 + 3
+    for i in range(n):                # everything changes
+        db[i][0] = (db[i][0] + 1) % 20
+    check(q2)
+    assert reused() == r0 + 4
+    db[5] = db[5][:-1].copy()         # another length: a different database
+    check(q2)
+    assert reused() == r0 + 4
+
+
 def test_multi_gpu_handle_device_side_gather(c2):
     """opalx_multi_*: one database dealt to several GPUs of one process (here three contexts on this box's one GPU), every
     shard's result block gathered on the root GPU by peer copies and permuted into database order there -- no result
