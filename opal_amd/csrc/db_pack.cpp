@@ -342,6 +342,9 @@ bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::funct
     db->fillT0 = now_ms();
     if (debug_on()) fprintf(stderr, "[opal] fill: %s %.3f ms, metadata + chunk plan %.3f ms, %d chunks of ~%.1f MB in %d pieces\n", reuse ? "same lengths as the last call (order kept):" : "order", tf1 - tf0, db->fillT0 - tf1, nchunks, (double)chunkBytes / 1048576.0, npieces);
     if (async) {
+        // A database found again is searched SPECULATIVELY: the launches do not wait for the comparison (no gate), the
+        // caller repeats the search if db_fill_finish reports that a chunk had changed after all (fill_changed()).
+        if (reuse && !getenv("OPAL_HIP_NO_SPECULATION")) g.active = false;
         pool.begin(npieces, db->gatherFn);
         db->gatherPending = true;
         return true;
@@ -380,6 +383,8 @@ bool db_fill_finish(OpalxDb* db) {
     db->gate.active = false;
     return ok;
 }
+
+bool fill_changed(const OpalxDb* db) { return db->gate.reuse && db->gate.uploaded.load() > 0; }
 
 bool gate_items(OpalxDb* db, void* stream, int firstItem, int count) {
     UploadGate& g = db->gate;

@@ -63,6 +63,15 @@ static int run_shard(int device, const unsigned char* query, int Q, unsigned cha
                          /*finalSync=*/false);
     const double t2b = now_ms();
     if (!db_fill_finish(pdb)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (fill_changed(pdb)) {
+        // the database looked like the previous call's (same lengths) and was searched before its residues had been
+        // compared; some differ: they are on the device by now (after the copy streams), the search is done again
+        pdb->quiesce();
+        if (debug_on()) fprintf(stderr, "[opal] shard: the database had changed under the same lengths: searching again\n");
+        if (opal_hip_memset32(dS, INT_MIN, nn, st) || (wantEnd && opal_hip_memset32(dQ, -1, 2 * nn, st))) return OPAL_ERR_NO_SIMD_SUPPORT;
+        rc = search_core(pdb, query, Q, Go, Ge, M, A, searchType, mode, dS, wantEnd ? dQ : nullptr, wantEnd ? dT : nullptr, nullptr,
+                         /*finalSync=*/false);
+    }
     const double t3 = now_ms();
     if (debug_on()) fprintf(stderr, "[opal] shard: launches issued %.3f ms after the fill began, pool done at %.3f ms\n", t2b - t1, t3 - t1);
     if (rc == OPAL_ERR_NO_SIMD_SUPPORT || rc == OPAL_ERR_INVALID_MODE) return rc;

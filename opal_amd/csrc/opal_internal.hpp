@@ -255,6 +255,9 @@ enum RawKind { RAW_POINTERS, RAW_DEVICE_FLAT };
 bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::function<const unsigned char*(int)>& getSeq,
              const unsigned char* flatDevice, const std::function<uint64_t(int)>& flatOff, bool async = false);
 bool db_fill_finish(OpalxDb* db);  // waits for the pool; false if a chunk failed
+// After db_fill_finish: the fill had recognised the previous call's database, searched it without waiting for the
+// comparison, and some chunk turned out to differ (it has been uploaded since): the search must be repeated.
+bool fill_changed(const OpalxDb* db);
 // Make `stream` wait for the residues of items [firstItem, firstItem + count) (host-waits until their chunks have been
 // enqueued, then one hipStreamWaitEvent per chunk). No-op without an active gate. False if a chunk failed.
 bool gate_items(OpalxDb* db, void* stream, int firstItem, int count);
