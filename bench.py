@@ -250,8 +250,8 @@ def cpu_baseline(query, res, offs, matrix, gap_open, gap_ext, mode_code):
 def e2e_call(query, res_host, offs, matrix, gap_open, gap_ext, search_type, mode_code, want_scores, calls=6):
     """The call the reference's own timer brackets (opal_aligner.cpp:157-165): opalSearchDatabase with N separate
     host pointers in and N result structs out, steady clock, best of `calls`. Two figures:
-      cold  the context holds ANOTHER database of the same shape before every timed call (every sequence differs in its
-            first residue), so every chunk is gathered, uploaded and searched: the cost of a database seen for the first time;
+      cold  the context holds ANOTHER database before every timed call (the same sequences in another order), so the
+            timed call orders, gathers, uploads and searches from scratch: the cost of a database seen for the first time;
       same  the same database again (many queries against one database through the plain API): the library finds its
             residues unchanged while gathering them and uploads nothing.
     Returns (cold_ms, same_ms, scores_match)."""
@@ -262,23 +262,22 @@ def e2e_call(query, res_host, offs, matrix, gap_open, gap_ext, search_type, mode
     q = np.ascontiguousarray(query, np.uint8)
     m = np.ascontiguousarray(matrix, np.int32)
     lens = np.ascontiguousarray(np.diff(offs), np.int32)
-    other = res_host.copy()
-    first = np.asarray(offs[:-1], dtype=np.int64)[lens > 0]
-    other[first] = (other[first] + 1) % 20
-
-    def pointers(buf):
-        return np.ascontiguousarray(buf.ctypes.data + np.asarray(offs[:-1], dtype=np.uint64), dtype=np.uint64)
-    ptrs, ptrs_other = pointers(res_host), pointers(other)
+    # "another database": the same sequences handed over in another order (rotated by one), so that its lengths differ
+    # position by position and the library must order, gather, upload and search from scratch, as for any new database
+    base = res_host.ctypes.data + np.asarray(offs[:-1], dtype=np.uint64)
+    ptrs = np.ascontiguousarray(base, dtype=np.uint64)
+    ptrs_other = np.ascontiguousarray(np.roll(base, 1), dtype=np.uint64)
+    lens_other = np.ascontiguousarray(np.roll(lens, 1), np.int32)
     arr = (OpalSearchResult * n)()
     words = np.frombuffer(arr, dtype=np.int32).reshape(n, 10)
     rptrs = np.ascontiguousarray(C.addressof(arr) + 40 * np.arange(n, dtype=np.uint64), dtype=np.uint64)
 
-    def call(p):
+    def call(p, ln=lens):
         words[:, 0] = 0            # scoreSet = 0 (opalInitSearchResult)
         words[:, 2:6] = -1
         t0 = time.perf_counter()
         rc = L.opalSearchDatabase(q.ctypes.data_as(C.POINTER(C.c_ubyte)), len(q), C.c_void_p(p.ctypes.data), n,
-                                  lens.ctypes.data_as(C.POINTER(C.c_int)), int(gap_open), int(gap_ext),
+                                  ln.ctypes.data_as(C.POINTER(C.c_int)), int(gap_open), int(gap_ext),
                                   m.ctypes.data_as(C.POINTER(C.c_int)), int(m.shape[0]), C.c_void_p(rptrs.ctypes.data),
                                   int(search_type), int(mode_code), 1)
         dt = (time.perf_counter() - t0) * 1e3
@@ -287,7 +286,7 @@ def e2e_call(query, res_host, offs, matrix, gap_open, gap_ext, search_type, mode
         return dt
     cold, same, ok = None, None, True
     for _ in range(calls):
-        call(ptrs_other)
+        call(ptrs_other, lens_other)
         dt = call(ptrs)
         cold = dt if cold is None else min(cold, dt)
         ok = ok and bool((words[:, 0] == 1).all() and (words[:, 1] == want_scores).all())

@@ -344,7 +344,9 @@ bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::funct
     if (async) {
         // A database found again is searched SPECULATIVELY: the launches do not wait for the comparison (no gate), the
         // caller repeats the search if db_fill_finish reports that a chunk had changed after all (fill_changed()).
-        if (reuse && !getenv("OPAL_HIP_NO_SPECULATION")) g.active = false;
+        // (Not right after a call that was caught out: a caller that edits its database in place pays the repeated search once.)
+        if (reuse && db->speculate && !getenv("OPAL_HIP_NO_SPECULATION")) g.active = false;
+        g.speculated = !g.active;
         pool.begin(npieces, db->gatherFn);
         db->gatherPending = true;
         return true;
@@ -369,6 +371,7 @@ bool db_fill_finish(OpalxDb* db) {
         for (int c = 0; c < db->gate.chunks(); c++)
             if (db->gate.state[(size_t)c].load(std::memory_order_acquire) < 0) ok = false;
         db->lastValid = ok && db->cached;
+        db->speculate = !(db->gate.reuse && db->gate.uploaded.load() > 0);  // (the database was edited under the same lengths: the next call waits for its comparison)
         if (debug_on()) fprintf(stderr, "[opal] fill: %d of %d chunks uploaded%s\n", db->gate.uploaded.load(), db->gate.chunks(), db->gate.reuse ? " (the others unchanged since the last call)" : "");
         if (db->gate.reuse) count(CNT_REUSED_FILLS);
         if (ok && db->gate.timed && debug_on() && db->gate.chunks() > 0 && !db->gate.reuse) {  // (debug only: waits for the copies)
@@ -384,7 +387,7 @@ bool db_fill_finish(OpalxDb* db) {
     return ok;
 }
 
-bool fill_changed(const OpalxDb* db) { return db->gate.reuse && db->gate.uploaded.load() > 0; }
+bool fill_changed(const OpalxDb* db) { return db->gate.reuse && db->gate.speculated && db->gate.uploaded.load() > 0; }
 
 bool gate_items(OpalxDb* db, void* stream, int firstItem, int count) {
     UploadGate& g = db->gate;

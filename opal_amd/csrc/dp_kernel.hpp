@@ -669,19 +669,13 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
                 constexpr int NBLK = SPAD / RB;   // LDS reads per column (RB rows each: 4 with 4-byte entries, 8 with 2-byte ones)
                 int4 pc = pcur;
                 if constexpr (!PF_TOP) pc = lds_ld16(offc[0]);
-                // (the skewed NW / HW kernels spend 6 instructions per cell: 24 per row block do not cover an LDS round trip
-                // with bank conflicts, so they keep TWO row blocks of profile entries in flight; 4 more registers)
-                constexpr bool DEEP = SKEW && MODE != MODE_OV && NBLK > 2;
-                int4 pahead = pc;
-                if constexpr (DEEP) pahead = lds_ld16(offc[0] + 1 * RB * ES);
                 reg d = V::adds(diag, (reg)pc.x), t = 0;  // (a 16-bit add reads the low half only)
+                // (two row blocks of profile entries in flight instead of one were tried for the 6-instruction kernels in
+                // round 3: NW unchanged, HW 2.8 % slower)
                 static_for<NBLK>([&](auto rbc) {
                     constexpr int rb = decltype(rbc)::value;
                     int4 pn = pc;
-                    if constexpr (DEEP) {
-                        pn = pahead;
-                        if constexpr (rb + 2 < NBLK) pahead = lds_ld16(offc[0] + (rb + 2) * RB * ES);
-                    } else if constexpr (rb + 1 < NBLK) pn = lds_ld16(offc[0] + (rb + 1) * RB * ES);
+                    if constexpr (rb + 1 < NBLK) pn = lds_ld16(offc[0] + (rb + 1) * RB * ES);
                     reg Pv[RB + 1];  // profile values of this block's rows, then of the next block's first row
                     if constexpr (ES == 4) {
                         Pv[0] = (reg)pc.x; Pv[1] = (reg)pc.y; Pv[2] = (reg)pc.z; Pv[3] = (reg)pc.w;

@@ -213,6 +213,16 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
             if (cut.size() == 1 && classes.size() > 1) at = std::max(at, bulk.first);  // every long class inside the first slice
             if (at > cut.back() && at < firstItem + numItems) cut.push_back(at);
         }
+        // a database of many chunks (hundreds of MB: the copy takes as long as the search) goes on in slices of a sixth of
+        // the chunks, none smaller than two resident rounds (65 536 sequences)
+        if (!getenv("OPAL_HIP_SLICES") && g.chunks() > 24) {
+            const int group = std::max(5, g.chunks() / 6);
+            while (chunk + group < g.chunks()) {
+                chunk += group;
+                const int at = g.cutItem[(size_t)chunk];
+                if (at - cut.back() >= 65536 && firstItem + numItems - at >= 65536) cut.push_back(at);
+            }
+        }
         cut.push_back(firstItem + numItems);
         void* fork = db->event(0);
         void* aux = db->aux();
@@ -439,6 +449,13 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
     // SW score-only searches with long queries stream their sequences through persistent waves (plain 16-bit arithmetic)
     StreamPlan splan;
     if (mode == OPAL_MODE_SW && fits16) splan = plan_stream(Q, A, mode, wantEnd, db->residues, db->pairLen.empty() ? 0 : db->pairLen[0], db->numSeqs);
+    // While the database is still arriving (opalSearchDatabase) a streaming launch would have to wait for the last chunk: at 16
+    // lanes per sequence or fewer, where streaming gains 2-4 % over the class kernels, the sliced class launches that start
+    // on the first chunks are the better trade (C4 shard: the copy of 218 MB takes a third of the call).
+    if (splan.G && splan.G <= 16 && db->gate.active && db->gate.chunks() >= 4 && narrow == 17 && !getenv("OPAL_HIP_NO_SLICES")) {
+        const char* en = getenv("OPAL_HIP_STREAM");
+        if (!(en && *en == '1')) splan = StreamPlan();
+    }
     const bool plain = narrow != 16 || splan.G;
     const int satLimit = plain ? (int)(32767 - maxS) : 32767;
     SearchCtx c{db, Q, A, Go, Ge, mode, wantEnd, dScore, dEndQ, dEndT, satLimit, mode == OPAL_MODE_SW ? -satLimit : 0, maxS};

@@ -123,6 +123,7 @@ struct UploadGate {
     std::unique_ptr<std::atomic<int>[]> dirty; // chunk c must be uploaded (always, unless the device already holds the same bytes)
     std::atomic<int> uploaded{0};              // chunks copied by this fill
     bool reuse = false;                        // this fill found the database of the previous call (same lengths)
+    bool speculated = false;                   // ... and its search was launched without waiting for the comparison
     size_t stateCap = 0;
     int chunks() const { return active ? (int)cutItem.size() - 1 : 0; }
 };
@@ -147,6 +148,7 @@ struct OpalxDb {
     std::vector<int> emptySeqs;           // caller indices of zero-length sequences (answered on the host)
     std::vector<int> lastLens;            // cached contexts: the lengths of the database the context holds (caller order) ...
     bool lastValid = false;               // ... if its fill completed: the next call may find the same database again
+    bool speculate = true;                // search a re-seen database before its residues have been compared (db_fill)
     opal_host::OrderScratch ordScratch;   // scratch of the ordering, kept across calls (no fresh pages per call)
     // device: the packed database
     opal_host::DevBuf<unsigned char> res;

@@ -18,9 +18,9 @@ arr = (OpalSearchResult * n)()
 words = np.frombuffer(arr, dtype=np.int32).reshape(n, 10)
 rptrs = np.ascontiguousarray(C.addressof(arr) + 40 * np.arange(n, dtype=np.uint64), dtype=np.uint64)
 cells = float(qlen) * float(offs[-1])
-other = res.copy(); other[offs[:-1]] = (other[offs[:-1]] + 1) % 20   # the same shape, every sequence different
-ptrs_other = np.ascontiguousarray(other.ctypes.data + np.asarray(offs[:-1], dtype=np.uint64), dtype=np.uint64)
-def call(p, st):
+ptrs_other = np.ascontiguousarray(np.roll(ptrs, 1))   # another database: the same sequences in another order (other lengths per position)
+ln_other = np.ascontiguousarray(np.roll(ln, 1))
+def call(p, st, ln=ln):
     words[:, 0] = 0; words[:, 2:6] = -1
     t0 = time.perf_counter()
     rc = L.opalSearchDatabase(q.ctypes.data_as(C.POINTER(C.c_ubyte)), qlen, C.c_void_p(p.ctypes.data), n,
@@ -31,7 +31,7 @@ def call(p, st):
 for st in (0, 1):
     cold, same = [], []
     for it in range(12):
-        call(ptrs_other, st)          # (untimed) the context now holds another database
+        call(ptrs_other, st, ln_other)   # (untimed) the context now holds another database
         cold.append(call(ptrs, st))   # every chunk gathered, uploaded, searched
     crc = int(words[:, 1].astype(np.int64).sum())
     for it in range(12):
