@@ -106,7 +106,7 @@ static bool order_into(int n, const int* lens, OrderScratch& scratch, std::vecto
         }
     });
     if ((size_t)m < items) ps[m] = -1;
-    memcpy(out.seq, ps, items * sizeof(int));
+    if (items) memcpy(out.seq, ps, items * sizeof(int));
     for (auto& v : empties) emptySeqs.insert(emptySeqs.end(), v.begin(), v.end());
     if (debug_on()) fprintf(stderr, "[opal] order: max + histogram %.3f ms (%d threads), prefix %.3f, placement %.3f\n", to1 - to0, T, to2 - to1, now_ms() - to2);
     if ((size_t)m < items) { pl[m] = 0; out.seq[m] = -1; so[m] = byte; }

@@ -1,7 +1,8 @@
 #!/bin/bash
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r3m
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r3n
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-for i in 1 2 3; do python3 bench.py --workload sprot --no-e2e --no-cpu-baseline | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('sprot', d['value'], d['roofline']['kernel_ms'], {k:v['gpu_kernel_ms'] for k,v in d['published_shape'].items()})"; done > $OUT/sprot3.txt 2>&1
-for m in NW HW NW HW; do python3 bench.py --workload c3 --mode $m --no-e2e --no-cpu-baseline --steps 50 --warmup 5 | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$m', d['value'], d['roofline']['kernel_ms'])"; done > $OUT/c3.txt 2>&1
-OPAL_HIP_DEBUG=1 python3 bench.py --workload sprot --no-e2e --no-cpu-baseline --steps 2 --warmup 1 2>&1 | grep "launch\|streaming" | head -8 > $OUT/sprot_plan.txt
+python3 scripts/gpu_api_e2e.py > $OUT/e2e.txt 2>&1
+NSEQ=625000 QLEN=513 python3 scripts/gpu_api_e2e.py > $OUT/e2e_625k.txt 2>&1
+python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > $OUT/pytest_gpu.log
+for w in "--workload c2" "--workload c4 --total-seqs 625000" "--workload c5 --total-seqs 100000"; do python3 bench.py $w --no-cpu-baseline --steps 10 --warmup 2 | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$w', d['value'], d['roofline']['kernel_ms'], d['e2e'])"; done > $OUT/bench_e2e.txt 2>&1

@@ -12,7 +12,7 @@ import oracle_lib
 from oracle_lib import MODES, OpalSearchResult
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "opal_amd", "csrc", "libopal.so")
+LIB = os.environ.get("OPAL_LIB_PATH") or os.path.join(ROOT, "opal_amd", "csrc", "libopal.so")
 
 pytestmark = pytest.mark.skipif(not os.path.exists(LIB), reason="libopal.so not built (run __graft_entry__.build())")
 
@@ -231,3 +231,22 @@ def test_ordering_is_a_stable_sort_by_length():
         np.testing.assert_array_equal(off[:m], np.concatenate([[0], np.cumsum(lens[want].astype(np.int64))])[:m].astype(np.uint64))
         if items > m:
             assert (seq[m], ln[m], off[m]) == (-1, 0, int(lens[want].astype(np.int64).sum()))
+
+
+def test_host_code_sanitized():
+    """The host translation units rebuilt with UndefinedBehaviorSanitizer (opal_amd/csrc/Makefile: libopal_ubsan.so) run
+    this module's tests -- API rules, ordering on several threads, the thread pool, the host traceback against the
+    reference's alignments -- in a child process; any undefined behaviour aborts it."""
+    import subprocess
+    import sys
+    if os.environ.get("OPAL_LIB_PATH"):
+        pytest.skip("already running against an alternative library")
+    csrc = os.path.join(ROOT, "opal_amd", "csrc")
+    try:
+        subprocess.check_call(["make", "-s", "-j", "4", "-C", csrc, "libopal_ubsan.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError):
+        pytest.skip("sanitized build not available here")
+    env = dict(os.environ, OPAL_LIB_PATH=os.path.join(csrc, "libopal_ubsan.so"))
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", "not sanitized"], env=env,
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
