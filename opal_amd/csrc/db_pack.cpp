@@ -47,7 +47,10 @@ static bool order_into(int n, const int* lens, OrderScratch& scratch, std::vecto
     }
     HostPool& pool = HostPool::get();
     const size_t B = (size_t)maxLen + 1;  // bucket b holds the sequences of length maxLen - b; length 0 is not placed
-    int T = n >= (1 << 16) ? std::min(pool.width(), 8) : 1;
+    // (measured on the GPU box's host, 100 000 / 625 000 sequences: 1 thread 0.235 / 1.46 ms, 4 threads 0.26 / 0.83 median --
+    // a job of the pool costs ~0.1 ms in wake-ups, so only large databases are worth spreading)
+    int T = n >= 400000 ? std::min(pool.width(), 4) : 1;
+    if (const char* e = getenv("OPAL_ORDER_THREADS")) { const int v = atoi(e); if (v >= 1) T = std::min(v, pool.width()); }  // tuning hook
     while (T > 1 && (size_t)T * B > (4u << 20)) T /= 2;
     std::vector<int>& hist = scratch.hist;  // (kept in the context: no fresh pages per call)
     hist.assign((size_t)T * B, 0);

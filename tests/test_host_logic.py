@@ -215,7 +215,8 @@ def test_ordering_is_a_stable_sort_by_length():
     rng = np.random.RandomState(5)
     cases = [np.zeros(0, np.int32), np.array([0, 0], np.int32), np.array([7], np.int32),
              rng.randint(0, 50, 1000).astype(np.int32), synth.lengths(42, 0, 100001, "sprot"),
-             rng.randint(1, 4, 70000).astype(np.int32), np.concatenate([synth.lengths(42, 0, 66000), [0, 0, 35213]]).astype(np.int32)]
+             rng.randint(1, 4, 70000).astype(np.int32), np.concatenate([synth.lengths(42, 0, 66000), [0, 0, 35213]]).astype(np.int32),
+             np.concatenate([synth.lengths(42, 0, 450000, "sprot"), [0, 17]]).astype(np.int32)]  # (>= 400 000: several threads)
     for lens in cases:
         n = len(lens)
         cap = n + 2
