@@ -176,6 +176,8 @@ bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::funct
              const unsigned char* flatDevice, const std::function<uint64_t(int)>& flatOff, bool async) {
     db->device = opal_hip_get_device();
     db->gate.active = false;
+    db->gate.speculated = false;
+    db->gate.reuse = false;
     db->tokensValid = false;
     const double tf0 = now_ms();
     // The SAME database as last time? (A caller that sends many queries against one database through the plain

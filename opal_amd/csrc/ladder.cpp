@@ -227,9 +227,11 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
         void* fork = db->event(0);
         void* aux = db->aux();
         void* side = db->stream(0);
-        if (!fork || !aux || !side || !db->stream(1) || !db->stream(2) || opal_hip_event_record(fork, db->main()) ||
-            opal_hip_stream_wait_event(aux, fork) || opal_hip_stream_wait_event(side, fork) || opal_hip_stream_wait_event(db->stream(1), fork) ||
-            opal_hip_stream_wait_event(db->stream(2), fork))
+        static const int how = [] { const char* e = getenv("OPAL_HIP_SLICE_STREAMS"); return !e ? 1 : !strcmp(e, "serial") ? 0 : !strcmp(e, "separate") ? 2 : 1; }();
+        if (!fork || !aux || !side || opal_hip_event_record(fork, db->main()) || opal_hip_stream_wait_event(aux, fork) ||
+            opal_hip_stream_wait_event(side, fork))
+            return OPAL_ERR_NO_SIMD_SUPPORT;
+        if (how == 2 && (!db->stream(1) || !db->stream(2) || opal_hip_stream_wait_event(db->stream(1), fork) || opal_hip_stream_wait_event(db->stream(2), fork)))
             return OPAL_ERR_NO_SIMD_SUPPORT;
         int err = 0;
         bool auxUsed = false;
@@ -240,7 +242,6 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
             // starts while the previous one drains), all on `main` ("serial": 0.3 ms slower on C2 -- a slice smaller than one
             // resident round, 32 000 sequences, leaves every SIMD with one or two waves), or main, aux, side streams 1 and 2
             // ("separate": no better than alternate)
-            static const int how = [] { const char* e = getenv("OPAL_HIP_SLICE_STREAMS"); return !e ? 1 : !strcmp(e, "serial") ? 0 : !strcmp(e, "separate") ? 2 : 1; }();
             void* stream = j == 0 ? side : db->main();
             if (j > 0 && how == 1) stream = (j & 1) ? db->main() : aux;
             if (j > 0 && how == 2) stream = j == 1 ? db->main() : j == 2 ? aux : db->stream(1 + (int)(j & 1));
@@ -263,7 +264,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
             if (!join || opal_hip_event_record(join, side) || opal_hip_stream_wait_event(db->main(), join)) err = 1;
         }
         if (!err && auxUsed)  // (whichever of them were used: joining an idle stream costs nothing)
-            for (int q = 0; q < 3 && !err; q++) {
+            for (int q = 0; q < (how == 2 ? 3 : 1) && !err; q++) {
                 void* other = q == 0 ? aux : db->stream(q);
                 void* join = db->event(q == 0 ? 6 : 1 + q);
                 if (!other || !join || opal_hip_event_record(join, other) || opal_hip_stream_wait_event(db->main(), join)) err = 1;
