@@ -262,6 +262,9 @@ int opalx_counters(long long* out, int capacity);
    lengths left out; an absent last item when their number is odd: seq -1, len 0). Fills seq / len / off (byte offset in
    the packed residue buffer), `capacity` entries each. Returns the number of items or -1 if capacity is too small. */
 int opalx_debug_order(const int* lens, int n, int* seq, int* len, unsigned long long* off, int capacity);
+/* Test hook, no device needed: stress of the library's host thread pool (`rounds` jobs of 1..300 tasks, synchronous and
+   asynchronous in turn, from `callers` threads at once). 0 if every task of every job ran exactly once. */
+int opalx_debug_pool_selftest(int rounds, int callers);
 void opalx_db_destroy(OpalxDb* db);
 /* Clock probe for measurements (bench.py): while enabled, every search on this handle also measures the shader clock
    its DP kernels ran at (cycle counter / constant-rate counter over the lifetime of one wave per workgroup) and reads it

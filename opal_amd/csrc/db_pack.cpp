@@ -489,6 +489,33 @@ extern "C" int opalx_debug_order(const int* lens, int n, int* seq, int* len, uns
     return fits ? (int)items : -1;
 }
 
+// Test hook (no device needed): a stress of the host thread pool -- jobs of 1..300 tasks, synchronous and begin/end in
+// turn, every task adds its index+1 to a sum; from `callers` threads at once when callers > 1 (submissions queue up).
+// Returns 0 if every task of every job ran exactly once.
+extern "C" int opalx_debug_pool_selftest(int rounds, int callers) {
+    std::atomic<long long> sum{0};
+    long long want = 0;
+    for (int rep = 0; rep < rounds; rep++) { const long long k = 1 + rep % 300; want += k * (k + 1) / 2; }
+    auto work = [&] {
+        HostPool& p = HostPool::get();
+        for (int rep = 0; rep < rounds; rep++) {
+            const int k = 1 + rep % 300;
+            std::vector<std::atomic<int>> hit((size_t)k);
+            for (auto& h : hit) h.store(0);
+            std::function<void(int)> fn = [&](int t) { hit[(size_t)t].fetch_add(1); sum.fetch_add(t + 1); };
+            if (rep % 3 == 0) { p.begin(k, fn); p.end(); } else p.parallel_for(k, fn);
+            for (auto& h : hit) if (h.load() != 1) sum.fetch_add(1LL << 40);  // a task ran twice or not at all
+        }
+    };
+    if (callers <= 1) work();
+    else {
+        std::vector<std::thread> th;
+        for (int c = 0; c < callers; c++) th.emplace_back(work);
+        for (auto& t : th) t.join();
+    }
+    return sum.load() == want * std::max(callers, 1) ? 0 : 1;
+}
+
 extern "C" long long opalx_stream_launch_count(void) { return g_counters[CNT_STREAM_SW].load() + g_counters[CNT_STREAM_GLOBAL].load(); }
 
 extern "C" int opalx_counters(long long* out, int capacity) {

@@ -402,6 +402,59 @@ def test_same_database_again_uploads_only_what_changed(oracle):
     assert reused() == r0 + 4
 
 
+def test_same_lengths_different_residues_across_threads_and_alignment(oracle):
+    """The nasty corner of the database recognition: databases with IDENTICAL lengths and DIFFERENT residues, searched from
+    three host threads that keep exchanging cached contexts -- every call finds "the same database" by its lengths,
+    searches speculatively and must notice that the residues are another database's. Plus OPAL_SEARCH_ALIGNMENT twice on
+    one database (start cells, operation strings identical the second time)."""
+    import threading
+    import opal_amd
+    from opal_amd import synth
+    from opal_amd.score_matrix import blosum50
+    m = blosum50()[1]
+    n = 8000
+    _, offs, lens = synth.database(n, seed=42, first=300000)
+    dbs = []
+    for t in range(3):  # same lengths, residues from different streams
+        flat = synth._residues(1000 + t, 0, int(offs[-1]))
+        dbs.append([flat[offs[i]:offs[i + 1]] for i in range(n)])
+    qs = [synth.query(140 + 30 * t, seed=20 + t) for t in range(3)]
+    pick = np.arange(0, n, 100)
+    want = [oracle.search(qs[t], [dbs[t][i] for i in pick], 11, 1, m, 1, opal_amd.MODES["SW"]) for t in range(3)]
+    errors = []
+
+    def run(t):
+        try:
+            for _ in range(6):
+                rc, results = opal_amd.search_database(qs[t], dbs[t], 11, 1, m, opal_amd.OPAL_SEARCH_SCORE_END, opal_amd.MODES["SW"])
+                got = opal_amd.result_fields(results, "score", "endLocationQuery", "endLocationTarget")
+                assert rc == 0
+                for a, b in zip(got, want[t][1:]):
+                    np.testing.assert_array_equal(a[pick], b)
+        except Exception as e:  # noqa
+            errors.append((t, repr(e)[:300]))
+    threads = [threading.Thread(target=run, args=(t,)) for t in range(3)]
+    for th in threads: th.start()
+    for th in threads: th.join()
+    assert not errors, errors
+    # alignment search twice on one database: the second call recognises it; identical starts and operations
+    ours = oracle_lib.OpalABI(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "opal_amd", "csrc", "libopal.so"))
+    small = dbs[0][:600]
+    first = None
+    for rep in range(2):
+        rc, s, eq, et, sset, (arr, _) = ours.search(qs[0], small, 11, 1, m, 2, opal_amd.MODES["SW"])
+        sq, st, ops = ours.alignments(arr)
+        assert rc == 0
+        if first is None:
+            first = (s, eq, et, sq, st, ops)
+            for i in range(0, 600, 60):
+                assert oracle.check_alignment(qs[0], small[i], 11, 1, m, s[i], sq[i], st[i], eq[i], et[i], np.frombuffer(ops[i], np.uint8)) == 0
+        else:
+            for a, b in zip(first[:5], (s, eq, et, sq, st)):
+                np.testing.assert_array_equal(a, b)
+            assert first[5] == ops
+
+
 def test_multi_gpu_handle_device_side_gather(c2):
     """opalx_multi_*: one database dealt to several GPUs of one process (here three contexts on this box's one GPU), every
     shard's result block gathered on the root GPU by peer copies and permuted into database order there -- no result

@@ -234,6 +234,15 @@ def test_ordering_is_a_stable_sort_by_length():
             assert (seq[m], ln[m], off[m]) == (-1, 0, int(lens[want].astype(np.int64).sum()))
 
 
+def test_host_pool_runs_every_task_exactly_once():
+    """The library's host thread pool (host_pool.hpp): jobs of 1..300 tasks, synchronous and begin/end in turn, from one
+    caller and from four callers at once; every task of every job exactly once."""
+    lib = C.CDLL(LIB)
+    lib.opalx_debug_pool_selftest.restype = C.c_int
+    assert lib.opalx_debug_pool_selftest(3000, 1) == 0
+    assert lib.opalx_debug_pool_selftest(1500, 4) == 0
+
+
 def test_host_code_sanitized():
     """The host translation units rebuilt with UndefinedBehaviorSanitizer (opal_amd/csrc/Makefile: libopal_ubsan.so) run
     this module's tests -- API rules, ordering on several threads, the thread pool, the host traceback against the
