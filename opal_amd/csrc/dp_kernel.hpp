@@ -392,11 +392,12 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
     constexpr bool SKEW = (FLAGS & FLAG_SKEW) != 0 && WIDTH == 17 && MODE != MODE_SW && !MULTI;
     // NW and OV read the first row block of the NEXT step's profile column at the top of the current step (measured on
     // the C3 workload: NW 1.183 -> 1.117 ms, OV 1.266 -> 1.248 ms; HW and SW gain nothing from it and the 4 extra live
-    // registers push their 39/40-row shapes over 128, so they read it at the start of their own step)
+    // registers push their 39/40-row shapes over 128, so they read it at the start of their own step; OV had it in round 2
+    // and measures 1.1 % faster without since round 3)
     // Shapes with FEW rows per lane (S <= 12: the 32- and 64-lane classes of the longest sequences, whose lone waves are the
     // critical path of a search with a real length tail -- a 35 213-residue target at 2 rows per lane is 35 000 steps of
     // pure latency) do it in every mode: with so few rows the LDS round trip is most of a step.
-    constexpr bool PF_TOP = PLAIN && (MODE == MODE_NW || (MODE == MODE_OV && S <= 38) || S <= 12);
+    constexpr bool PF_TOP = PLAIN && (MODE == MODE_NW || S <= 12);  // (OV with it: 1.1 % slower since round 3's leaner last-column code)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int log2G = cls.log2G;
@@ -871,7 +872,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
             // larger value, then the smaller row. The lane holding query row Q-1 ends up with the column's maximum and the
             // smallest row attaining it.
             const bool lastc = c >= 0 && c == len[0] - 1;
-            if (__ballot(lastc) != 0ull) {
+            if (__ballot(lastc) != 0ull) {  // (marking this and the other rare blocks unlikely, so that they are laid out behind the loop, measured no faster)
                 unsigned inKey = shr1((unsigned)lcMax[0]);
                 if (k == 0) inKey = 0u;
                 if (lastc) {

@@ -9,6 +9,15 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# PyTorch-ROCm wheels bundle their own HIP runtime (same SONAME as /opt/rocm's): whichever is loaded first owns the GPU.
+# Tests that load libopal.so directly (ctypes) and tests that use torch.cuda run in one process, so torch goes first --
+# whatever the test order or selection (opal_amd/_lib.py does the same for library users).
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
