@@ -8,6 +8,8 @@ Input kinds:
   random4    test.cpp-style uniform 4-letter sequences (reference src/test.cpp:37-54), drawn
              from splitmix64 instead of libc rand
   literal    sequences written out in the case
+  randomA    uniform random sequences over an alphabet of A letters with a seeded random symmetric matrix
+             (entries -6..8, diagonal 2..10), drawn from splitmix64: alphabets of 2 .. 255 letters
 """
 import os
 
@@ -78,6 +80,24 @@ _add("random4_q200_db300_o0", kind="random4", qlen=200, nseq=300, seed=1002, mat
      alphabet=4, gap_open=5, gap_ext=2, minlen=1, maxlen=400)
 
 
+# ---- gap penalties at the edges the API allows (opal.h:99-111: non-negative): free gaps, linear gaps (open == extend), an
+#      opening cheaper than an extension, free extensions. (The reference's ALIGNMENT pass crashes for some of these; its
+#      score / end-location search is defined for all of them.)
+for _go, _ge in ((0, 0), (0, 1), (1, 0), (2, 2), (1, 3), (5, 0), (7, 7)):
+    _add(f"gaps_o{_go}_e{_ge}", kind="random4", qlen=90, nseq=40, seed=2001, matrix=("simple", 3, -2), alphabet=4,
+         gap_open=_go, gap_ext=_ge, minlen=20, maxlen=300)
+
+# ---- the smallest shapes: queries of 1-3 letters against targets of 1, 2 and 5 letters
+for _q in (1, 2, 3):
+    for _l in (1, 2, 5):
+        _add(f"tiny_q{_q}_l{_l}", kind="random4", qlen=_q, nseq=6, seed=3000 + 10 * _q + _l, matrix=("simple", 3, -2), alphabet=4,
+             minlen=_l, maxlen=_l)
+
+# ---- alphabets from 2 to 255 letters (the API takes any unsigned char alphabet; the query profile of a large one no
+#      longer fits the LDS in one piece: row chunks)
+for _a in (2, 64, 200, 255):
+    _add(f"alphabet_{_a}", kind="randomA", alphabet=_a, qlen=150, nseq=30, seed=4000 + _a, minlen=30, maxlen=400, gap_open=5, gap_ext=2)
+
 # ---- alignment (traceback) goldens: start locations and operation strings recorded from the reference
 for _n in ("readme_example", "td_test1_test1", "td_O74807_sprot15_o3", "td_O74807_sprot15_o11", "pin_100_same_match3"):
     CASES[_n]["align"] = True
@@ -105,6 +125,20 @@ def random4(seed, qlen, nseq, alphabet=4, minlen=800, maxlen=4799):
     return q, [flat[offs[i]:offs[i + 1]] for i in range(nseq)]
 
 
+def random_alphabet(seed, alphabet, qlen, nseq, minlen, maxlen):
+    """Uniform random sequences over `alphabet` letters and a random symmetric matrix (entries -6..8, diagonal 2..10)."""
+    A = alphabet
+    r = synth.splitmix64(seed, 0, A * A + A)
+    m = (r[: A * A] % np.uint64(15)).astype(np.int64).reshape(A, A) - 6
+    m = np.minimum(m, m.T)
+    m[np.arange(A), np.arange(A)] = 2 + (r[A * A:] % np.uint64(9)).astype(np.int64)
+    q = (synth.splitmix64(seed + 1, 0, qlen) % np.uint64(A)).astype(np.uint8)
+    lens = (minlen + synth.splitmix64(seed + 2, 0, nseq) % np.uint64(maxlen - minlen + 1)).astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    flat = (synth.splitmix64(seed + 3, 0, int(offs[-1])) % np.uint64(A)).astype(np.uint8)
+    return q, [flat[offs[i]:offs[i + 1]] for i in range(nseq)], m.astype(np.int32)
+
+
 def materialise(case):
     """-> (query uint8[], list of uint8[] targets, int32[A,A] matrix)."""
     kind = case["kind"]
@@ -121,6 +155,8 @@ def materialise(case):
         q, db = random4(case["seed"], case["qlen"], case["nseq"], case["alphabet"],
                         case.get("minlen", 800), case.get("maxlen", 4799))
         return q, db, _matrix(case["matrix"], case["alphabet"])
+    if kind == "randomA":
+        return random_alphabet(case["seed"], case["alphabet"], case["qlen"], case["nseq"], case["minlen"], case["maxlen"])
     if kind == "literal":
         q = np.array(case["query"], dtype=np.uint8)
         db = [np.array(s, dtype=np.uint8) for s in case["db"]]
