@@ -324,7 +324,17 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # BENCH_FORCE_DIST=1 (test hook): one rank goes through everything N ranks go through -- process group on the chosen
+    # backend (RCCL by default), deal, padded gather, index_select, barrier, all-reduce -- so that the RCCL branch can be
+    # exercised on a one-GPU box (RCCL refuses two ranks on one GPU).
+    multi = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -351,7 +361,7 @@ def main():
     # ---- this rank's shard of the one global database. One rank: the database in its own order (results land at their
     # database index). Several: 64-sequence groups dealt by residue count (opal_amd/shard.py).
     all_lens = synth.lengths(42, 0, total, args.dist)
-    owned_lists = shard.deal(all_lens, world) if world > 1 else [np.arange(total, dtype=np.int64)]
+    owned_lists = shard.deal(all_lens, world) if multi else [np.arange(total, dtype=np.int64)]
     owned = owned_lists[rank]
     n = len(owned)
     npad = max(len(o) for o in owned_lists)
@@ -367,11 +377,11 @@ def main():
     # {score, endQ, endT} blocks, padded to the largest shard. Two result buffers used in turn (N > 1): the search runs on
     # the library's own stream, the gather on torch's, so step i+1 must not overwrite what step i's gather is still
     # reading; a buffer is reused two steps later, after waiting on the event recorded behind its last reader.
-    outs = [torch.zeros(nres * npad, dtype=torch.int32, device=dev) for _ in range(2 if world > 1 else 1)]
+    outs = [torch.zeros(nres * npad, dtype=torch.int32, device=dev) for _ in range(2 if multi else 1)]
     done = [None, None]
-    done_ev = [torch.cuda.Event(), torch.cuda.Event()] if world > 1 else None  # (reused: no event creation per step)
+    done_ev = [torch.cuda.Event(), torch.cuda.Event()] if multi else None  # (reused: no event creation per step)
     # position of every database sequence in the gathered [rank][value][npad] block: ONE index operation per step
-    plan = shard.GatherPlan(owned_lists, nres, dev if backend == "nccl" else "cpu", root=rank == 0) if world > 1 else None
+    plan = shard.GatherPlan(owned_lists, nres, dev if backend == "nccl" else "cpu", root=rank == 0) if multi else None
     torch.cuda.synchronize()  # (the zero fills above run on torch's stream, the searches on the library's)
     kernel_ms = []
     step_no = [0]
@@ -388,7 +398,7 @@ def main():
         if rc != 0:
             raise SystemExit(f"search failed rc={rc}")
         kernel_ms.append(kms)
-        if world > 1:
+        if multi:
             # the path's only exchange: ONE gather of the per-sequence result block to rank 0, which puts the
             # blocks back into database order with the deal's permutation (one index_select for all result vectors)
             plan.gather(out if backend == "nccl" else out.cpu(), rank)
@@ -396,7 +406,7 @@ def main():
             done[b].record()
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -411,7 +421,7 @@ def main():
     dt = time.perf_counter() - t0
     rdev = dev if backend == "nccl" else torch.device("cpu")
     tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
-    if world > 1:
+    if multi:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -434,7 +444,7 @@ def main():
     if not ok_local:
         sys.stderr.write(f"bench.py: rank {rank}: results differ from the oracle on its shard sample\n")
     vflag = torch.tensor([1 if ok_local else 0], dtype=torch.int32, device=rdev)
-    if world > 1:
+    if multi:
         dist.all_reduce(vflag, op=dist.ReduceOp.MIN)
     verified = bool(int(vflag.item()) == 1)
 
@@ -443,9 +453,9 @@ def main():
         gcups = total_cells * args.steps / dt / 1e9
         kms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
         kernel_gcups = cells / (kms * 1e-3) / 1e9
-        gall = plan.glob.cpu().numpy() if world > 1 else mine
+        gall = plan.glob.cpu().numpy() if multi else mine
         gscore = np.ascontiguousarray(gall[0])
-        if world > 1:  # the gathered, re-ordered block must hold rank 0's own verified values at their database indices
+        if multi:  # the gathered, re-ordered block must hold rank 0's own verified values at their database indices
             verified = verified and bool((gall[:, owned] == mine).all())
 
         # ---- the clock the chip holds under this kernel (it clocks to its power budget): a few more searches with the
@@ -580,7 +590,7 @@ def main():
                 res_host = d_res.cpu().numpy()
             res_line["cpu_baseline"] = cpu_baseline(query, res_host, offs, matrix, args.gap_open, args.gap_ext, mode)
         print(json.dumps(res_line), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     sys.exit(status)

@@ -300,6 +300,21 @@ def test_two_rank_bench_on_one_gpu():
     assert one["verify"]["score_crc32"] == two["verify"]["score_crc32"]
 
 
+def test_bench_rccl_branch_with_one_rank():
+    """The RCCL side of bench.py on a one-GPU box (RCCL refuses two ranks on one GPU, so the two-rank test above runs on
+    gloo): BENCH_FORCE_DIST=1 sends ONE rank through everything N ranks go through -- `nccl` process group bound to the
+    device, the deal's permutation, dist.gather into the plan's block, the one index_select, barrier, the all-reduces of the
+    time and of the verdict. Same scores as the plain one-GPU run."""
+    common = ["--total-seqs", "30000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-e2e"]
+    plain = _run_bench(["--gpus", "1"] + common)
+    forced = _run_bench(["--gpus", "1"] + common, {"BENCH_FORCE_DIST": "1"})
+    assert plain["verified"] and forced["verified"]
+    assert plain["verify"]["score_crc32"] == forced["verify"]["score_crc32"]
+    forced_end = _run_bench(["--gpus", "1", "--workload", "c3", "--mode", "HW", "--seqs", "20000", "--steps", "2", "--warmup", "1",
+                             "--no-cpu-baseline", "--no-e2e"], {"BENCH_FORCE_DIST": "1"})
+    assert forced_end["verified"]
+
+
 def test_bench_launcher_failing_rank_on_gpu():
     """`bench.py --gpus 2` with rank 1 dying before the rendezvous while rank 0 really waits in it (gloo, shared GPU): the
     parent kills rank 0 and returns non-zero within seconds instead of sitting out the rendezvous timeout."""
