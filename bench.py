@@ -302,6 +302,13 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))  # nothing GPU-related has been imported or touched in this process
 
+    # stdout carries exactly ONE line, the JSON: libraries write there too (RCCL prints "Librccl path : ..." when the
+    # process group goes away, i.e. AFTER the result), so everything else of this process is sent to stderr and the line
+    # is written to the real stdout at the very end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -589,10 +596,12 @@ def main():
             if res_host is None:
                 res_host = d_res.cpu().numpy()
             res_line["cpu_baseline"] = cpu_baseline(query, res_host, offs, matrix, args.gap_open, args.gap_ext, mode)
-        print(json.dumps(res_line), flush=True)
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res_line) + "\n").encode())
     sys.exit(status)
 
 
