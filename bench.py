@@ -3,7 +3,8 @@
 
 A "step" is one pass of the hot path over one batch: one query against the whole synthetic protein
 database shard of this rank, database already packed and resident in HBM, results written to device
-buffers in database order, then (N > 1 only) ONE gather of the per-sequence results to rank 0 -- the path's only exchange.
+buffers in database order, then (N > 1 only) ONE gather of the per-sequence results to rank 0 -- the path's only exchange
+(issued by the host while the GPU is already on the next step's search: opalx_search_device_async / opalx_db_wait).
 
 Workloads (BASELINE.json `configs`):
   c2 (default)  300-aa synthetic query x 100 000 synthetic sequences PER GPU, SW score-only, gaps 11/1  -> "weak"
@@ -393,6 +394,15 @@ def main():
     kernel_ms = []
     step_no = [0]
 
+    pending = [None]  # (N > 1) the result buffer whose exchange is still to be issued
+
+    def exchange(b):
+        # the path's only exchange: ONE gather of the per-sequence result block to rank 0, which puts the
+        # blocks back into database order with the deal's permutation (one index_select for all result vectors)
+        plan.gather(outs[b] if backend == "nccl" else outs[b].cpu(), rank)
+        done[b] = done_ev[b]
+        done[b].record()
+
     def step():
         b = step_no[0] % len(outs)
         step_no[0] += 1
@@ -400,17 +410,27 @@ def main():
         if done[b] is not None:
             done[b].synchronize()
         score, endq, endt = out[:npad], (out[npad:2 * npad] if want_end else None), (out[2 * npad:] if want_end else None)
-        rc, kms = pdb.search_device(query, args.gap_open, args.gap_ext, matrix, args.search_type, mode, score.data_ptr(),
-                                    endq.data_ptr() if want_end else 0, endt.data_ptr() if want_end else 0)
+        if not multi:
+            rc, kms = pdb.search_device(query, args.gap_open, args.gap_ext, matrix, args.search_type, mode, score.data_ptr(),
+                                        endq.data_ptr() if want_end else 0, endt.data_ptr() if want_end else 0)
+        else:
+            # the search is only ENQUEUED; while the GPU works on it the host issues the previous step's exchange (its
+            # Python / RCCL call overhead, ~0.2 ms, would otherwise sit between two searches), then waits for the search
+            rc = pdb.search_device_async(query, args.gap_open, args.gap_ext, matrix, args.search_type, mode, score.data_ptr(),
+                                         endq.data_ptr() if want_end else 0, endt.data_ptr() if want_end else 0)
+            if rc == 0 and pending[0] is not None:
+                exchange(pending[0])
+            rc2, kms = pdb.wait()
+            rc = rc or rc2
+            pending[0] = b
         if rc != 0:
             raise SystemExit(f"search failed rc={rc}")
         kernel_ms.append(kms)
-        if multi:
-            # the path's only exchange: ONE gather of the per-sequence result block to rank 0, which puts the
-            # blocks back into database order with the deal's permutation (one index_select for all result vectors)
-            plan.gather(out if backend == "nccl" else out.cpu(), rank)
-            done[b] = done_ev[b]
-            done[b].record()
+
+    def flush():
+        if multi and pending[0] is not None:
+            exchange(pending[0])
+            pending[0] = None
 
     def fence():
         if multi:
@@ -419,11 +439,13 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    flush()
     kernel_ms.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    flush()  # (the last step's exchange: inside the timed region)
     fence()
     dt = time.perf_counter() - t0
     rdev = dev if backend == "nccl" else torch.device("cpu")

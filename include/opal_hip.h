@@ -291,6 +291,17 @@ int opalx_search_device(OpalxDb* db, const unsigned char* query, int query_lengt
                         int search_type, int mode, int overflow_method,
                         int* d_score, int* d_end_query, int* d_end_target, float* kernel_ms);
 
+/* The same without the wait: the kernels are enqueued on the handle's stream and the call returns, so that the caller
+   can do other host work (bench.py: the previous step's gather) while the GPU searches; opalx_db_wait waits for the search
+   and reports its kernel time. One search in flight per handle: call opalx_db_wait before the next search on it. A search
+   that needs a host decision midway (a 16-bit rung whose scores can saturate: the re-run list is read back) waits
+   internally and is complete on return. Return codes as opalx_search_device (a 32-bit wrap is reported by the call that
+   detects it). */
+int opalx_search_device_async(OpalxDb* db, const unsigned char* query, int query_length,
+                              int gap_open, int gap_ext, const int* score_matrix, int alphabet_length,
+                              int search_type, int mode, int* d_score, int* d_end_query, int* d_end_target);
+int opalx_db_wait(OpalxDb* db, float* kernel_ms);
+
 /* As above with HOST result buffers (copied back after the kernels). */
 int opalx_search_host(OpalxDb* db, const unsigned char* query, int query_length,
                       int gap_open, int gap_ext, const int* score_matrix, int alphabet_length,

@@ -46,6 +46,11 @@ def lib():
         L.opalx_search_device.restype = C.c_int
         L.opalx_search_device.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_int, i32p, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+        L.opalx_search_device_async.restype = C.c_int
+        L.opalx_search_device_async.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_int, i32p, C.c_int, C.c_int, C.c_int,
+                                                C.c_void_p, C.c_void_p, C.c_void_p]
+        L.opalx_db_wait.restype = C.c_int
+        L.opalx_db_wait.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.opalx_search_starts.restype = C.c_int
         L.opalx_search_starts.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_int, i32p, C.c_int, C.c_int, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, i32p, i32p]

@@ -139,6 +139,21 @@ class PreparedDb:
                                             C.byref(ms))
         return rc, ms.value
 
+    def search_device_async(self, query, gap_open, gap_ext, score_matrix, search_type, mode, d_score, d_end_q=0, d_end_t=0):
+        """opalx_search_device_async: enqueue the search and return (results are complete after wait()). Returns rc."""
+        q = _u8(query)
+        m = np.ascontiguousarray(score_matrix, dtype=np.int32)
+        self._keep = (q, m)  # (read by asynchronous copies until wait())
+        return _lib.lib().opalx_search_device_async(self._h, q.ctypes.data_as(C.POINTER(C.c_ubyte)), len(q), int(gap_open), int(gap_ext),
+                                                    m.ctypes.data_as(C.POINTER(C.c_int)), int(m.shape[0]), int(search_type), int(mode),
+                                                    C.c_void_p(d_score), C.c_void_p(d_end_q or None), C.c_void_p(d_end_t or None))
+
+    def wait(self):
+        """opalx_db_wait: wait for the search launched last. Returns (rc, kernel_ms)."""
+        ms = C.c_float(0)
+        rc = _lib.lib().opalx_db_wait(self._h, C.byref(ms))
+        return rc, ms.value
+
     def search_starts_device(self, query, gap_open, gap_ext, score_matrix, mode, d_score, d_end_q, d_end_t, d_start_q, d_start_t):
         """opalx_search_starts: start cells on the device from the score / end-cell arrays a SCORE_END search of the
         same query left in device memory (raw pointers). Returns (rc, redo) -- `redo` = indices the host must redo."""

@@ -464,7 +464,9 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
     const LenView pairLenOf{db->pairLen.data(), 2, nullptr};  // width-16 items are pairs
     const LenView seqLenOf{db->pairLen.data(), 1, nullptr};   // width-17/18/32 items are pair*2+half
     void* evStart = nullptr; void* evStop = nullptr;
-    if (kernelMs) { evStart = db->event(4); evStop = db->event(5); }
+    const bool timed = kernelMs || db->asyncTimed;  // (asyncTimed: opalx_search_device_async -- opalx_db_wait reads the events)
+    db->asyncEvents = false;
+    if (timed) { evStart = db->event(4); evStop = db->event(5); }
     if (evStart) opal_hip_event_record(evStart, st);
 
     if (mode == OPAL_MODE_SW) {
@@ -598,7 +600,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
             if (e) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
         }
     }
-    if (evStop) opal_hip_event_record(evStop, st);
+    if (evStop) { opal_hip_event_record(evStop, st); db->asyncEvents = db->asyncTimed; }
     // (a caller that copies the results back on the same stream and waits for that copy needs no wait of its own here)
     if ((finalSync || kernelMs) && opal_hip_stream_sync(st)) return OPAL_ERR_NO_SIMD_SUPPORT;
     if (kernelMs && evStart && evStop) *kernelMs = opal_hip_event_elapsed_ms(evStart, evStop);

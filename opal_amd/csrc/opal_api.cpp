@@ -118,6 +118,28 @@ extern "C" int opalx_search_device(OpalxDb* db, const unsigned char* query, int 
                        d_score, d_end_query, d_end_target, kernel_ms);
 }
 
+extern "C" int opalx_search_device_async(OpalxDb* db, const unsigned char* query, int query_length, int gap_open, int gap_ext,
+                                         const int* score_matrix, int alphabet_length, int search_type, int mode,
+                                         int* d_score, int* d_end_query, int* d_end_target) {
+    if (!db) return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (search_type != OPAL_SEARCH_SCORE && (!d_end_query || !d_end_target)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    db->asyncTimed = true;
+    const int rc = search_core(db, query, query_length, gap_open, gap_ext, score_matrix, alphabet_length, search_type, mode,
+                               d_score, d_end_query, d_end_target, nullptr, /*finalSync=*/false);
+    db->asyncTimed = false;
+    return rc;
+}
+
+extern "C" int opalx_db_wait(OpalxDb* db, float* kernel_ms) {
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (!db) return OPAL_ERR_NO_SIMD_SUPPORT;
+    void* st = db->main();
+    if (!st || opal_hip_stream_sync(st)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (kernel_ms && db->asyncEvents) *kernel_ms = opal_hip_event_elapsed_ms(db->event(4), db->event(5));
+    db->asyncEvents = false;
+    return 0;
+}
+
 extern "C" int opalx_search_host(OpalxDb* db, const unsigned char* query, int query_length, int gap_open, int gap_ext,
                                  const int* score_matrix, int alphabet_length, int search_type, int mode,
                                  int overflow_method, int* score, int* end_query, int* end_target) {

@@ -160,6 +160,8 @@ struct OpalxDb {
     opal_host::PinVec<uint64_t> hPairOff;
     size_t numTokens = 0;
     bool tokensValid = false;
+    bool asyncTimed = false;   // a search launched by opalx_search_device_async is in flight (its events 4/5 get recorded)
+    bool asyncEvents = false;  // ... and they were
     bool clockProbe = false;   // opalx_db_clock_probe
     bool timelineProbe = false;
     opal_host::DevBuf<unsigned long long> timeline;  // [2 x 65536 workgroups], zeroed before a probed search
