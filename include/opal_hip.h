@@ -137,6 +137,7 @@ double opal_hip_wall_clock_hz(void);       /* ticks per second of the constant-r
 void* opal_hip_malloc(size_t bytes);
 void opal_hip_free(void* p);
 void* opal_hip_host_malloc(size_t bytes);  /* pinned host memory (staging of residues and results) */
+void* opal_hip_host_malloc_device_cached(size_t bytes);  /* the same, coarse-grained: kernels may read it directly (cached in L2) */
 void opal_hip_host_free(void* p);
 int opal_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
 int opal_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);

@@ -13,7 +13,7 @@ static void fill_launch(OpalHipLaunch& a, const SearchCtx& c, int width, int swE
     a.width = width; a.mode = c.mode; a.want_end = swEndPass; a.detect_wrap = detectWrap;
     a.query = db->query.p; a.query_length = c.Q; a.score_matrix = db->matrix.p; a.alphabet_length = c.A;
     a.gap_open = c.Go; a.gap_ext = c.Ge;
-    a.residues = db->res.p; a.seq_offset = db->dSeqOff.p;
+    a.residues = c.zeroCopy ? db->hRaw.p : db->res.p; a.seq_offset = db->dSeqOff.p;  // (zeroCopy: sliced launches of a cold opalSearchDatabase call)
     a.tokens = db->tokens.p; a.pair_token_offset = db->pairOff.p;  // (width 16 only: ensure_pair_tokens)
     a.pair_len = db->dPairLen.p; a.pair_seq = db->dPairSeq.p;
     a.work = work;
@@ -167,10 +167,10 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
         else if (k.G != 2 * bulk.G && k.G != 4 * bulk.G) oneGrid = false;
     }
     // items [i0, i1) of the classes as ONE grid on `stream` (any class may be empty there)
-    auto launch_grid = [&](int i0, int i1, void* stream) -> int {
+    auto launch_grid = [&](const SearchCtx& cx, int i0, int i1, void* stream) -> int {
         OpalHipUberLaunch u;
         memset(&u, 0, sizeof u);
-        fill_launch(u.base, c, width, swEndPass, detectWrap, nullptr, ovfCounter);
+        fill_launch(u.base, cx, width, swEndPass, detectWrap, nullptr, ovfCounter);
         u.base.stream = stream;
         u.base.lanes_per_seq = bulk.G; u.base.rows_per_lane = bulk.rows; u.base.waves_per_block = 4; u.base.skew = skewBulk;
         for (const LaunchClass& k : classes) {
@@ -195,6 +195,8 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
     // the first slice holds the long classes.
     if (db->gate.active && !work && (width == 17 || width == 18) && db->gate.chunks() >= 4 && !getenv("OPAL_HIP_NO_SLICES")) {
         const UploadGate& g = db->gate;
+        SearchCtx zc = c;
+        zc.zeroCopy = g.zeroCopy;  // (a database seen for the first time: the launches read the pinned staging buffer over PCIe)
         // chunks per slice, the rest in the last one (C2: 17 chunks of 2 MB). The FIRST slice holds the long classes: its
         // longest sequence is the critical path of the whole search, so it is as small as it can be (it starts as soon as
         // one chunk has landed) and runs on a high-priority side stream of its own; the others take `main` and `aux` in
@@ -246,16 +248,16 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
             if (j > 0 && how == 1) stream = (j & 1) ? db->main() : aux;
             if (j > 0 && how == 2) stream = j == 1 ? db->main() : j == 2 ? aux : db->stream(1 + (int)(j & 1));
             auxUsed |= stream != side && stream != db->main();
-            if (!gate_items(db, stream, cut[j], cut[j + 1] - cut[j])) { err = 1; break; }
+            if (!gate_items(db, stream, cut[j], cut[j + 1] - cut[j], /*needDevice=*/!zc.zeroCopy)) { err = 1; break; }
             if (dbg) { void* ev = opal_hip_event_create(); marks.push_back(ev); if (ev) opal_hip_event_record(ev, stream); }
-            if (oneGrid) err = launch_grid(cut[j], cut[j + 1], stream);
+            if (oneGrid) err = launch_grid(zc, cut[j], cut[j + 1], stream);
             else
                 for (size_t ki = 0; ki < classes.size() && !err; ki++) {
                     LaunchClass k = classes[ki];
                     const int a = std::max(k.first, cut[j]), b = std::min(k.first + k.count, cut[j + 1]);
                     if (b <= a) continue;
                     k.first = a; k.count = b - a;
-                    err = launch_class(c, width, swEndPass, detectWrap, nullptr, k, maySkew && skew_ok(classes[ki].first), ovfCounter, stream, ki + 1 < classes.size());
+                    err = launch_class(zc, width, swEndPass, detectWrap, nullptr, k, maySkew && skew_ok(classes[ki].first), ovfCounter, stream, ki + 1 < classes.size());
                 }
             if (dbg) { void* ev = opal_hip_event_create(); marks.push_back(ev); if (ev) opal_hip_event_record(ev, stream); }
         }
@@ -284,7 +286,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
     if (!gate_items(db, db->main(), 0, 2 * db->numPairs)) return OPAL_ERR_NO_SIMD_SUPPORT;
 
     if (oneGrid && classes.size() >= 2) {
-        if (launch_grid(firstItem, firstItem + numItems, db->main())) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
+        if (launch_grid(c, firstItem, firstItem + numItems, db->main())) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
         return 0;
     }
     // The last class (the bulk of the database) runs on the main stream; the classes of long

@@ -62,7 +62,11 @@ static int run_shard(int device, const unsigned char* query, int Q, unsigned cha
     int rc = search_core(pdb, query, Q, Go, Ge, M, A, searchType, mode, dS, wantEnd ? dQ : nullptr, wantEnd ? dT : nullptr, nullptr,
                          /*finalSync=*/false);
     const double t2b = now_ms();
+    const bool zeroCopied = pdb->gate.zeroCopy;
     if (!db_fill_finish(pdb)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    // (a zero-copy search did not wait for the chunk copies: whatever follows on `main` -- start cells, traceback -- reads the
+    // device copy of the residues)
+    if (zeroCopied && startQ && startT && !wait_uploads(pdb, st)) return OPAL_ERR_NO_SIMD_SUPPORT;
     if (fill_changed(pdb)) {
         // the database looked like the previous call's (same lengths) and was searched before its residues had been
         // compared; some differ: they are on the device by now (after the copy streams), the search is done again

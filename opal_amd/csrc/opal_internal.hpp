@@ -77,12 +77,13 @@ template <typename T> struct DevBuf {
 template <typename T> struct PinBuf {
     T* p = nullptr;
     size_t cap = 0;
+    bool deviceCached = false;  // coarse-grained: kernels read it directly over PCIe (see opal_hip_host_malloc_device_cached)
     bool ensure(size_t n, double slack = 1.0) {
         if (p && cap > 4 * std::max<size_t>(n, 1) && cap * sizeof(T) > (256u << 20)) release();
         if (n <= cap && p) return true;
         opal_hip_host_free(p);
         const size_t want = std::max<size_t>((size_t)((double)n * slack), 1);
-        p = (T*)opal_hip_host_malloc(want * sizeof(T));
+        p = (T*)(deviceCached ? opal_hip_host_malloc_device_cached(want * sizeof(T)) : opal_hip_host_malloc(want * sizeof(T)));
         cap = p ? want : 0;
         return p != nullptr;
     }
@@ -123,6 +124,7 @@ struct UploadGate {
     std::unique_ptr<std::atomic<int>[]> dirty; // chunk c must be uploaded (always, unless the device already holds the same bytes)
     std::atomic<int> uploaded{0};              // chunks copied by this fill
     bool reuse = false;                        // this fill found the database of the previous call (same lengths)
+    bool zeroCopy = false;                     // the sliced launches of this fill's search read the pinned staging buffer directly
     bool speculated = false;                   // ... and its search was launched without waiting for the comparison
     size_t stateCap = 0;
     int chunks() const { return active ? (int)cutItem.size() - 1 : 0; }
@@ -264,7 +266,11 @@ bool db_fill_finish(OpalxDb* db);  // waits for the pool; false if a chunk faile
 bool fill_changed(const OpalxDb* db);
 // Make `stream` wait for the residues of items [firstItem, firstItem + count) (host-waits until their chunks have been
 // enqueued, then one hipStreamWaitEvent per chunk). No-op without an active gate. False if a chunk failed.
-bool gate_items(OpalxDb* db, void* stream, int firstItem, int count);
+bool gate_items(OpalxDb* db, void* stream, int firstItem, int count, bool needDevice = true);
+// (needDevice = false: the launch reads the residues from the pinned staging buffer itself -- zero copy --, so it only has to
+// wait until its chunks have been GATHERED)
+// Make `stream` wait for every chunk copy of the last fill (after a zero-copy search: what follows reads the device copy).
+bool wait_uploads(OpalxDb* db, void* stream);
 // The 16-bit pair token streams of the width-16 kernels (built on the device on first use). 0 on success.
 int ensure_pair_tokens(OpalxDb* db);
 
@@ -313,6 +319,7 @@ struct SearchCtx {
     int* dScore; int* dEndQ; int* dEndT;
     int satLimit, negPad;  // width 17 (plain 16-bit) parameters
     long long maxScore;    // largest matrix entry (>= 0)
+    bool zeroCopy = false; // launches read the residues from the pinned staging buffer (db->hRaw) instead of the device copy
 };
 
 // Lengths of the items of a launch range: item i has length lens[(idx ? idx[i] : i) * stride]

@@ -52,6 +52,16 @@ extern "C" void* opal_hip_host_malloc(size_t bytes) {
     return p;
 }
 
+// Pinned host memory the DEVICE caches (coarse-grained: coherent with the host at kernel boundaries). The residue staging
+// buffer is of this kind: the DP kernels of a cold opalSearchDatabase call read it directly over PCIe (one pass over every
+// byte: with the default fine-grained mapping every 8-byte batch of a slot would re-fetch its cache line).
+extern "C" void* opal_hip_host_malloc_device_cached(size_t bytes) {
+    void* p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocNonCoherent);
+    if (e != hipSuccess) { fail("hipHostMalloc(non-coherent)", e); return nullptr; }
+    return p;
+}
+
 extern "C" void opal_hip_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 // Ticks per second of s_memrealtime (the constant-rate counter the clock probe divides shader cycles by).
