@@ -32,6 +32,11 @@ extern "C" {
 /* ------------------------------------------------------------------ part 1 */
 
 /* One kernel launch over `num_items` work items. All pointers are device pointers. */
+/* Zero-copy launches (OpalHipLaunch::residues_out): SW kernels only, and those of more rows per lane than this have no
+ * register to spare for the extra store and ignore residues_out -- the host must not rely on it there. */
+#define OPAL_ZERO_COPY_MAX_ROWS 38
+#define OPAL_ZERO_COPY_MAX_ROWS_SWEND 36
+
 typedef struct OpalHipLaunch {
     /* what to compute */
     int width;        /* 16: two sequences per lane as packed int16; 17: one sequence per lane, plain 16-bit
@@ -53,6 +58,8 @@ typedef struct OpalHipLaunch {
        first; item i = position in that order = pair * 2 + half */
     const unsigned char* residues;  /* one byte per residue, sequence after sequence in item order */
     const uint64_t* seq_offset;     /* [items] start of each sequence in `residues` */
+    unsigned char* residues_out;    /* NULL, or: `residues` is pinned host memory read over PCIe, and the kernels (widths 17, 18,
+                                       32; class launches) also write every residue they read here -- the device copy */
     const uint16_t* tokens;      /* width 16 only. Per pair (items 2p, 2p+1): max(lenA,lenB) entries, low byte = residue of A, high byte = B */
     const uint64_t* pair_token_offset; /* width 16 only. [num_pairs] start of each pair's token stream */
     const int* pair_len;         /* [2*num_pairs] lengths of A and B (0 = absent) */

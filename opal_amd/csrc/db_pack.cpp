@@ -179,6 +179,7 @@ bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::funct
     db->gate.speculated = false;
     db->gate.reuse = false;
     db->gate.zeroCopy = false;
+    db->gate.kernelFilled = false;
     db->tokensValid = false;
     const double tf0 = now_ms();
     // The SAME database as last time? (A caller that sends many queries against one database through the plain
@@ -301,12 +302,13 @@ bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::funct
         g.state.reset(new std::atomic<int>[(size_t)nchunks]);
         g.left.reset(new std::atomic<int>[(size_t)nchunks]);
         g.dirty.reset(new std::atomic<int>[(size_t)nchunks]);
+        g.copied.reset(new std::atomic<int>[(size_t)nchunks]);
         g.stateCap = (size_t)nchunks;
     }
     for (int c = 0; c < nchunks; c++) { g.state[(size_t)c].store(0, std::memory_order_relaxed); g.left[(size_t)c].store(0, std::memory_order_relaxed); }
     for (int p = 0; p < npieces; p++) g.left[(size_t)g.pieceChunk[(size_t)p]].fetch_add(1, std::memory_order_relaxed);
     const int dev = db->device;
-    for (int c = 0; c < nchunks; c++) g.dirty[(size_t)c].store(reuse ? 0 : 1, std::memory_order_relaxed);
+    for (int c = 0; c < nchunks; c++) { g.dirty[(size_t)c].store(reuse ? 0 : 1, std::memory_order_relaxed); g.copied[(size_t)c].store(0, std::memory_order_relaxed); }
     db->gatherFn = [db, getSeq, dev, total, items, reuse](int p) {
         static thread_local int myDevice = -1;  // pool threads start on device 0: the copy below names a stream of `dev`
         if (myDevice != dev) { opal_hip_set_device(dev); myDevice = dev; }
@@ -327,7 +329,8 @@ bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::funct
         // the last piece of chunk c: its copy, and the event the launches wait for (an unchanged chunk of a database the
         // device already holds needs neither: its event of the earlier call has long completed)
         bool good = true;
-        if (gg.dirty[(size_t)c].load(std::memory_order_relaxed)) {
+        if (gg.dirty[(size_t)c].load(std::memory_order_relaxed) && !gg.zeroCopy) {
+            gg.copied[(size_t)c].store(1, std::memory_order_relaxed);
             const size_t i0 = (size_t)gg.cutItem[(size_t)c], i1 = (size_t)gg.cutItem[(size_t)c + 1];
             const uint64_t b0 = off[i0], b1 = i1 < items ? off[i1] : total;
             static const bool two = [] { const char* e = getenv("OPAL_HIP_COPY_STREAMS"); return !(e && *e == '1'); }();
@@ -382,11 +385,14 @@ bool db_fill_finish(OpalxDb* db) {
         db->gatherPending = false;
         for (int c = 0; c < db->gate.chunks(); c++)
             if (db->gate.state[(size_t)c].load(std::memory_order_acquire) < 0) ok = false;
-        db->lastValid = ok && db->cached;
+        // (a zero-copy fill leaves a complete device copy only if its kernels wrote every item, or every chunk was copied on demand)
+        bool deviceComplete = !db->gate.zeroCopy || db->gate.kernelFilled;
+        if (!deviceComplete) { deviceComplete = true; for (int c = 0; c < db->gate.chunks(); c++) deviceComplete &= db->gate.copied[(size_t)c].load() != 0; }
+        db->lastValid = ok && db->cached && deviceComplete;
         db->speculate = !(db->gate.reuse && db->gate.uploaded.load() > 0);  // (the database was edited under the same lengths: the next call waits for its comparison)
         if (debug_on()) fprintf(stderr, "[opal] fill: %d of %d chunks uploaded%s\n", db->gate.uploaded.load(), db->gate.chunks(), db->gate.reuse ? " (the others unchanged since the last call)" : "");
         if (db->gate.reuse) count(CNT_REUSED_FILLS);
-        if (ok && db->gate.timed && debug_on() && db->gate.chunks() > 0 && !db->gate.reuse) {  // (debug only: waits for the copies)
+        if (ok && db->gate.timed && debug_on() && db->gate.chunks() > 0 && !db->gate.reuse && !db->gate.zeroCopy) {  // (debug only: waits for the copies)
             opal_hip_stream_sync(db->copyStream); opal_hip_stream_sync(db->copyStream2);
             const int nc = db->gate.chunks();
             for (int c : {0, nc / 4, nc / 2, 3 * nc / 4, nc - 1})
@@ -419,7 +425,18 @@ bool gate_items(OpalxDb* db, void* stream, int firstItem, int count, bool needDe
             if (++spins < 2000) __builtin_ia32_pause();
             else std::this_thread::yield();
         }
-        if (s < 0 || (needDevice && opal_hip_stream_wait_event(stream, g.events[(size_t)c]))) return false;
+        if (s < 0) return false;
+        if (!needDevice) continue;
+        if (g.zeroCopy && g.copied[(size_t)c].exchange(1, std::memory_order_acq_rel) == 0) {
+            // a zero-copy fill copies a chunk only when something asks for its device copy: now
+            const size_t items = db->pairLen.size();
+            const size_t i0 = (size_t)g.cutItem[(size_t)c], i1 = (size_t)g.cutItem[(size_t)c + 1];
+            const uint64_t b0 = db->seqOff[i0], b1 = i1 < items ? db->seqOff[i1] : (uint64_t)db->residues;
+            void* cs = (c & 1) ? db->copyStream2 : db->copyStream;
+            if ((b1 > b0 && opal_hip_memcpy_h2d(db->res.p + b0, db->hRaw.p + b0, b1 - b0, cs)) || opal_hip_event_record(g.events[(size_t)c], cs)) return false;
+            g.uploaded.fetch_add(1, std::memory_order_relaxed);
+        }
+        if (opal_hip_stream_wait_event(stream, g.events[(size_t)c])) return false;
     }
     return true;
 }

@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
+#include "opal_hip.h"  // OPAL_ZERO_COPY_MAX_ROWS*
 
 #include <type_traits>
 #include <utility>
@@ -56,6 +57,8 @@ struct KParams {
     const int* matrix;
     int Q, A, Go, Ge;
     const unsigned char* res;  // residues of every sequence (item order = sorted by length, longest first), one byte each
+    unsigned char* resOut;     // not null: `res` is the pinned HOST staging buffer of a database seen for the first time (read
+                               // over PCIe while the DP runs); every token a lane decodes is also written here, the device copy
     const uint64_t* seqOff;    // [items] where each one starts
     const uint16_t* tokens;    // width 16 only: per pair (items 2p, 2p+1), column by column, residue of A | residue of B << 8
     const uint64_t* pairOff;   // width 16 only: [pairs] start of each pair's token stream
@@ -84,13 +87,14 @@ struct KParams {
     unsigned long long* tl;
 };
 
-// The two start stamps -- and the pointer itself -- wait in 32 bytes behind the workgroup's LDS data, so that nothing of
+// The two start stamps -- and the pointer itself -- wait in 48 bytes behind the workgroup's LDS data, so that nothing of
 // the probe is live in a register across the column loop (the 40-row kernels sit at 128 VGPRs).
-__device__ __forceinline__ void clk_begin(unsigned long long* clk, unsigned long long* tl, unsigned char* slot) {
+__device__ __forceinline__ void clk_begin(unsigned long long* clk, unsigned long long* tl, unsigned char* slot, unsigned char* resOut = nullptr) {
     if (threadIdx.x == 0) {
         unsigned long long* s = reinterpret_cast<unsigned long long*>(slot);
         s[2] = (unsigned long long)(uintptr_t)clk;
         s[3] = (unsigned long long)(uintptr_t)tl;
+        s[4] = (unsigned long long)(uintptr_t)resOut;  // (zero-copy search: see advance())
         if (clk || tl) { s[0] = (unsigned long long)clock64(); s[1] = (unsigned long long)wall_clock64(); }
     }
 }
@@ -416,8 +420,8 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
     const int CR = MULTI ? p.chunkRows : Q;
     const bool hasPrev = MULTI && (p.chunkFlags & 1), hasNext = MULTI && (p.chunkFlags & 2);
     const int padTop = (MODE == MODE_NW || hasPrev) ? 0 : (G * S - CR);
-    unsigned char* const clkSlot = lds + (size_t)(A + 1) * stride;  // (the launch reserves 32 bytes behind the profile)
-    clk_begin(p.clk, p.tl, clkSlot);
+    unsigned char* const clkSlot = lds + (size_t)(A + 1) * stride;  // (the launch reserves 48 bytes behind the profile)
+    clk_begin(p.clk, p.tl, clkSlot, p.resOut);
 
     // ---- stage the query profile in LDS: QP[letter][k][j] = M[query[k*S+j-padTop]][letter]; letter A = padding.
     // A thread owns (lane k, row j) positions and walks the letters: one query byte per position, then matrix reads
@@ -583,6 +587,14 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
         if ((sn & (G - 1)) == 0) {  // wave-uniform: refill the queue with columns sn .. sn+G-1
             const unsigned tok = tokNext;
             const int col = sn + k;
+            if constexpr (NH == 1 && MODE == MODE_SW && S <= (SWEND ? OPAL_ZERO_COPY_MAX_ROWS_SWEND : OPAL_ZERO_COPY_MAX_ROWS)) {
+                // Zero-copy search (KParams::resOut): the kernel is the copy engine (shapes of up to 38 rows per lane: the 39- and
+                // 40-row ones have no register to spare for the store's address). The pointer is read from the LDS slot
+                // every batch (volatile: not hoisted) -- as a kernel argument kept across the loop it cost the 40-row
+                // shapes two registers they do not have.
+                unsigned char* const ro = *reinterpret_cast<unsigned char* volatile*>(clkSlot + 32);
+                if (ro && col < slotLen) ro[tokBase + (uint64_t)col] = (unsigned char)tok;
+            }
             if (col + G < slotLen) tokNext = token(col + G);
 #pragma unroll
             for (int h = 0; h < NH; h++) {

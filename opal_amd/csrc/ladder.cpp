@@ -14,6 +14,7 @@ static void fill_launch(OpalHipLaunch& a, const SearchCtx& c, int width, int swE
     a.query = db->query.p; a.query_length = c.Q; a.score_matrix = db->matrix.p; a.alphabet_length = c.A;
     a.gap_open = c.Go; a.gap_ext = c.Ge;
     a.residues = c.zeroCopy ? db->hRaw.p : db->res.p; a.seq_offset = db->dSeqOff.p;  // (zeroCopy: sliced launches of a cold opalSearchDatabase call)
+    a.residues_out = c.zeroCopy ? db->res.p : nullptr;
     a.tokens = db->tokens.p; a.pair_token_offset = db->pairOff.p;  // (width 16 only: ensure_pair_tokens)
     a.pair_len = db->dPairLen.p; a.pair_seq = db->dPairSeq.p;
     a.work = work;
@@ -196,7 +197,11 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
     if (db->gate.active && !work && (width == 17 || width == 18) && db->gate.chunks() >= 4 && !getenv("OPAL_HIP_NO_SLICES")) {
         const UploadGate& g = db->gate;
         SearchCtx zc = c;
-        zc.zeroCopy = g.zeroCopy;  // (a database seen for the first time: the launches read the pinned staging buffer over PCIe)
+        bool shapesOk = c.mode == OPAL_MODE_SW;  // (the zero-copy store exists in the SW kernels of up to 38 rows only, 36 with end
+                                                // locations: the others have no register to spare for it -- dp_kernel.hpp)
+        for (const LaunchClass& k : classes) shapesOk = shapesOk && k.rows <= (swEndPass ? OPAL_ZERO_COPY_MAX_ROWS_SWEND : OPAL_ZERO_COPY_MAX_ROWS);
+        zc.zeroCopy = g.zeroCopy && shapesOk;  // (a database seen for the first time: the launches read the pinned staging buffer over PCIe ...
+        if (zc.zeroCopy && firstItem == 0 && numItems == 2 * db->numPairs) db->gate.kernelFilled = true;  // ... and write the device copy)
         // chunks per slice, the rest in the last one (C2: 17 chunks of 2 MB). The FIRST slice holds the long classes: its
         // longest sequence is the critical path of the whole search, so it is as small as it can be (it starts as soon as
         // one chunk has landed) and runs on a high-priority side stream of its own; the others take `main` and `aux` in

@@ -66,7 +66,7 @@ static int run_shard(int device, const unsigned char* query, int Q, unsigned cha
     if (!db_fill_finish(pdb)) return OPAL_ERR_NO_SIMD_SUPPORT;
     // (a zero-copy search did not wait for the chunk copies: whatever follows on `main` -- start cells, traceback -- reads the
     // device copy of the residues)
-    if (zeroCopied && startQ && startT && !wait_uploads(pdb, st)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    (void)zeroCopied;  // (its kernels wrote the device copy themselves, on streams joined into `main`; chunks copied on demand were waited for)
     if (fill_changed(pdb)) {
         // the database looked like the previous call's (same lengths) and was searched before its residues had been
         // compared; some differ: they are on the device by now (after the copy streams), the search is done again
@@ -77,6 +77,7 @@ static int run_shard(int device, const unsigned char* query, int Q, unsigned cha
                          /*finalSync=*/false);
     }
     const double t3 = now_ms();
+    if (rc == OPAL_ERR_NO_SIMD_SUPPORT || rc == OPAL_ERR_INVALID_MODE) pdb->lastValid = false;  // (the device copy may be incomplete)
     if (debug_on()) fprintf(stderr, "[opal] shard: launches issued %.3f ms after the fill began, pool done at %.3f ms\n", t2b - t1, t3 - t1);
     if (rc == OPAL_ERR_NO_SIMD_SUPPORT || rc == OPAL_ERR_INVALID_MODE) return rc;
     int* h = pdb->hResults.p;

@@ -124,7 +124,10 @@ struct UploadGate {
     std::unique_ptr<std::atomic<int>[]> dirty; // chunk c must be uploaded (always, unless the device already holds the same bytes)
     std::atomic<int> uploaded{0};              // chunks copied by this fill
     bool reuse = false;                        // this fill found the database of the previous call (same lengths)
-    bool zeroCopy = false;                     // the sliced launches of this fill's search read the pinned staging buffer directly
+    bool zeroCopy = false;                     // the sliced launches of this fill's search read the pinned staging buffer directly:
+                                               // the pool only gathers, a chunk is copied when something asks for its device copy (gate_items)
+    bool kernelFilled = false;                 // ... and they covered every item: the kernels have written the whole device copy
+    std::unique_ptr<std::atomic<int>[]> copied; // chunk c's copy has been enqueued
     bool speculated = false;                   // ... and its search was launched without waiting for the comparison
     size_t stateCap = 0;
     int chunks() const { return active ? (int)cutItem.size() - 1 : 0; }

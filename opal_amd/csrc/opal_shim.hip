@@ -284,7 +284,7 @@ static int raise_lds_limit(const void* fn) {
 
 static size_t lds_bytes(int width, int G, int rows, int A) {
     const int es = (width == 16 || width == 18) ? 2 : 4;  // widths 17 and 32 keep 4-byte profile entries
-    return (size_t)(A + 1) * (size_t)opal_profile_stride(es, G, rows, width == 18) + 32;  // (+32: clock-probe slot, dp_kernel.hpp)
+    return (size_t)(A + 1) * (size_t)opal_profile_stride(es, G, rows, width == 18) + 48;  // (+48: probe / zero-copy slot, dp_kernel.hpp)
 }
 
 extern "C" size_t opal_hip_lds_bytes(int width, int lanes_per_seq, int rows_per_lane, int alphabet_length) {
@@ -377,7 +377,7 @@ extern "C" int opal_hip_launch_uber(const OpalHipUberLaunch* u) {
     KParams& b = p.base;
     b.query = a->query; b.matrix = a->score_matrix; b.Q = a->query_length; b.A = a->alphabet_length;
     b.Go = a->gap_open; b.Ge = a->gap_ext;
-    b.res = a->residues; b.seqOff = a->seq_offset;
+    b.res = a->residues; b.seqOff = a->seq_offset; b.resOut = a->residues_out;
     b.tokens = a->tokens; b.pairOff = a->pair_token_offset; b.pairLen = a->pair_len; b.pairSeq = a->pair_seq;
     b.work = nullptr;
     b.outScore = a->out_score; b.outEndQ = a->out_end_query; b.outEndT = a->out_end_target;
@@ -430,7 +430,7 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
     memset(&p, 0, sizeof p);
     p.query = a->query; p.matrix = a->score_matrix; p.Q = a->query_length; p.A = a->alphabet_length;
     p.Go = a->gap_open; p.Ge = a->gap_ext;
-    p.res = a->residues; p.seqOff = a->seq_offset;
+    p.res = a->residues; p.seqOff = a->seq_offset; p.resOut = a->residues_out;
     p.tokens = a->tokens; p.pairOff = a->pair_token_offset; p.pairLen = a->pair_len; p.pairSeq = a->pair_seq;
     p.work = a->work; p.firstItem = a->first_item; p.numItems = a->num_items; p.log2G = log2G;
     p.outScore = a->out_score; p.outEndQ = a->out_end_query; p.outEndT = a->out_end_target;

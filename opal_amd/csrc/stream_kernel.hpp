@@ -53,7 +53,7 @@ __host__ __device__ inline int opal_stream_stride(int G, int S) {
 }
 template <int WIDTH>
 __host__ __device__ inline size_t opal_stream_lds_bytes(int G, int S, int A) {
-    return (size_t)(A + 3) * (size_t)opal_stream_stride<WIDTH>(G, S) + (size_t)STREAM_WAVES * (64 / G) * STREAM_RING * STREAM_DESC_BYTES + 32;  // (+32: clock-probe slot)
+    return (size_t)(A + 3) * (size_t)opal_stream_stride<WIDTH>(G, S) + (size_t)STREAM_WAVES * (64 / G) * STREAM_RING * STREAM_DESC_BYTES + 48;  // (+48: probe slot)
 }
 
 
@@ -390,7 +390,7 @@ __host__ __device__ inline int opal_gl_init_entries(int S) { return 2 * ((S + 3)
 template <int WIDTH>
 __host__ __device__ inline size_t opal_gl_stream_lds_bytes(int G, int S, int A) {
     return (size_t)(A + 1) * (size_t)opal_gl_stream_stride<WIDTH>(G, S) + (size_t)G * opal_gl_init_entries(S) * 4 +
-           (size_t)STREAM_WAVES * (64 / G) * STREAM_RING * STREAM_DESC_BYTES + 32;  // (+32: clock-probe slot)
+           (size_t)STREAM_WAVES * (64 / G) * STREAM_RING * STREAM_DESC_BYTES + 48;  // (+48: probe slot)
 }
 
 template <int WIDTH, int MODE, int S>
