@@ -1050,4 +1050,5 @@ KernelFn opal_kernel_s18(int mode, int flags, int rows);   // width 18 (2-byte p
 KernelFn opal_kernel_s16skew(int mode, int rows);           // width 17, NW/HW/OV, FLAG_SKEW: rows 1..40
 KernelFn opal_kernel_s16(int mode, int flags, int rows);  // width 17, other variants incl. FLAG_MULTI: rows 4,8,..,40
 KernelFn opal_kernel_w16_multi(int mode, int flags, int rows);  // FLAG_MULTI variants
+KernelFn opal_kernel_s18_multi(int mode, int flags, int rows);  // width 18, FLAG_MULTI: rows 8,16,24,32
 KernelFn opal_kernel_w32_multi(int mode, int flags, int rows);

@@ -30,38 +30,32 @@ static void fill_launch(OpalHipLaunch& a, const SearchCtx& c, int width, int swE
 // beyond the 160 KiB of LDS): the query is cut into row chunks processed top to bottom by one launch each;
 // the bottom row of a chunk (H and the F input of the next row, per column) travels through HBM.
 static int launch_chunked(const SearchCtx& c, int width, int swEndPass, int detectWrap, const int* work, int firstItem,
-                          int numItems, int* ovfCounter) {
-    int bestG = 0, bestS = 0;
-    for (int G = 64; G >= 1; G /= 2)
-        for (int S = OPAL_HIP_MAX_ROWS; S >= 1; S--) {
-            if (opal_hip_rows_supported(width, c.mode, swEndPass | 2, S) != S) continue;
-            if (opal_hip_lds_bytes(width, G, S, c.A) > 160 * 1024) continue;
-            if ((long long)G * S > (long long)bestG * bestS) { bestG = G; bestS = S; }
-            break;  // largest S for this G
-        }
-    if (const char* geo = getenv("OPAL_HIP_CHUNK_GEOMETRY")) {  // "G,S": test hook to force small chunks
-        int g = 0, r = 0;
-        if (sscanf(geo, "%d,%d", &g, &r) == 2 && opal_hip_rows_supported(width, c.mode, swEndPass | 2, r) == r &&
-            opal_hip_lds_bytes(width, g, r, c.A) <= 160 * 1024) { bestG = g; bestS = r; }
-    }
-    if (!bestG) {
+                          int numItems, LenView lenOf, int* ovfCounter) {
+    OpalxDb* db = c.db;
+    int bestG = 0, bestS = 0, wpb = 4;
+    // the items of THIS range (a re-run list, the 32-bit prefix of a global-mode search: a handful of long sequences, which
+    // want every lane on one sequence; the whole database: the bulk decides): longest first, mean from a sample
+    double meanLen = 0;
+    const int sampleStep = std::max(1, numItems / 256);
+    int sampled = 0;
+    for (int i = 0; i < numItems; i += sampleStep, sampled++) meanLen += lenOf(firstItem + i);
+    meanLen /= std::max(sampled, 1);
+    if (!plan_chunks(width, c.mode, swEndPass, c.Q, c.A, numItems, meanLen, numItems > 0 ? lenOf(firstItem) : 0, &bestG, &bestS, &wpb)) {
         fprintf(stderr, "[opal] alphabet of %d letters does not fit the on-chip query profile at width %d\n", c.A, width);
         return OPAL_ERR_NO_SIMD_SUPPORT;
     }
-    OpalxDb* db = c.db;
+    if (const char* geo = getenv("OPAL_HIP_CHUNK_GEOMETRY")) {  // "G,S": test hook to force small chunks
+        int g = 0, r = 0, ldsPad = 0;
+        if (sscanf(geo, "%d,%d", &g, &r) == 2 && opal_hip_rows_supported(width, c.mode, swEndPass | 2, r) == r &&
+            opal_hip_lds_bytes(width, g, r, c.A) <= 160 * 1024) {
+            bestG = g; bestS = r;
+            pick_occupancy(kernel_vgprs(width, c.mode, swEndPass, 1, 0, bestS), opal_hip_lds_bytes(width, bestG, bestS, c.A), &wpb, &ldsPad,
+                           opal_hip_max_waves_per_block(width));
+        }
+    }
     // (8 bytes per column of every item's -- width 16: every pair's -- residue stream)
     if (!db->boundary.ensure(8 * ((size_t)db->residues + 16)) || !db->scratch.ensure(2 * (size_t)std::max(db->numSeqs, 1)))
         return OPAL_ERR_NO_SIMD_SUPPORT;
-    int wpb = 4, ldsPad = 0;
-    pick_occupancy(kernel_vgprs(width, c.mode, swEndPass, 1, 0, bestS), opal_hip_lds_bytes(width, bestG, bestS, c.A), &wpb, &ldsPad);
-    // Equal chunks: with nchunks passes needed anyway, the smallest rows-per-lane value that still covers Q in that many
-    // passes (a 3000-aa query ran as 440 + 2560 rows at 40 rows per lane, 2 900 GCUPS; as 2 x 1500 at 24 rows per lane ...)
-    if (!getenv("OPAL_HIP_CHUNK_GEOMETRY")) {
-        const int passes = (c.Q + bestG * bestS - 1) / (bestG * bestS);
-        const int need = ((c.Q + passes - 1) / passes + bestG - 1) / bestG;  // rows per lane of a balanced chunk
-        const int rows = opal_hip_rows_supported(width, c.mode, swEndPass | 2, need);
-        if (rows && rows < bestS) bestS = rows;
-    }
     const int cap = bestG * bestS;
     const int nchunks = (c.Q + cap - 1) / cap;
     const int firstRows = c.Q - (nchunks - 1) * cap;  // SW/HW/OV: the partial chunk is the first one
@@ -155,7 +149,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
     }
     if (classes.empty() || getenv("OPAL_HIP_FORCE_CHUNKS")) {
         if (!gate_items(db, db->main(), 0, 2 * db->numPairs)) return OPAL_ERR_NO_SIMD_SUPPORT;
-        return launch_chunked(c, width, swEndPass, detectWrap, work, firstItem, numItems, ovfCounter);
+        return launch_chunked(c, width, swEndPass, detectWrap, work, firstItem, numItems, lenOf, ovfCounter);
     }
     // Can the classes run as one grid? (bulk on G0 lanes, the others on 2*G0 and 4*G0, all on the same arithmetic)
     const LaunchClass& bulk = classes.back();
@@ -453,6 +447,13 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                 narrow = 18;
         }
         if (narrow == 18 && !fits(18)) narrow = 16;
+        // Queries that no single launch holds at any width (more than 64 lanes x 40 rows) run in row chunks: on the plain
+        // kernels with 2-byte profile entries, whose chunk profiles leave room for twice the waves of the 4-byte ones and which,
+        // unlike the packed pairs, issue at full rate (3000-aa query x 100 000 sequences: ... GCUPS against 5 260 at width 16)
+        if (!getenv("OPAL_HIP_NARROW") && !(force && atoi(force) == 17) && !fits(17) && !fits(18) && !fits(16)) {
+            narrow = mode == OPAL_MODE_HW ? 17 : 18;  // (HW: no 2-byte-profile chunk kernels beyond 16 rows per lane, inst_s18multi.hip)
+            if (const char* cw = getenv("OPAL_HIP_CHUNK_WIDTH")) { const int v = atoi(cw); if (v == 16 || v == 17 || v == 18) narrow = v; }
+        }
     }
     // SW score-only searches with long queries stream their sequences through persistent waves (plain 16-bit arithmetic)
     StreamPlan splan;
@@ -491,7 +492,25 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                 a.first_item = 0; a.num_items = 2 * P;
                 if (debug_on())
                     fprintf(stderr, "[opal] streaming launch width=%d G=%d rows=%d end=%d items=%d\n", splan.width, splan.G, splan.rows, wantEnd, 2 * P);
-                rc = (!gate_items(db, st, 0, 2 * P) || opal_hip_launch_stream(&a, db->ovfCount.p + 2)) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
+                if (!gate_items(db, st, 0, 2 * P)) return OPAL_ERR_NO_SIMD_SUPPORT;
+                if (splan.passes > 1) {
+                    // a query beyond one wave: row chunks from the top, the first one partial (as launch_chunked cuts them), a
+                    // chunk's bottom row through db->boundary (4 bytes per residue), the hand-out counter zeroed in between
+                    if (!db->boundary.ensure(8 * ((size_t)db->residues + 16))) return OPAL_ERR_NO_SIMD_SUPPORT;
+                    const int cap = splan.G * splan.rows;
+                    const int firstRows = Q - (splan.passes - 1) * cap;
+                    for (int ch = 0; ch < splan.passes && !rc; ch++) {
+                        a.chunk_flags = (ch > 0 ? 1 : 0) | (ch < splan.passes - 1 ? 2 : 0);
+                        a.chunk_row0 = ch == 0 ? 0 : firstRows + (ch - 1) * cap;
+                        a.chunk_rows = ch == 0 ? firstRows : cap;
+                        a.boundary = db->boundary.p;
+                        if (debug_on()) fprintf(stderr, "[opal] streaming chunk %d/%d rows [%d,+%d)\n", ch + 1, splan.passes, a.chunk_row0, a.chunk_rows);
+                        if (ch > 0 && opal_hip_memset32(db->ovfCount.p + 2, 0, 1, st)) return OPAL_ERR_NO_SIMD_SUPPORT;
+                        rc = opal_hip_launch_stream(&a, db->ovfCount.p + 2) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
+                        count(CNT_CHUNK_LAUNCHES);
+                    }
+                } else
+                rc = opal_hip_launch_stream(&a, db->ovfCount.p + 2) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
                 count(CNT_STREAM_SW);
             }
             else if (narrow == 16) rc = launch_range(c, 16, wantEnd, 0, nullptr, 0, nNarrow, pairLenOf, db->ovfCount.p);

@@ -337,7 +337,8 @@ int kernel_vgprs(int width, int mode, int swEndPass, int multi, int skew, int ro
 int pick_occupancy(int vgprs, size_t ldsBytes, int* wpbOut, int* ldsPadOut, int maxWpb = 8);
 std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass, int skew, int Q, int A, LenView lenOf, int first,
                                       int count, int maxGFactor = 0);
-struct StreamPlan { int width = 0, G = 0, rows = 0; };
+bool plan_chunks(int width, int mode, int swEndPass, int Q, int A, long long nItems, double meanLen, int maxLen, int* G, int* rows, int* wpb);
+struct StreamPlan { int width = 0, G = 0, rows = 0, passes = 1; };  // passes > 1: the query runs in that many row chunks
 StreamPlan plan_stream(int Q, int A, int mode, int wantEnd, long long residues, int longest, int numSeqs);
 
 bool args_fit_int32(int Go, int Ge, const int* M, int A);

@@ -295,6 +295,7 @@ static KernelFn pick_kernel(int width, int mode, int flags, int rows) {
     if (flags & FLAG_MULTI) {
         if (width == 16) return opal_kernel_w16_multi(mode, flags, rows);
         if (width == 17) return opal_kernel_s16(mode, flags, rows);
+        if (width == 18) return opal_kernel_s18(mode, flags, rows);
         if (width == 32) return opal_kernel_w32_multi(mode, flags, rows);
         return nullptr;
     }
@@ -464,7 +465,8 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
 }
 
 // ------------------------------------------------------------------ streaming SW score search (stream_kernel.hpp)
-static StreamFn pick_stream(int width, int mode, int want_end, int rows) {
+static StreamFn pick_stream(int width, int mode, int want_end, int rows, int chunked = 0) {
+    if (chunked) return (mode == MODE_SW && !want_end && width == 17) ? opal_stream_s17chunk(rows) : nullptr;
     if (mode != MODE_SW) {
         if (width == 17) return opal_stream_gl17(mode, rows);
         if (width == 18) return opal_stream_gl18(mode, rows);
@@ -479,8 +481,9 @@ static size_t stream_lds_bytes(int width, int mode, int G, int rows, int A) {
     return width == 18 ? opal_stream_lds_bytes<18>(G, rows, A) : opal_stream_lds_bytes<17>(G, rows, A);
 }
 extern "C" int opal_hip_stream_rows_supported(int width, int mode, int want_end, int min_rows) {
+    /* bit1 of want_end: ask about the row-chunk variants (as opal_hip_rows_supported does) */
     for (int r = min_rows < 1 ? 1 : min_rows; r <= OPAL_HIP_MAX_ROWS; r++)
-        if (pick_stream(width, mode, want_end, r)) return r;
+        if (pick_stream(width, mode, want_end & 1, r, want_end & 2)) return r;
     return 0;
 }
 extern "C" size_t opal_hip_stream_lds_bytes(int width, int mode, int lanes_per_seq, int rows_per_lane, int alphabet_length) {
@@ -491,10 +494,12 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
     int log2G = 0;
     while ((1 << log2G) < G) log2G++;
     StreamFn fn = nullptr;
-    if ((1 << log2G) == G && G <= 64 && a->mode >= 0 && a->mode <= 3 && !a->work && !a->chunk_flags && next_counter &&
+    if ((1 << log2G) == G && G <= 64 && a->mode >= 0 && a->mode <= 3 && !a->work && next_counter &&
         (!a->want_end || (a->out_end_query && a->out_end_target)) &&
-        a->query_length >= 1 && (long long)G * a->rows_per_lane >= a->query_length)
-        fn = pick_stream(a->width, a->mode, a->want_end, a->rows_per_lane);
+        a->query_length >= 1 && (long long)G * a->rows_per_lane >= (a->chunk_flags ? a->chunk_rows : a->query_length) &&
+        (!a->chunk_flags || (a->boundary && a->chunk_rows >= 1 && a->chunk_row0 >= 0 && a->chunk_row0 + a->chunk_rows <= a->query_length &&
+                             ((a->chunk_flags & 1) == 0 || a->chunk_rows == G * a->rows_per_lane))))  /* only the first chunk may be partial */
+        fn = pick_stream(a->width, a->mode, a->want_end, a->rows_per_lane, a->chunk_flags);
     if (!fn) {
         snprintf(g_err, sizeof g_err, "unlaunchable streaming shape: width=%d G=%d rows=%d Q=%d", a->width, G, a->rows_per_lane, a->query_length);
         fprintf(stderr, "[opal-hip] %s\n", g_err);
@@ -520,7 +525,10 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
     p.firstItem = a->first_item; p.numItems = a->num_items; p.log2G = log2G;
     p.outScore = a->out_score; p.outEndQ = a->out_end_query; p.outEndT = a->out_end_target;  /* (SW score only: NULL) */
     p.ovfCount = a->overflow_count; p.ovfItems = a->overflow_items;
-    p.chunkRows = a->query_length;
+    p.q0 = a->chunk_flags ? a->chunk_row0 : 0;
+    p.chunkRows = a->chunk_flags ? a->chunk_rows : a->query_length;
+    p.chunkFlags = a->chunk_flags;
+    p.bnd = (uint2*)a->boundary;
     p.satLimit = a->sat_limit; p.negPad = a->neg_pad;
     p.clk = a->clock_probe; p.tl = a->timeline;
     sp.next = next_counter;

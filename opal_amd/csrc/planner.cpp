@@ -86,6 +86,41 @@ int pick_occupancy(int vgprs, size_t ldsBytes, int* wpbOut, int* ldsPadOut, int 
     return bestW;
 }
 /*
+ * Wave geometry of a query that runs in row chunks (launch_chunked): every geometry G x rows of the width is priced the way
+ * plan_classes prices a class -- per-step overhead, fill and drain of the G-lane pipeline against the mean sequence
+ * length, waves per SIMD that the chunk's profile leaves room for, and the longest sequence alone on its wave, once per
+ * pass -- with the rows per lane lowered to the smallest value that still covers the query in the same number of passes
+ * (equal chunks). Measured, 3000-aa query x 100 000 sequences, ms per search: 32 x 32 19.0, 16 x 32 19.7, 64 x 24 21.0,
+ * 8 x 32 41.1 (width 18; the model: 18.1 : 19.3 : 20.4 : 38.5).
+ */
+bool plan_chunks(int width, int mode, int swEndPass, int Q, int A, long long nItems, double meanLen, int maxLen, int* Gout, int* rowsOut, int* wpbOut) {
+    double bestClocks = 0;
+    for (int G = 1; G <= 64; G *= 2)
+        for (int S = OPAL_HIP_MAX_ROWS; S >= 1; S--) {
+            if (opal_hip_rows_supported(width, mode, swEndPass | 2, S) != S) continue;
+            if (opal_hip_lds_bytes(width, G, S, A) > 160 * 1024) continue;
+            const int passes = (Q + G * S - 1) / (G * S);
+            const int need = ((Q + passes - 1) / passes + G - 1) / G;  // rows per lane of a balanced chunk
+            const int rows = opal_hip_rows_supported(width, mode, swEndPass | 2, need);
+            if (!rows || rows > S) continue;
+            int wpb = 4, ldsPad = 0;
+            const int waves = pick_occupancy(kernel_vgprs(width, mode, swEndPass, 1, 0, rows), opal_hip_lds_bytes(width, G, rows, A), &wpb, &ldsPad,
+                                             opal_hip_max_waves_per_block(width));
+            // one pass: every item's len+G-1 steps on G of a wave's 64 lanes over 1024 SIMDs -- or the longest item's steps at the
+            // lone-wave rate if that takes longer (passes run one after the other: each needs the boundary row of the one above)
+            const double bulk = (double)nItems * (meanLen + G - 1) * G / 64.0 * step_clocks(width, rows) / 1024.0 / issue_factor(waves);
+            const double tail = ((double)maxLen + G - 1) * lone_step_clocks(width, rows);
+            // (the two overlap, but not for free: measured passes take the larger of the two plus about a third of the smaller)
+            const double clocks = passes * (std::max(bulk, tail) + 0.35 * std::min(bulk, tail) + 24000.0);
+            if (debug_on())
+                fprintf(stderr, "[opal] chunk plan width=%d G=%d rows=%d: %d passes, %d waves/SIMD (waves/block %d), bulk %.0f tail %.0f -> %.0f clocks\n",
+                        width, G, rows, passes, waves, wpb, bulk, tail, clocks);
+            if (bestClocks == 0 || clocks < bestClocks) { bestClocks = clocks; *Gout = G; *rowsOut = rows; *wpbOut = wpb; }
+        }
+    return bestClocks > 0;
+}
+
+/*
  * Split the item range [first, first+count) (sorted by length, longest first) into classes of
  * equal wave geometry. Each sequence (pair) is spread over G lanes; a wave therefore needs
  * len+G-1 column steps of `rows` rows each. Short sequences want a small G (little fill/drain and
@@ -218,15 +253,46 @@ StreamPlan plan_stream(int Q, int A, int mode, int wantEnd, long long residues, 
             if (cost < bestCost) { bestCost = cost; best.width = width; best.G = G; best.rows = rows; }
         }
     }
+    if (!best.G && mode == OPAL_MODE_SW && !wantEnd && !(forceW && *forceW) && !getenv("OPAL_HIP_NO_STREAM_CHUNKS")) {
+        // No single launch holds the query (more than 64 lanes x 40 rows, or a profile beyond LDS): row chunks, one streaming
+        // launch each (stream_kernel.hpp, CHUNK), equal chunks at the fewest passes each geometry allows.
+        for (int G = 16; G <= 64; G *= 2) {
+            if (forceG && *forceG && atoi(forceG) != G) continue;
+            int cap = 0;
+            for (int S = OPAL_HIP_MAX_ROWS; S >= 1 && !cap; S--)
+                if (opal_hip_stream_rows_supported(17, mode, 2, S) == S && opal_hip_stream_lds_bytes(17, mode, G, S, A) <= 160 * 1024) cap = S;
+            if (!cap) continue;
+            const int passes = (Q + G * cap - 1) / (G * cap);
+            const int need = ((Q + passes - 1) / passes + G - 1) / G;
+            const int rows = opal_hip_stream_rows_supported(17, mode, 2, need);
+            if (!rows || rows > cap) continue;
+            const double cost = passes * (9.0 * rows + 36.0) * G / Q;
+            // the longest sequence alone on its lanes against the whole pass, as below (the alternative here are the class
+            // kernels' chunks, which no geometry brings beyond 0.60-0.65 of the issue bound: 3000-aa query, 100 000 sequences)
+            const double stepInstr = 9.0 * rows + 36.0;
+            const double total = (double)residues * G / 64.0 * stepInstr * 2.15 / 1024.0;
+            const double crit = ((double)longest + G) * stepInstr * 3.5;
+            if (!force && crit > (G >= 32 ? 1.5 : 0.5) * total) continue;
+            if (cost < bestCost) { bestCost = cost; best.width = 17; best.G = G; best.rows = rows; best.passes = passes; }
+        }
+    }
+    if (const char* sc = getenv("OPAL_HIP_STREAM_CHUNKS")) {  // "G,S": test hook -- row chunks of G x S rows whatever the query length
+        int g = 0, r = 0;
+        if (mode == OPAL_MODE_SW && !wantEnd && sscanf(sc, "%d,%d", &g, &r) == 2 && g >= 1 && g <= 64 && (g & (g - 1)) == 0 &&
+            opal_hip_stream_rows_supported(17, mode, 2, r) == r && opal_hip_stream_lds_bytes(17, mode, g, r, A) <= 160 * 1024 && Q > g * r) {
+            best.width = 17; best.G = g; best.rows = r; best.passes = (Q + g * r - 1) / (g * r);
+            return best;
+        }
+    }
     if (best.G && !force && (wantEnd || mode != OPAL_MODE_SW) && best.G < 32) best = StreamPlan();  // (end locations, NW/HW/OV at 16 lanes or fewer: class kernels, unmeasured otherwise)
-    if (best.G && !force) {
+    if (best.G && !force && best.passes == 1) {
         // A sequence stays on its G lanes from its first column to its last: the longest one (handed out first) sets a
         // floor of (longest + G) steps at the rate of a wave that ends up alone on its SIMD (~3.5 clk per instruction).
         // On a small database that floor exceeds the time of the whole search and the class kernels (4*G lanes for
         // the longest sequences) win: measured with 20 000 sequences, 1000-aa query 2.6 ms against 1.7 ms; with 100 000
         // sequences 4.9 ms against 7.0 ms.
         const double stepInstr = (best.width == 18 ? 9.5 : 9.0) * best.rows + 30.0;
-        const double total = (double)residues * best.G / 64.0 * stepInstr * 2.15 / 1024.0;
+        const double total = (double)residues * best.G / 64.0 * stepInstr * 2.15 / 1024.0;  // (of one pass; so is crit)
         const double crit = ((double)longest + best.G) * stepInstr * 3.5;
         if (best.G >= 32) {
             if (crit > 1.5 * total) best = StreamPlan();

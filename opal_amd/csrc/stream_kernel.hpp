@@ -65,6 +65,7 @@ struct SlotStream {
     int lastEnd = 0;      // end of the last real entry
     bool done = false;
     unsigned tokNext = 0;  // letter of the position fetched last
+    unsigned bndNext = 0;  // row-chunked queries: the chunk boundary {H, F input} above that position (0: none)
 };
 
 // Token of stream position x for lane k of a slot (x - k is a multiple of G; called by all lanes of the wave together):
@@ -74,7 +75,7 @@ struct SlotStream {
 // sequence; an entry spans at least 2G positions (pad columns after short sequences), which is what bounds the look-up
 // to two descriptors and the ring to four.
 // Descriptor: {start, len, caller index, -, residue offset lo, hi, item, running maximum (SW with end locations)}.
-template <int SEPS>
+template <int SEPS, bool BND = false>
 __device__ __forceinline__ void stream_fetch(SlotStream& st, const KParams& p, int* next, int* ring, const int x, const int k,
                                              const int G, const int slotLane0, const int PAD) {
     const int base = x - k;
@@ -110,7 +111,7 @@ __device__ __forceinline__ void stream_fetch(SlotStream& st, const KParams& p, i
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    unsigned tok = (unsigned)PAD;
+    unsigned tok = (unsigned)PAD, bnd = 0;
     if (st.nEntries > 0 && x < st.lastEnd) {
         const int e = (x >= st.curStart) ? (st.nEntries - 1) : (st.nEntries - 2);
         const int* d = ring + (e & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4);
@@ -119,14 +120,24 @@ __device__ __forceinline__ void stream_fetch(SlotStream& st, const KParams& p, i
         if (col < d0.y) {
             const uint64_t tb = (uint64_t)(unsigned)d[4] | ((uint64_t)(unsigned)d[5] << 32);
             tok = p.res[tb + (uint64_t)col];
+            if constexpr (BND) { if (p.chunkFlags & 1) bnd = reinterpret_cast<const unsigned*>(p.bnd)[tb + (uint64_t)col]; }
         } else if (SEPS >= 1 && col == d0.y) tok = (unsigned)(PAD + 1);
         else if (SEPS >= 2 && col == d0.y + 1) tok = (unsigned)(PAD + 2);
     }
     st.tokNext = tok;
+    st.bndNext = bnd;
 }
 
-template <int WIDTH, int S, bool SWEND = false>
+// CHUNK (score searches): the launch covers query rows [q0, q0 + chunkRows) of a query beyond one wave (more than 64 lanes
+// x 40 rows, or a profile beyond LDS), one launch per row chunk from the top. The chunk's bottom row -- H and the F input
+// of the row below, 16 bits each in one word per column, at the column's residue offset -- goes through p.bnd: lane 0
+// takes its top inputs from the word the chunk above left (fetched with the letter, a batch ahead, and handed to lane 0
+// through the same lane queue), the last lane's outputs are collected in a second lane queue and stored once per batch,
+// every lane one column. Separator and pad columns carry zeros, as the top boundary of local alignment does everywhere.
+// A sequence's score is the maximum over the chunks (read-modify-write of outScore: one chunk at a time).
+template <int WIDTH, int S, bool SWEND = false, bool CHUNK = false>
 __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const StreamParams sp) {
+    static_assert(!(SWEND && CHUNK), "row chunks: score searches only");
     using V = Vec<WIDTH>;
     using reg = typename V::reg;
     using elem = typename V::elem;
@@ -140,8 +151,11 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     const int log2G = p.log2G;
     const int G = 1 << log2G;
     const int stride = opal_stream_stride<WIDTH>(G, S);
-    const int Q = p.Q, A = p.A;
-    const int padTop = G * S - Q;  // virtual rows above the query (profile 0: H, E, F stay 0 there)
+    const int A = p.A;
+    const int q0 = CHUNK ? p.q0 : 0;              // first query row of this launch
+    const int Q = CHUNK ? p.chunkRows : p.Q;      // ... and how many it covers
+    const bool hasPrev = CHUNK && (p.chunkFlags & 1), hasNext = CHUNK && (p.chunkFlags & 2);
+    const int padTop = G * S - Q;  // virtual rows above the query (profile 0: H, E, F stay 0 there; first chunk only)
     const int PAD = A, SEP1 = A + 1, SEP2 = A + 2;
     unsigned char* const clkSlot = lds + (size_t)(A + 3) * stride + (size_t)STREAM_WAVES * (64 >> log2G) * STREAM_RING * STREAM_DESC_BYTES;
     clk_begin(p.clk, p.tl, clkSlot);
@@ -156,7 +170,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
             const bool real = lr >= 0 && j < S;
             unsigned char* dst = lds + k * LANE_BYTES + j * ES;
             if (real) {
-                const int* mrow = p.matrix + (int)p.query[lr] * A;
+                const int* mrow = p.matrix + (int)p.query[q0 + lr] * A;
                 for (int letter = 0; letter < A; letter += 2) {
                     const int l1 = min(letter + 1, A - 1);
                     const int v0 = mrow[letter], v1 = mrow[l1];
@@ -214,21 +228,54 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     int outCol = INT_MAX, outRow = -1;
     const int r0 = k * S - padTop;  // query row held in register 0
 
-    auto fetch = [&](const int x) { stream_fetch<2>(st, p, sp.next, ring, x, k, G, slotLane0, PAD); };
+    auto fetch = [&](const int x) { stream_fetch<2, CHUNK>(st, p, sp.next, ring, x, k, G, slotLane0, PAD); };
     fetch(k);
+    unsigned bndq = 0;  // CHUNK: lane queue of the boundary words above the columns of this batch (lane 0 consumes)
+    unsigned outq = 0;  // CHUNK: lane queue of the last lane's outputs, oldest towards lane 0
 
     for (int s = 0;; s++) {
         if ((s & (G - 1)) == 0) {  // wave-uniform: refill the queue with columns s .. s+G-1, fetch those of the next batch
             const unsigned letter = st.tokNext;
+            const unsigned above = st.bndNext;
+            if constexpr (CHUNK) {
+                // The last lane's outputs were pushed at the start of each of the G steps behind us (position x leaves it in step
+                // x+G-1): lane j holds the word of position s-2G+j. The positions [s-2G, s+G) touch at most three ring entries (an
+                // entry spans at least 2G positions): the newest three.
+                const int xo = s - 2 * G + k;
+                if (hasNext && xo >= 0 && st.nEntries > 0 && xo < st.lastEnd) {
+                    int e = st.nEntries - 1;
+                    const int* d = ring + (e & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4);
+                    if (xo < d[0] && e > 0) { e--; d = ring + (e & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4); }
+                    if (xo < d[0] && e > 0) { e--; d = ring + (e & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4); }
+                    const int col = xo - d[0];
+                    if (col >= 0 && col < d[1]) {
+                        const uint64_t tb = (uint64_t)(unsigned)d[4] | ((uint64_t)(unsigned)d[5] << 32);
+                        reinterpret_cast<unsigned*>(p.bnd)[tb + (uint64_t)col] = outq;
+                    }
+                }
+            }
             fetch(s + G + k);
             tokq = ldsBase + letter * (unsigned)stride;
-            // every slot has run dry and its last separator has left the last lane
+            bndq = above;
+            // every slot has run dry and its last separator has left the last lane (CHUNK: the store above covered the positions
+            // up to s-G-1, i.e. everything before lastEnd)
             if (__ballot(!(st.done && s >= st.lastEnd + G)) == 0ull) break;
+        }
+        if constexpr (CHUNK) {  // the last lane's outputs of the step behind us join the queue
+            const unsigned mine = ((unsigned)outH & 0xffffu) | ((unsigned)outF << 16);
+            const unsigned shifted = shl1(outq);
+            outq = (k == G - 1) ? mine : shifted;
         }
         reg inH = (reg)shr1((unsigned)outH);
         reg inF = (reg)shr1((unsigned)outF);
-        inH = (k == 0) ? (reg)0 : inH;  // top boundary of local alignment
-        inF = (k == 0) ? (reg)0 : inF;
+        if constexpr (CHUNK) {  // top boundary: what the chunk above left for this column (zeros in the first chunk)
+            inH = (k == 0) ? (reg)(bndq & 0xffffu) : inH;
+            inF = (k == 0) ? (reg)(bndq >> 16) : inF;
+            bndq = shl1(bndq);
+        } else {
+            inH = (k == 0) ? (reg)0 : inH;  // top boundary of local alignment
+            inF = (k == 0) ? (reg)0 : inF;
+        }
         {
             const unsigned shifted = shr1(offv) + (unsigned)LANE_BYTES;
             offv = (k == 0) ? tokq : shifted;
@@ -348,7 +395,21 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
                 if (k == G - 1) {
                     const int seq = d[2];
                     if constexpr (!SWEND) flushCount++;
-                    if (seq >= 0) {
+                    if (CHUNK && seq >= 0) {
+                        // maximum over the chunks; a score at the saturation limit is listed for the 32-bit re-run once, by the
+                        // first chunk that sees it, and marked for the chunks below (as the class kernels do, dp_kernel.hpp)
+                        const int prev = hasPrev ? p.outScore[seq] : 0;
+                        const int sc = prev > outM ? prev : outM;
+                        if (sc >= p.satLimit) {
+                            if (!(hasPrev && prev >= p.satLimit)) {
+                                const int at = atomicAdd(p.ovfCount, 1);
+                                p.ovfItems[at] = d[6];
+                            }
+                            p.outScore[seq] = p.satLimit;
+                        } else {
+                            p.outScore[seq] = sc;
+                        }
+                    } else if (seq >= 0) {
                         if (outM >= p.satLimit) {  // (opal.cpp:364-370): hand over to width 32
                             const int at = atomicAdd(p.ovfCount, 1);
                             p.ovfItems[at] = d[6];
@@ -672,6 +733,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
 }
 
 StreamFn opal_stream_s17(int rows);     // width 17 (4-byte profile entries), score only: rows 1..40
+StreamFn opal_stream_s17chunk(int rows);  // one row chunk of a longer query (CHUNK), width 17, score only: rows 16..40
 StreamFn opal_stream_s18(int rows);     // width 18 (2-byte entries), score only: rows 20..40
 StreamFn opal_stream_s17end(int rows);  // with end locations: rows 1..36
 StreamFn opal_stream_s18end(int rows);  // rows 20..36

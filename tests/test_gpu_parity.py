@@ -301,11 +301,15 @@ def test_dropin_cli_output_equals_reference_cli(mode, level):
     assert la == lb
 
 
-@pytest.mark.parametrize("geometry", ["2,8", "8,8", "1,16", "64,8", "4,40"])
+@pytest.mark.parametrize("geometry,narrow", [("2,8", None), ("8,8", None), ("1,16", None), ("64,8", None), ("4,40", None),
+                                             ("2,8", "18"), ("16,8", "18"), ("1,24", "18"), ("4,32", "18"), ("2,8", "16"), ("4,40", "16")])
 @pytest.mark.parametrize("mode", ["SW", "NW", "HW", "OV"])
-def test_query_chunks_forced(geometry, mode, ours, oracle, monkeypatch):
+def test_query_chunks_forced(geometry, narrow, mode, ours, oracle, monkeypatch):
     """Long-query path on short inputs: force the query to be cut into many row chunks (boundary row through
-    HBM) and compare with the oracle, 16-bit and 32-bit kernels, score and end locations."""
+    HBM) and compare with the oracle, 16-bit (plain with 4- and 2-byte profile entries, packed pairs) and 32-bit
+    kernels, score and end locations."""
+    if narrow:
+        monkeypatch.setenv("OPAL_HIP_NARROW", narrow)
     from opal_amd import synth
     from opal_amd.score_matrix import blosum50
     res, offs, lens = synth.database(90, seed=321)
@@ -513,6 +517,57 @@ def test_streaming_sw_score_kernels(qlen, lanes, narrow, ours, oracle, monkeypat
             # with end locations (the streaming kernels exist up to 36 rows per lane; beyond that the class kernels answer)
             got = ours.search(q, db, go, ge, m, 1, MODES["SW"])[:4]
             _check(got, oracle.search(q, db, go, ge, m, 1, MODES["SW"]), "SW", f"stream+end q{qlen} G={lanes} w{narrow} gaps {go}/{ge} blocks={blocks or 'auto'}")
+
+
+@pytest.mark.parametrize("qlen,geometry", [(300, "16,16"), (700, "16,16"), (1000, "32,16"), (1290, "16,40"), (2100, "64,16"), (2000, "32,23"),
+                                           (3000, None), (5200, None)])
+def test_streaming_sw_row_chunks(qlen, geometry, ours, oracle, monkeypatch):
+    """Queries beyond one wave stream through one launch per row chunk, the chunk's bottom row (H and F, one word per column)
+    going through HBM: forced on shorter queries with small chunks (2 to 5 passes, a partial first chunk), and the natural
+    case; once more with a single workgroup, so that every slot carries many sequences across every chunk boundary."""
+    from opal_amd.score_matrix import blosum50
+    q, db = _stream_db(qlen, n=300 if qlen > 2500 else 500)
+    m = blosum50()[1]
+    if geometry:
+        monkeypatch.setenv("OPAL_HIP_STREAM_CHUNKS", geometry)
+    else:
+        monkeypatch.setenv("OPAL_HIP_STREAM", "1")
+    cnt = (C.c_longlong * 9)()
+    for blocks in ("", "1"):
+        if blocks:
+            monkeypatch.setenv("OPAL_HIP_STREAM_BLOCKS", blocks)
+        for go, ge in ((11, 1), (3, 1)):
+            ours.lib.opalx_counters(cnt, 9)
+            before = (cnt[0], cnt[4])
+            got = ours.search(q, db, go, ge, m, 0, MODES["SW"])[:4]
+            ours.lib.opalx_counters(cnt, 9)
+            assert cnt[0] - before[0] == 1 and cnt[4] - before[1] >= 2, "not on the chunked streaming path"
+            want = oracle.search(q, db, go, ge, m, 0, MODES["SW"])
+            assert got[0] == want[0] == 0
+            np.testing.assert_array_equal(got[1], want[1], err_msg=f"stream chunks q{qlen} {geometry} gaps {go}/{ge} blocks={blocks or 'auto'}")
+
+
+def test_streaming_row_chunks_saturated_scores(ours, oracle, monkeypatch):
+    """Scores that reach the 16-bit limit in the first, a middle or the last chunk are listed for the 32-bit re-run exactly
+    once and come back exact; the others keep the maximum over the chunks."""
+    monkeypatch.setenv("OPAL_HIP_STREAM_CHUNKS", "16,20")
+    rng = np.random.RandomState(15)
+    q = rng.randint(0, 4, size=1400).astype(np.uint8)
+    m = cases.simple_matrix(4, 60, -40)
+    db = []
+    for i in range(181):
+        if i % 3 == 0:
+            db.append(rng.randint(0, 4, size=int(rng.randint(20, 900))).astype(np.uint8))
+        else:
+            a = int(rng.randint(0, 1000))
+            t = q[a: a + int(rng.randint(100, 1400))].copy()   # a piece of the query: high scores in the chunks that hold it
+            t[rng.randint(0, len(t), size=3)] = rng.randint(0, 4, size=3)
+            db.append(t)
+    got = ours.search(q, db, 30, 5, m, 0, MODES["SW"])[:4]
+    want = oracle.search(q, db, 30, 5, m, 0, MODES["SW"])
+    assert (want[1] > 32767).sum() > 40 and (want[1] < 20000).sum() > 40
+    assert got[0] == 0
+    np.testing.assert_array_equal(got[1], want[1])
 
 
 def test_streaming_is_what_long_queries_run_on(ours):
