@@ -32,10 +32,9 @@ extern "C" {
 /* ------------------------------------------------------------------ part 1 */
 
 /* One kernel launch over `num_items` work items. All pointers are device pointers. */
-/* Zero-copy launches (OpalHipLaunch::residues_out): SW kernels only, and those of more rows per lane than this have no
- * register to spare for the extra store and ignore residues_out -- the host must not rely on it there. */
+/* Zero-copy launches (OpalHipLaunch::residues_out with opal_hip_launch_uber): SW score searches whose bulk class has at most
+ * this many rows per lane -- the shapes instantiated with the extra store (opal_hip_uber_supported(mode, 16, ...) tells). */
 #define OPAL_ZERO_COPY_MAX_ROWS 38
-#define OPAL_ZERO_COPY_MAX_ROWS_SWEND 36
 
 typedef struct OpalHipLaunch {
     /* what to compute */
@@ -58,8 +57,8 @@ typedef struct OpalHipLaunch {
        first; item i = position in that order = pair * 2 + half */
     const unsigned char* residues;  /* one byte per residue, sequence after sequence in item order */
     const uint64_t* seq_offset;     /* [items] start of each sequence in `residues` */
-    unsigned char* residues_out;    /* NULL, or: `residues` is pinned host memory read over PCIe, and the kernels (widths 17, 18,
-                                       32; class launches) also write every residue they read here -- the device copy */
+    unsigned char* residues_out;    /* opal_hip_launch_uber, SW score only: NULL, or `residues` is pinned host memory read over PCIe
+                                       and the kernel also stores every residue it reads here -- the device copy */
     const uint16_t* tokens;      /* width 16 only. Per pair (items 2p, 2p+1): max(lenA,lenB) entries, low byte = residue of A, high byte = B */
     const uint64_t* pair_token_offset; /* width 16 only. [num_pairs] start of each pair's token stream */
     const int* pair_len;         /* [2*num_pairs] lengths of A and B (0 = absent) */
@@ -121,7 +120,8 @@ typedef struct OpalHipUberLaunch {
     int longest_first_item, longest_num_items;
     int long_priority, longest_priority;   /* s_setprio of those classes' waves (0: none) */
 } OpalHipUberLaunch;
-/* 1 if a one-launch kernel exists for this variant (width 17, single launch) and bulk rows-per-lane value */
+/* 1 if a one-launch kernel exists for this variant (width 17, single launch) and bulk rows-per-lane value; bit 4 of
+   `want_end` (16) asks for the zero-copy variant (base.residues_out set: SW score only) */
 int opal_hip_uber_supported(int mode, int want_end, int skew, int rows_per_lane);
 int opal_hip_launch_uber(const OpalHipUberLaunch* args);
 

@@ -44,6 +44,8 @@
 #define FLAG_WRAP 2   // width 32 SW: detect 32-bit wrap of ulH + P (reference opal.cpp:302-303,339-351)
 #define FLAG_MULTI 4  // the query is processed in several row chunks; the boundary row travels through HBM
 #define FLAG_SKEW 8   // width 17, NW/HW/OV: diagonal-skewed values, no gap-extension subtractions (see row_skew)
+#define FLAG_ZC 16    // zero-copy search: the residues are read from pinned host memory and every one is also stored to
+                      // KParams::resOut, the device copy (own instantiations: the store costs the SW score kernel 2.2 %)
 
 #define WAVES_PER_BLOCK 4      // default waves per block (the launch may use fewer or more, up to MAX)
 #define MAX_WAVES_PER_BLOCK 8
@@ -587,10 +589,9 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
         if ((sn & (G - 1)) == 0) {  // wave-uniform: refill the queue with columns sn .. sn+G-1
             const unsigned tok = tokNext;
             const int col = sn + k;
-            if constexpr (NH == 1 && MODE == MODE_SW && S <= (SWEND ? OPAL_ZERO_COPY_MAX_ROWS_SWEND : OPAL_ZERO_COPY_MAX_ROWS)) {
-                // Zero-copy search (KParams::resOut): the kernel is the copy engine (shapes of up to 38 rows per lane: the 39- and
-                // 40-row ones have no register to spare for the store's address). The pointer is read from the LDS slot
-                // every batch (volatile: not hoisted) -- as a kernel argument kept across the loop it cost the 40-row
+            if constexpr (NH == 1 && (FLAGS & FLAG_ZC) != 0) {
+                // Zero-copy search (KParams::resOut): the kernel is the copy engine. The pointer is read from the LDS slot
+                // every batch (volatile: not hoisted) -- as a kernel argument kept across the loop it costs the tall
                 // shapes two registers they do not have.
                 unsigned char* const ro = *reinterpret_cast<unsigned char* volatile*>(clkSlot + 32);
                 if (ro && col < slotLen) ro[tokBase + (uint64_t)col] = (unsigned char)tok;
@@ -1044,7 +1045,7 @@ KernelFn opal_kernel_w16(int mode, int flags, int rows);  // width 16, the other
 KernelFn opal_kernel_w32(int mode, int flags, int rows);  // width 32: rows 8,16,24,32,40
 KernelFn opal_kernel_s16sw(int rows);                     // width 17, SW, score only: rows 1..40
 KernelFn opal_kernel_s16swend(int rows);                  // width 17, SW, score + end location: rows 1..40
-UberFn opal_uber_sw(int flags, int rows);                // one-launch kernels: SW score / SW end, bulk rows 1..40
+UberFn opal_uber_sw(int flags, int rows);                // one-launch kernels: SW score / SW end, bulk rows 1..40; FLAG_ZC (score): 1..38
 UberFn opal_uber_skew(int mode, int rows);               // NW/HW/OV, FLAG_SKEW
 KernelFn opal_kernel_s18(int mode, int flags, int rows);   // width 18 (2-byte profile entries): rows 8,16,..,40
 KernelFn opal_kernel_s16skew(int mode, int rows);           // width 17, NW/HW/OV, FLAG_SKEW: rows 1..40

@@ -9,8 +9,10 @@ static UberFn pick(int rows, std::integer_sequence<int, R...>) {
 }
 
 UberFn opal_uber_swend(int rows);
+UberFn opal_uber_swzc(int rows);
 
 UberFn opal_uber_sw(int flags, int rows) {
+    if (flags == FLAG_ZC) return opal_uber_swzc(rows);
     if (flags & ~FLAG_SWEND) return nullptr;
     return (flags & FLAG_SWEND) ? opal_uber_swend(rows) : pick(rows, std::make_integer_sequence<int, 40>{});
 }

@@ -191,10 +191,9 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
     if (db->gate.active && !work && (width == 17 || width == 18) && db->gate.chunks() >= 4 && !getenv("OPAL_HIP_NO_SLICES")) {
         const UploadGate& g = db->gate;
         SearchCtx zc = c;
-        bool shapesOk = c.mode == OPAL_MODE_SW;  // (the zero-copy store exists in the SW kernels of up to 38 rows only, 36 with end
-                                                // locations: the others have no register to spare for it -- dp_kernel.hpp)
-        for (const LaunchClass& k : classes) shapesOk = shapesOk && k.rows <= (swEndPass ? OPAL_ZERO_COPY_MAX_ROWS_SWEND : OPAL_ZERO_COPY_MAX_ROWS);
-        zc.zeroCopy = g.zeroCopy && shapesOk;  // (a database seen for the first time: the launches read the pinned staging buffer over PCIe ...
+        // (a database seen for the first time: the launches read the pinned staging buffer over PCIe and write the device copy
+        // -- on the kernels instantiated with that store: SW score searches that run as one grid, inst_uber_swzc.hip)
+        zc.zeroCopy = g.zeroCopy && oneGrid && width == 17 && c.mode == OPAL_MODE_SW && !swEndPass && opal_hip_uber_supported(OPAL_MODE_SW, 16, 0, bulk.rows);
         if (zc.zeroCopy && firstItem == 0 && numItems == 2 * db->numPairs) db->gate.kernelFilled = true;  // ... and write the device copy)
         // chunks per slice, the rest in the last one (C2: 17 chunks of 2 MB). The FIRST slice holds the long classes: its
         // longest sequence is the critical path of the whole search, so it is as small as it can be (it starts as soon as

@@ -349,6 +349,7 @@ extern "C" int opal_hip_uber_supported(int mode, int want_end, int skew, int row
     OpalHipLaunch a;
     memset(&a, 0, sizeof a);
     a.width = 17; a.mode = mode; a.want_end = want_end & 1; a.skew = skew;
+    if (want_end & 16) return mode == MODE_SW && !(want_end & 1) && pick_uber(mode, FLAG_ZC, rows_per_lane) != nullptr;  /* bit 4: the zero-copy variants */
     return pick_uber(mode, launch_flags(&a), rows_per_lane) != nullptr;
 }
 
@@ -360,7 +361,7 @@ extern "C" int opal_hip_launch_uber(const OpalHipUberLaunch* u) {
     UberFn fn = nullptr;
     if (a->width == 17 && !a->chunk_flags && !a->work && (1 << log2G0) == G0 && S0 >= 1 && S0 <= OPAL_HIP_MAX_ROWS &&
         (long long)G0 * S0 >= a->query_length && a->query_length >= 1 && a->mode >= 0 && a->mode <= 3)
-        fn = pick_uber(a->mode, launch_flags(a), S0);
+        fn = pick_uber(a->mode, launch_flags(a) | (a->residues_out ? FLAG_ZC : 0), S0);  /* (zero copy: SW score shapes only, else no kernel) */
     const int items[3] = {u->longest_num_items, u->long_num_items, a->num_items};
     const int firsts[3] = {u->longest_first_item, u->long_first_item, a->first_item};
     const int prios[3] = {u->longest_priority, u->long_priority, a->priority};
@@ -431,7 +432,7 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
     memset(&p, 0, sizeof p);
     p.query = a->query; p.matrix = a->score_matrix; p.Q = a->query_length; p.A = a->alphabet_length;
     p.Go = a->gap_open; p.Ge = a->gap_ext;
-    p.res = a->residues; p.seqOff = a->seq_offset; p.resOut = a->residues_out;
+    p.res = a->residues; p.seqOff = a->seq_offset; p.resOut = nullptr;  /* (zero copy: one-launch kernels only) */
     p.tokens = a->tokens; p.pairOff = a->pair_token_offset; p.pairLen = a->pair_len; p.pairSeq = a->pair_seq;
     p.work = a->work; p.firstItem = a->first_item; p.numItems = a->num_items; p.log2G = log2G;
     p.outScore = a->out_score; p.outEndQ = a->out_end_query; p.outEndT = a->out_end_target;
