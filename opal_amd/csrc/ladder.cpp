@@ -21,7 +21,7 @@ static void fill_launch(OpalHipLaunch& a, const SearchCtx& c, int width, int swE
     a.out_score = c.dScore; a.out_end_query = c.wantEnd ? c.dEndQ : nullptr; a.out_end_target = c.wantEnd ? c.dEndT : nullptr;
     a.overflow_count = ovfCounter; a.overflow_items = db->ovfItems.p;
     a.sat_limit = c.satLimit; a.neg_pad = c.negPad;
-    a.stream = db->main();
+    a.stream = c.stream ? c.stream : db->main();
     a.clock_probe = db->clockProbe ? (unsigned long long*)(db->header.p + 16) : nullptr;
     a.timeline = (db->clockProbe && db->timelineProbe) ? db->timeline.p : nullptr;
 }
@@ -148,7 +148,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
         }
     }
     if (classes.empty() || getenv("OPAL_HIP_FORCE_CHUNKS")) {
-        if (!gate_items(db, db->main(), 0, 2 * db->numPairs)) return OPAL_ERR_NO_SIMD_SUPPORT;
+        if (!gate_items(db, c.stream ? c.stream : db->main(), 0, 2 * db->numPairs)) return OPAL_ERR_NO_SIMD_SUPPORT;
         return launch_chunked(c, width, swEndPass, detectWrap, work, firstItem, numItems, lenOf, ovfCounter);
     }
     // Can the classes run as one grid? (bulk on G0 lanes, the others on 2*G0 and 4*G0, all on the same arithmetic)
@@ -422,6 +422,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
     // pairs (half-rate VALU, 2-byte entries: queries whose 4-byte profile exceeds LDS); 18 = plain with 2-byte entries
     // (+0.5 instructions per cell; experimental, on request only).
     int narrow = 17;
+    bool chunkedQuery = false;  // no single launch holds the query at any width: row chunks
     if (const char* e = getenv("OPAL_HIP_NARROW")) { const int v = atoi(e); narrow = (v == 16 || v == 18) ? v : 17; }
     {
         auto fits = [&](int width) {  // does some single-launch geometry hold the query at this width?
@@ -449,7 +450,8 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
         // Queries that no single launch holds at any width (more than 64 lanes x 40 rows) run in row chunks: on the plain
         // kernels with 2-byte profile entries, whose chunk profiles leave room for twice the waves of the 4-byte ones and which,
         // unlike the packed pairs, issue at full rate (3000-aa query x 100 000 sequences: ... GCUPS against 5 260 at width 16)
-        if (!getenv("OPAL_HIP_NARROW") && !(force && atoi(force) == 17) && !fits(17) && !fits(18) && !fits(16)) {
+        chunkedQuery = !fits(17) && !fits(18) && !fits(16);
+        if (!getenv("OPAL_HIP_NARROW") && !(force && atoi(force) == 17) && chunkedQuery) {
             narrow = mode == OPAL_MODE_HW ? 17 : 18;  // (HW: no 2-byte-profile chunk kernels beyond 16 rows per lane, inst_s18multi.hip)
             if (const char* cw = getenv("OPAL_HIP_CHUNK_WIDTH")) { const int v = atoi(cw); if (v == 16 || v == 17 || v == 18) narrow = v; }
         }
@@ -616,14 +618,28 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
             nBad++;
         }
         if (nBad > 0) rc = OPAL_ERR_OVERFLOW;
-        if (2 * p32 > nBad && launch_range(c, 32, 0, 0, nullptr, nBad, 2 * p32 - nBad, seqLenOf, db->ovfCount.p + 1))
+        // A query beyond one wave runs in row chunks, one launch after the other; its 32-bit prefix (a few long sequences: every
+        // chunk is one long lone-wave tail, 2 x 2.4 ms of a 26 ms 3000-aa NW search) runs BESIDE the 16-bit chunks on a
+        // high-priority side stream. The two ranges share nothing but the buffers they index by their own sequences.
+        void* join32 = nullptr;
+        SearchCtx c32 = c;
+        if (chunkedQuery && 2 * p32 > nBad && P > q32 && !getenv("OPAL_HIP_NO_SIDE_PREFIX")) {
+            void* fork = db->event(8);
+            void* side = db->stream(0);
+            if (fork && side && !opal_hip_event_record(fork, st) && !opal_hip_stream_wait_event(side, fork)) { c32.stream = side; join32 = db->event(9); }
+        }
+        if (2 * p32 > nBad && launch_range(c32, 32, 0, 0, nullptr, nBad, 2 * p32 - nBad, seqLenOf, db->ovfCount.p + 1)) {
+            db->quiesce();
             return OPAL_ERR_NO_SIMD_SUPPORT;
+        }
+        if (c32.stream && (!join32 || opal_hip_event_record(join32, c32.stream))) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
         if (P > q32) {
             const int e = gplan.G ? launch_global_stream()
                         : narrow == 16 ? launch_range(c, 16, 0, 0, nullptr, p32, P - p32, pairLenOf, db->ovfCount.p)
                                        : launch_range(c, narrow, 0, 0, nullptr, 2 * p32, 2 * (P - p32), seqLenOf, db->ovfCount.p);
             if (e) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
         }
+        if (c32.stream && opal_hip_stream_wait_event(st, join32)) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
     }
     if (evStop) { opal_hip_event_record(evStop, st); db->asyncEvents = db->asyncTimed; }
     // (a caller that copies the results back on the same stream and waits for that copy needs no wait of its own here)

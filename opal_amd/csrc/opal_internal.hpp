@@ -214,7 +214,7 @@ struct OpalxDb {
     void* copyStream2 = nullptr;  // odd chunks (the per-copy set-up of one overlaps the transfer of the other)
     void* auxStream = nullptr;
     void* streams[3] = {nullptr, nullptr, nullptr};
-    void* events[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // 0 fork, 1-3 joins, 4-5 timing, 6 aux join, 7 fill
+    void* events[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // 0 fork, 1-3 joins, 4-5 timing, 6 aux join, 7 fill, 8-9 fork / join of a 32-bit prefix beside row chunks
     void* main() {
         if (!mainStream) mainStream = opal_hip_stream_create();
         return mainStream;
@@ -323,6 +323,7 @@ struct SearchCtx {
     int satLimit, negPad;  // width 17 (plain 16-bit) parameters
     long long maxScore;    // largest matrix entry (>= 0)
     bool zeroCopy = false; // launches read the residues from the pinned staging buffer (db->hRaw) instead of the device copy
+    void* stream = nullptr; // launch on this stream instead of the handle's main one (row chunks of a 32-bit prefix beside the 16-bit ones)
 };
 
 // Lengths of the items of a launch range: item i has length lens[(idx ? idx[i] : i) * stride]

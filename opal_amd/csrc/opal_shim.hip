@@ -467,7 +467,7 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
 
 // ------------------------------------------------------------------ streaming SW score search (stream_kernel.hpp)
 static StreamFn pick_stream(int width, int mode, int want_end, int rows, int chunked = 0) {
-    if (chunked) return (mode == MODE_SW && !want_end && width == 17) ? opal_stream_s17chunk(rows) : nullptr;
+    if (chunked) return (mode == MODE_SW && width == 17) ? (want_end ? opal_stream_s17chunkend(rows) : opal_stream_s17chunk(rows)) : nullptr;
     if (mode != MODE_SW) {
         if (width == 17) return opal_stream_gl17(mode, rows);
         if (width == 18) return opal_stream_gl18(mode, rows);

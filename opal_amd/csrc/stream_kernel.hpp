@@ -128,16 +128,16 @@ __device__ __forceinline__ void stream_fetch(SlotStream& st, const KParams& p, i
     st.bndNext = bnd;
 }
 
-// CHUNK (score searches): the launch covers query rows [q0, q0 + chunkRows) of a query beyond one wave (more than 64 lanes
+// CHUNK: the launch covers query rows [q0, q0 + chunkRows) of a query beyond one wave (more than 64 lanes
 // x 40 rows, or a profile beyond LDS), one launch per row chunk from the top. The chunk's bottom row -- H and the F input
 // of the row below, 16 bits each in one word per column, at the column's residue offset -- goes through p.bnd: lane 0
 // takes its top inputs from the word the chunk above left (fetched with the letter, a batch ahead, and handed to lane 0
 // through the same lane queue), the last lane's outputs are collected in a second lane queue and stored once per batch,
 // every lane one column. Separator and pad columns carry zeros, as the top boundary of local alignment does everywhere.
-// A sequence's score is the maximum over the chunks (read-modify-write of outScore: one chunk at a time).
+// A sequence's score is the maximum over the chunks (read-modify-write of outScore: one chunk at a time); with end
+// locations the best cell so far stays unless this chunk's is better (higher score, or the same in a smaller column).
 template <int WIDTH, int S, bool SWEND = false, bool CHUNK = false>
 __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const StreamParams sp) {
-    static_assert(!(SWEND && CHUNK), "row chunks: score searches only");
     using V = Vec<WIDTH>;
     using reg = typename V::reg;
     using elem = typename V::elem;
@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     int endCol = INT_MAX, endRow = -1, myStart = 0;
     reg pmOut = V::splat(-1), seqM1 = V::splat(-1);
     int outCol = INT_MAX, outRow = -1;
-    const int r0 = k * S - padTop;  // query row held in register 0
+    const int r0 = q0 + k * S - padTop;  // query row held in register 0
 
     auto fetch = [&](const int x) { stream_fetch<2, CHUNK>(st, p, sp.next, ring, x, k, G, slotLane0, PAD); };
     fetch(k);
@@ -399,7 +399,16 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
                         // maximum over the chunks; a score at the saturation limit is listed for the 32-bit re-run once, by the
                         // first chunk that sees it, and marked for the chunks below (as the class kernels do, dp_kernel.hpp)
                         const int prev = hasPrev ? p.outScore[seq] : 0;
-                        const int sc = prev > outM ? prev : outM;
+                        int sc = prev > outM ? prev : outM;
+                        int col = outCol, row = outRow;
+                        if constexpr (SWEND) {
+                            // the chunks above hold smaller rows: on equal scores they keep the cell unless ours has a smaller column
+                            if (hasPrev) {
+                                int pc = p.outEndT[seq];
+                                if (pc < 0) pc = INT_MAX;
+                                if (prev > outM || (prev == outM && pc <= outCol)) { col = pc; row = p.outEndQ[seq]; }
+                            }
+                        }
                         if (sc >= p.satLimit) {
                             if (!(hasPrev && prev >= p.satLimit)) {
                                 const int at = atomicAdd(p.ovfCount, 1);
@@ -408,6 +417,11 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
                             p.outScore[seq] = p.satLimit;
                         } else {
                             p.outScore[seq] = sc;
+                            if constexpr (SWEND) {
+                                const bool none = sc <= 0 || col == INT_MAX;  // score 0: no cell (test.cpp:242-243)
+                                p.outEndQ[seq] = none ? -1 : row;
+                                p.outEndT[seq] = none ? -1 : col;
+                            }
                         }
                     } else if (seq >= 0) {
                         if (outM >= p.satLimit) {  // (opal.cpp:364-370): hand over to width 32
@@ -734,6 +748,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
 
 StreamFn opal_stream_s17(int rows);     // width 17 (4-byte profile entries), score only: rows 1..40
 StreamFn opal_stream_s17chunk(int rows);  // one row chunk of a longer query (CHUNK), width 17, score only: rows 16..40
+StreamFn opal_stream_s17chunkend(int rows);  // ... with end locations: rows 16..32
 StreamFn opal_stream_s18(int rows);     // width 18 (2-byte entries), score only: rows 20..40
 StreamFn opal_stream_s17end(int rows);  // with end locations: rows 1..36
 StreamFn opal_stream_s18end(int rows);  // rows 20..36

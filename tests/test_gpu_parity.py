@@ -545,6 +545,9 @@ def test_streaming_sw_row_chunks(qlen, geometry, ours, oracle, monkeypatch):
             want = oracle.search(q, db, go, ge, m, 0, MODES["SW"])
             assert got[0] == want[0] == 0
             np.testing.assert_array_equal(got[1], want[1], err_msg=f"stream chunks q{qlen} {geometry} gaps {go}/{ge} blocks={blocks or 'auto'}")
+            # with end locations: the best cell so far travels from chunk to chunk with the score (kernels up to 32 rows per lane)
+            got = ours.search(q, db, go, ge, m, 1, MODES["SW"])[:4]
+            _check(got, oracle.search(q, db, go, ge, m, 1, MODES["SW"]), "SW", f"stream chunks + end q{qlen} {geometry} gaps {go}/{ge} blocks={blocks or 'auto'}")
 
 
 def test_streaming_row_chunks_saturated_scores(ours, oracle, monkeypatch):
@@ -568,6 +571,8 @@ def test_streaming_row_chunks_saturated_scores(ours, oracle, monkeypatch):
     assert (want[1] > 32767).sum() > 40 and (want[1] < 20000).sum() > 40
     assert got[0] == 0
     np.testing.assert_array_equal(got[1], want[1])
+    got = ours.search(q, db, 30, 5, m, 1, MODES["SW"])[:4]
+    _check(got, oracle.search(q, db, 30, 5, m, 1, MODES["SW"]), "SW", "stream chunks + end, overflows")
 
 
 def test_streaming_is_what_long_queries_run_on(ours):
