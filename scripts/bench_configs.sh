@@ -24,4 +24,7 @@ run --workload c5 --total-seqs 100000 --search-type 1 --mode OV --no-e2e
 run --workload c5 --total-seqs 625000
 run --workload c5 --total-seqs 100000 --qlen 1000 --no-e2e
 run --workload c5 --total-seqs 100000 --qlen 3000 --no-e2e
+run --workload c5 --total-seqs 100000 --qlen 3000 --search-type 1 --no-e2e
+run --workload c5 --total-seqs 100000 --qlen 3000 --search-type 1 --mode NW --no-e2e
+run --workload c5 --total-seqs 100000 --qlen 6000 --no-e2e
 run --workload sprot --no-e2e
