@@ -587,7 +587,9 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
             };
             while (q32 < P && !skew_safe(db->pairLen[2 * (size_t)q32])) { moved += db->pairLen[2 * (size_t)q32] + db->pairLen[2 * (size_t)q32 + 1]; q32++; }
             const char* sen = getenv("OPAL_HIP_STREAM");
-            if (q32 < P && (moved * 50 <= db->residues || (sen && *sen == '1')) && !getenv("OPAL_HIP_NO_SKEW")) {
+            // (a query in row chunks: the unskewable sequences run on the class kernels' chunks on a side stream BESIDE the
+            // streamed ones, not inside the launch -- they may hold a sixth of the residues before they become the longer side)
+            if (q32 < P && (moved * (chunkedQuery ? 6 : 50) <= db->residues || (sen && *sen == '1')) && !getenv("OPAL_HIP_NO_SKEW")) {
                 gplan = plan_stream(Q, A, mode, wantEnd, db->residues - moved, db->pairLen[2 * (size_t)q32], db->numSeqs - 2 * q32);
             }
             if (!gplan.G) q32 = p32;
@@ -597,6 +599,30 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
             fill_launch(a, c, gplan.width, 0, 0, nullptr, db->ovfCount.p);
             a.lanes_per_seq = gplan.G; a.rows_per_lane = gplan.rows; a.skew = 1;
             a.first_item = 2 * q32; a.num_items = 2 * (P - q32);
+            if (gplan.passes > 1) {
+                // a query beyond one wave: row chunks from the top (NW: the last one partial, HW/OV: the first), a chunk's bottom
+                // row through the upper half of db->boundary (4 bytes per residue; the class-kernel chunks of the sequences that
+                // need 32 bits or cannot be skewed run beside this on a side stream and index the lower half by THEIR residues)
+                if (!gate_items(db, st, 0, 2 * P)) return 1;
+                if (!db->boundary.ensure(8 * ((size_t)db->residues + 16)) || !db->scratch.ensure(2 * (size_t)std::max(db->numSeqs, 1))) return 1;
+                const int cap = gplan.G * gplan.rows;
+                const int firstRows = Q - (gplan.passes - 1) * cap;
+                count(CNT_STREAM_GLOBAL);
+                for (int ch = 0; ch < gplan.passes; ch++) {
+                    a.chunk_flags = (ch > 0 ? 1 : 0) | (ch < gplan.passes - 1 ? 2 : 0);
+                    if (mode == OPAL_MODE_NW) { a.chunk_row0 = ch * cap; a.chunk_rows = std::min(cap, Q - a.chunk_row0); }
+                    else { a.chunk_row0 = ch == 0 ? 0 : firstRows + (ch - 1) * cap; a.chunk_rows = ch == 0 ? firstRows : cap; }
+                    a.boundary = db->boundary.p + 4 * ((size_t)db->residues + 16);
+                    a.scratch = db->scratch.p;
+                    if (debug_on())
+                        fprintf(stderr, "[opal] streaming chunk %d/%d mode=%d G=%d rows=%d: query rows [%d,+%d) items=[%d,+%d)\n", ch + 1, gplan.passes,
+                                mode, gplan.G, gplan.rows, a.chunk_row0, a.chunk_rows, a.first_item, a.num_items);
+                    if (ch > 0 && opal_hip_memset32(db->ovfCount.p + 2, 0, 1, st)) return 1;
+                    if (opal_hip_launch_stream(&a, db->ovfCount.p + 2)) return 1;
+                    count(CNT_CHUNK_LAUNCHES);
+                }
+                return 0;
+            }
             // the skew-unsafe sequences (the longest ones) ride along in the same launch on the unskewed class body
             a.side_first_item = 2 * p32; a.side_num_items = 2 * (q32 - p32);
             if (debug_on())
@@ -623,7 +649,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
         // high-priority side stream. The two ranges share nothing but the buffers they index by their own sequences.
         void* join32 = nullptr;
         SearchCtx c32 = c;
-        if (chunkedQuery && 2 * p32 > nBad && P > q32 && !getenv("OPAL_HIP_NO_SIDE_PREFIX")) {
+        if (chunkedQuery && P > q32 && (2 * p32 > nBad || (gplan.G && gplan.passes > 1 && q32 > p32)) && !getenv("OPAL_HIP_NO_SIDE_PREFIX")) {
             void* fork = db->event(8);
             void* side = db->stream(0);
             if (fork && side && !opal_hip_event_record(fork, st) && !opal_hip_stream_wait_event(side, fork)) { c32.stream = side; join32 = db->event(9); }
@@ -631,6 +657,12 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
         if (2 * p32 > nBad && launch_range(c32, 32, 0, 0, nullptr, nBad, 2 * p32 - nBad, seqLenOf, db->ovfCount.p + 1)) {
             db->quiesce();
             return OPAL_ERR_NO_SIMD_SUPPORT;
+        }
+        if (gplan.G && gplan.passes > 1 && q32 > p32) {
+            // (streamed row chunks: the 16-bit sequences that cannot be skewed take the class kernels' chunks, after the 32-bit ones)
+            const int e = narrow == 16 ? launch_range(c32, 16, 0, 0, nullptr, p32, q32 - p32, pairLenOf, db->ovfCount.p)
+                                       : launch_range(c32, narrow, 0, 0, nullptr, 2 * p32, 2 * (q32 - p32), seqLenOf, db->ovfCount.p);
+            if (e) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
         }
         if (c32.stream && (!join32 || opal_hip_event_record(join32, c32.stream))) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
         if (P > q32) {

@@ -467,7 +467,11 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
 
 // ------------------------------------------------------------------ streaming SW score search (stream_kernel.hpp)
 static StreamFn pick_stream(int width, int mode, int want_end, int rows, int chunked = 0) {
-    if (chunked) return (mode == MODE_SW && width == 17) ? (want_end ? opal_stream_s17chunkend(rows) : opal_stream_s17chunk(rows)) : nullptr;
+    if (chunked) {
+        if (width != 17) return nullptr;
+        if (mode != MODE_SW) return opal_stream_gl17chunk(mode, rows);
+        return want_end ? opal_stream_s17chunkend(rows) : opal_stream_s17chunk(rows);
+    }
     if (mode != MODE_SW) {
         if (width == 17) return opal_stream_gl17(mode, rows);
         if (width == 18) return opal_stream_gl18(mode, rows);
@@ -495,11 +499,12 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
     int log2G = 0;
     while ((1 << log2G) < G) log2G++;
     StreamFn fn = nullptr;
-    if ((1 << log2G) == G && G <= 64 && a->mode >= 0 && a->mode <= 3 && !a->work && next_counter &&
+    if ((1 << log2G) == G && G <= 64 && a->mode >= 0 && a->mode <= 3 && !a->work && next_counter && !(a->chunk_flags && a->side_num_items > 0) &&
         (!a->want_end || (a->out_end_query && a->out_end_target)) &&
         a->query_length >= 1 && (long long)G * a->rows_per_lane >= (a->chunk_flags ? a->chunk_rows : a->query_length) &&
         (!a->chunk_flags || (a->boundary && a->chunk_rows >= 1 && a->chunk_row0 >= 0 && a->chunk_row0 + a->chunk_rows <= a->query_length &&
-                             ((a->chunk_flags & 1) == 0 || a->chunk_rows == G * a->rows_per_lane))))  /* only the first chunk may be partial */
+                             /* a partial chunk is the first one (SW/HW/OV: padded above) or the last one (NW: padded below) */
+                             (a->chunk_rows == G * a->rows_per_lane || (a->chunk_flags & (a->mode == MODE_NW ? 2 : 1)) == 0))))
         fn = pick_stream(a->width, a->mode, a->want_end, a->rows_per_lane, a->chunk_flags);
     if (!fn) {
         snprintf(g_err, sizeof g_err, "unlaunchable streaming shape: width=%d G=%d rows=%d Q=%d", a->width, G, a->rows_per_lane, a->query_length);
@@ -530,6 +535,7 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
     p.chunkRows = a->chunk_flags ? a->chunk_rows : a->query_length;
     p.chunkFlags = a->chunk_flags;
     p.bnd = (uint2*)a->boundary;
+    p.scratch = a->scratch;
     p.satLimit = a->sat_limit; p.negPad = a->neg_pad;
     p.clk = a->clock_probe; p.tl = a->timeline;
     sp.next = next_counter;

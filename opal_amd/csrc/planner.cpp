@@ -253,11 +253,12 @@ StreamPlan plan_stream(int Q, int A, int mode, int wantEnd, long long residues, 
             if (cost < bestCost) { bestCost = cost; best.width = width; best.G = G; best.rows = rows; }
         }
     }
-    if (!best.G && mode == OPAL_MODE_SW && !(forceW && *forceW) && !getenv("OPAL_HIP_NO_STREAM_CHUNKS")) {
+    if (!best.G && !(forceW && *forceW) && !getenv("OPAL_HIP_NO_STREAM_CHUNKS")) {
         // No single launch holds the query (more than 64 lanes x 40 rows, or a profile beyond LDS): row chunks, one streaming
         // launch each (stream_kernel.hpp, CHUNK), equal chunks at the fewest passes each geometry allows.
         for (int G = 16; G <= 64; G *= 2) {
             if (forceG && *forceG && atoi(forceG) != G) continue;
+            if (!force && (wantEnd || mode != OPAL_MODE_SW) && G < 32) continue;  // (as below: those run at 32 lanes or more)
             int cap = 0;
             for (int S = OPAL_HIP_MAX_ROWS; S >= 1 && !cap; S--)
                 if (opal_hip_stream_rows_supported(17, mode, wantEnd | 2, S) == S && opal_hip_stream_lds_bytes(17, mode, G, S, A) <= 160 * 1024) cap = S;
@@ -266,10 +267,11 @@ StreamPlan plan_stream(int Q, int A, int mode, int wantEnd, long long residues, 
             const int need = ((Q + passes - 1) / passes + G - 1) / G;
             const int rows = opal_hip_stream_rows_supported(17, mode, wantEnd | 2, need);
             if (!rows || rows > cap) continue;
-            const double cost = passes * ((wantEnd ? 10.5 : 9.0) * rows + 36.0) * G / Q;
+            const double perRowC = mode == OPAL_MODE_SW ? (wantEnd ? 10.5 : 9.0) : 6.0;
+            const double cost = passes * (perRowC * rows + 36.0) * G / Q;
             // the longest sequence alone on its lanes against the whole pass, as below (the alternative here are the class
             // kernels' chunks, which no geometry brings beyond 0.60-0.65 of the issue bound: 3000-aa query, 100 000 sequences)
-            const double stepInstr = (wantEnd ? 10.5 : 9.0) * rows + 36.0;
+            const double stepInstr = perRowC * rows + 36.0;
             const double total = (double)residues * G / 64.0 * stepInstr * 2.15 / 1024.0;
             const double crit = ((double)longest + G) * stepInstr * 3.5;
             if (!force && crit > (G >= 32 ? 1.5 : 0.5) * total) continue;
@@ -278,7 +280,7 @@ StreamPlan plan_stream(int Q, int A, int mode, int wantEnd, long long residues, 
     }
     if (const char* sc = getenv("OPAL_HIP_STREAM_CHUNKS")) {  // "G,S": test hook -- row chunks of G x S rows whatever the query length
         int g = 0, r = 0;
-        if (mode == OPAL_MODE_SW && sscanf(sc, "%d,%d", &g, &r) == 2 && g >= 1 && g <= 64 && (g & (g - 1)) == 0 &&
+        if (sscanf(sc, "%d,%d", &g, &r) == 2 && g >= 1 && g <= 64 && (g & (g - 1)) == 0 &&
             opal_hip_stream_rows_supported(17, mode, wantEnd | 2, r) == r && opal_hip_stream_lds_bytes(17, mode, g, r, A) <= 160 * 1024 && Q > g * r) {
             best.width = 17; best.G = g; best.rows = r; best.passes = (Q + g * r - 1) / (g * r);
             return best;

@@ -468,7 +468,12 @@ __host__ __device__ inline size_t opal_gl_stream_lds_bytes(int G, int S, int A) 
            (size_t)STREAM_WAVES * (64 / G) * STREAM_RING * STREAM_DESC_BYTES + 48;  // (+48: probe slot)
 }
 
-template <int WIDTH, int MODE, int S>
+// CHUNK: one row chunk [q0, q0 + chunkRows) of a query beyond one wave, as in opal_sw_stream: the chunk's bottom row goes
+// through p.bnd as TRUE values (H, and the F input of the row below; 16 bits each -- the host has proven that every true
+// value fits), moved out of the last lane's skewed frame when it is queued for the store and into lane 0's when it is
+// consumed (two additions each). NW pads below the query (the last chunk is the partial one), HW/OV above (the first);
+// results are written by the last chunk only, OV's last-column maximum travels from chunk to chunk through p.scratch.
+template <int WIDTH, int MODE, int S, bool CHUNK = false>
 __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const StreamParams sp) {
     using V = Vec<WIDTH>;
     using reg = typename V::reg;
@@ -493,7 +498,10 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
     const int log2G = p.log2G;
     const int G = 1 << log2G;
     const int stride = opal_gl_stream_stride<WIDTH>(G, S);
-    const int Q = p.Q, A = p.A;
+    const int A = p.A;
+    const int q0 = CHUNK ? p.q0 : 0;           // first query row of this launch
+    const int Q = CHUNK ? p.chunkRows : p.Q;   // ... and how many it covers
+    const bool hasPrev = CHUNK && (p.chunkFlags & 1), hasNext = CHUNK && (p.chunkFlags & 2);
     const int Go = p.Go, Ge = p.Ge;
     const int padTop = (MODE == MODE_NW) ? 0 : (G * S - Q);  // NW pads below the query, HW/OV above (dp_kernel.hpp)
     const int PAD = A;
@@ -512,7 +520,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
             const bool real = lr >= 0 && j < S && lr < Q;
             unsigned char* dst = lds + k * LANE_BYTES + j * ES;
             if (real) {
-                const int* mrow = p.matrix + (int)p.query[lr] * A;
+                const int* mrow = p.matrix + (int)p.query[q0 + lr] * A;
                 for (int letter = 0; letter < A; letter += 2) {
                     const int l1 = min(letter + 1, A - 1);
                     const int v0 = mrow[letter], v1 = mrow[l1];
@@ -525,8 +533,8 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
                 for (int letter = 0; letter <= A; letter++) *reinterpret_cast<elem*>(dst + letter * stride) = (elem)fill;
             }
         }
-        auto hbound = [&](int r) -> long long {  // H[r][-1] (opal.cpp:671-679); rows above the query: 0
-            return (MODE == MODE_OV || r < 0) ? 0LL : -(long long)Go - (long long)r * Ge;
+        auto hbound = [&](int lr) -> long long {  // H[r][-1] of chunk row lr = query row q0 + lr (opal.cpp:671-679); rows above the query: 0
+            return (MODE == MODE_OV || q0 + lr < 0) ? 0LL : -(long long)Go - (long long)(q0 + lr) * Ge;
         };
         for (int idx = threadIdx.x; idx < G * INIT; idx += blockDim.x) {
             const int k = idx / INIT;
@@ -572,7 +580,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
     // where query row Q-1 lives: NW lane kLast, register jLast; HW/OV the last register of the last lane
     const int kLast = (MODE == MODE_NW) ? (Q - 1) / S : G - 1;
     const int jLast = (MODE == MODE_NW) ? (Q - 1) - kLast * S : S - 1;
-    const int r0 = k * S - padTop;
+    const int r0 = q0 + k * S - padTop;
     int jlo = padTop - k * S, jhi = Q + padTop - k * S;  // my registers [jlo, jhi) hold real query rows
     jlo = jlo < 0 ? 0 : (jlo > S ? S : jlo);
     jhi = jhi < 0 ? 0 : (jhi > S ? S : jhi);
@@ -584,15 +592,38 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
     int bestCol = -1;              // its first column
     int outLcV = INT_MIN, outLcRow = -1;                    // OV: last-column maximum handed down the lanes
 
-    auto fetch = [&](const int x) { stream_fetch<0>(st, p, sp.next, ring, x, k, G, slotLane0, PAD); };
+    auto fetch = [&](const int x) { stream_fetch<0, CHUNK>(st, p, sp.next, ring, x, k, G, slotLane0, PAD); };
     fetch(k);
+    unsigned bndq = 0;     // CHUNK: lane queue of the boundary words above the columns of this batch (lane 0 consumes)
+    unsigned outq = 0;     // CHUNK: lane queue of the last lane's outputs (true values), oldest towards lane 0
+    unsigned outPack = 0;  // CHUNK: what I produced in the step behind us, out of my frame
 
     for (int s = 0;; s++) {
         if ((s & (G - 1)) == 0) {
             const unsigned letter = st.tokNext;
+            const unsigned above = st.bndNext;
+            if constexpr (CHUNK) {  // store the last lane's words of positions s-2G .. s-G-1 (see opal_sw_stream)
+                const int xo = s - 2 * G + k;
+                if (hasNext && xo >= 0 && st.nEntries > 0 && xo < st.lastEnd) {
+                    int e = st.nEntries - 1;
+                    const int* d = ring + (e & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4);
+                    if (xo < d[0] && e > 0) { e--; d = ring + (e & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4); }
+                    if (xo < d[0] && e > 0) { e--; d = ring + (e & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4); }
+                    const int col = xo - d[0];
+                    if (col >= 0 && col < d[1]) {
+                        const uint64_t tb = (uint64_t)(unsigned)d[4] | ((uint64_t)(unsigned)d[5] << 32);
+                        reinterpret_cast<unsigned*>(p.bnd)[tb + (uint64_t)col] = outq;
+                    }
+                }
+            }
             fetch(s + G + k);
             tokq = ldsBase + letter * (unsigned)stride;
+            bndq = above;
             if (__ballot(!(st.done && s >= st.lastEnd + G)) == 0ull) break;
+        }
+        if constexpr (CHUNK) {  // the last lane's outputs of the step behind us join the queue
+            const unsigned shifted = shl1(outq);
+            outq = (k == G - 1) ? outPack : shifted;
         }
         const int x = s - k;  // my stream position
         // ---- first column of my next sequence: reload the boundary column
@@ -629,9 +660,13 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
         reg inF = V::subs((reg)shr1((unsigned)outF), SR1v);
         if (k == 0) {
             // H[-1][c] + (s-1)*Ge and F[0][c] + s*Ge = H[-1][c] - Go + s*Ge; NW: H[-1][c] = -Go - c*Ge, HW/OV: 0
-            if (MODE == MODE_NW) { inH = V::splat(-Go - Ge); inF = V::splat(-2 * Go); }
+            if (hasPrev) {  // ... a lower chunk: what the chunk above left for this column, into my frame (k = 0: sRv = c*Ge)
+                inH = V::adds((reg)(bndq & 0xffffu), V::subs(sRv, Rv));
+                inF = V::adds((reg)(bndq >> 16), sRv);
+            } else if (MODE == MODE_NW) { inH = V::splat(-Go - Ge); inF = V::splat(-2 * Go); }
             else { inH = V::subs(sRv, Rv); inF = V::subs(sRv, Qv); }
         }
+        if constexpr (CHUNK) bndq = shl1(bndq);
         {
             const unsigned shifted = shr1(offv) + (unsigned)LANE_BYTES;
             offv = (k == 0) ? tokq : shifted;
@@ -669,16 +704,22 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
         outH = Hp[S - 1];
         outF = f;
         diagIn = inH;
+        if constexpr (CHUNK) {
+            // my outputs as true values: H of my last row is in frame (S-1 + local step), the F input of the row below in
+            // frame (S + local step); sRv = local step * Ge
+            const reg fr = V::adds(sRv, SR1v);
+            outPack = ((unsigned)V::subs(outH, fr) & 0xffffu) | ((unsigned)V::subs(outF, V::adds(fr, Rv)) << 16);
+        }
 
         // ---- results (caller index and length of my sequence: descriptor started-1)
-        if (MODE == MODE_NW) {
+        if (MODE == MODE_NW && !hasNext) {
             if (k == kLast && c == myLen - 1 && myLen > 0) {  // the final cell: once per sequence
                 const reg hl = SelectRow<reg, S, 0, S>::get(Hp, jLast);
                 const int v = V::half(V::subs(hl, V::adds(sRv, V::splat(jLast * Ge))), 0);
                 const int seq = ring[((started - 1) & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4) + 2];
                 if (seq >= 0) {
                     p.outScore[seq] = v;
-                    if (p.outEndQ) { p.outEndQ[seq] = Q - 1; p.outEndT[seq] = myLen - 1; }
+                    if (p.outEndQ) { p.outEndQ[seq] = p.Q - 1; p.outEndT[seq] = myLen - 1; }
                 }
             }
         }
@@ -728,13 +769,22 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
             bestCol = better ? c : bestCol;
             if (k == kLast && lastc) {
                 const reg frame = V::adds(sRv, SR1v);
-                int sc = V::half(V::subs(bestF, frame), 0), eq = Q - 1, et = bestCol;
+                int sc = V::half(V::subs(bestF, frame), 0), eq = p.Q - 1, et = bestCol;
+                const int seq = ring[((started - 1) & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4) + 2];
+                if constexpr (CHUNK && MODE == MODE_OV) {  // the last-column maximum over the chunks (the upper rows win ties)
+                    if (seq >= 0) {
+                        if (hasPrev) {
+                            const int pv = p.scratch[2 * seq], pr = p.scratch[2 * seq + 1];
+                            if (pv >= lcV) { lcV = pv; lcRow = pr; }
+                        }
+                        if (hasNext) { p.scratch[2 * seq] = lcV; p.scratch[2 * seq + 1] = lcRow; }
+                    }
+                }
                 if (MODE == MODE_OV) {
                     const int prevBest = (myLen > 1) ? V::half(V::subs(prevF, frame), 0) : INT_MIN;
                     if (lcV > prevBest) { sc = lcV; et = myLen - 1; eq = lcRow; }
                 }
-                const int seq = ring[((started - 1) & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4) + 2];
-                if (seq >= 0) {
+                if (seq >= 0 && !hasNext) {
                     p.outScore[seq] = sc;
                     if (p.outEndQ) { p.outEndQ[seq] = eq; p.outEndT[seq] = et; }
                 }
@@ -754,3 +804,4 @@ StreamFn opal_stream_s17end(int rows);  // with end locations: rows 1..36
 StreamFn opal_stream_s18end(int rows);  // rows 20..36
 StreamFn opal_stream_gl17(int mode, int rows);  // NW/HW/OV, width 17: rows 1..40
 StreamFn opal_stream_gl18(int mode, int rows);  // width 18: rows 20..40
+StreamFn opal_stream_gl17chunk(int mode, int rows);  // one row chunk of a longer query (CHUNK), width 17: rows 24..40

@@ -575,6 +575,36 @@ def test_streaming_row_chunks_saturated_scores(ours, oracle, monkeypatch):
     _check(got, oracle.search(q, db, 30, 5, m, 1, MODES["SW"]), "SW", "stream chunks + end, overflows")
 
 
+@pytest.mark.parametrize("mode", ["NW", "HW", "OV"])
+@pytest.mark.parametrize("qlen,geometry", [(1000, "16,24"), (1700, "32,24"), (2000, "16,37"), (3000, None), (4100, None)])
+def test_streaming_global_row_chunks(mode, qlen, geometry, ours, oracle, monkeypatch):
+    """NW/HW/OV queries beyond one wave stream their row chunks too: the boundary row goes through HBM as true values and
+    changes skewed frame on the way (NW: the last chunk is the partial one, HW/OV: the first; OV's last-column maximum
+    travels from chunk to chunk). The sequences that need 32 bits or cannot be skewed (a 5000-residue one, one beyond
+    31 000) take the class kernels' chunks beside the stream. Forced on shorter queries, natural at 3000 and 4100 aa;
+    once more with a single workgroup."""
+    from opal_amd.score_matrix import blosum50
+    q, db = _stream_db(qlen, n=300)
+    m = blosum50()[1]
+    if geometry:
+        monkeypatch.setenv("OPAL_HIP_STREAM_CHUNKS", geometry)
+    monkeypatch.setenv("OPAL_HIP_STREAM", "1")  # (a small database: its few long sequences hold more than the share the scheduler allows)
+    cnt = (C.c_longlong * 9)()
+    for blocks in ("", "1"):
+        if blocks:
+            monkeypatch.setenv("OPAL_HIP_STREAM_BLOCKS", blocks)
+        for go, ge in ((11, 1), (3, 1)):
+            ours.lib.opalx_counters(cnt, 9)
+            before = (cnt[1], cnt[4])
+            got = ours.search(q, db, go, ge, m, 1, MODES[mode])[:4]
+            ours.lib.opalx_counters(cnt, 9)
+            assert cnt[1] - before[0] == 1 and cnt[4] - before[1] >= 2, "not on the chunked streaming path"
+            _check(got, oracle.search(q, db, go, ge, m, 1, MODES[mode]), mode, f"global stream chunks q{qlen} {geometry} {mode} gaps {go}/{ge} blocks={blocks or 'auto'}")
+        got = ours.search(q, db, 11, 1, m, 0, MODES[mode])[:4]
+        want = oracle.search(q, db, 11, 1, m, 0, MODES[mode])
+        np.testing.assert_array_equal(got[1], want[1])
+
+
 def test_streaming_is_what_long_queries_run_on(ours):
     """Without any forcing, a long query on a database large enough for the longest sequence not to dominate takes the
     streaming path (with or without end locations); a short query and a small database do not."""
