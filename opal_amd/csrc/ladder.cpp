@@ -188,7 +188,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
     // SLICES of whole upload chunks, every slice launched as soon as its chunks have been enqueued, on two streams in turn
     // (`main` and `aux`) so that a slice starts while the previous one drains. Sequences are sorted longest first, so
     // the first slice holds the long classes.
-    if (db->gate.active && !work && (width == 17 || width == 18) && db->gate.chunks() >= 4 && !getenv("OPAL_HIP_NO_SLICES")) {
+    if (db->gate.active && !work && !c.stream && (width == 17 || width == 18) && db->gate.chunks() >= 4 && !getenv("OPAL_HIP_NO_SLICES")) {
         const UploadGate& g = db->gate;
         SearchCtx zc = c;
         // (a database seen for the first time: the launches read the pinned staging buffer over PCIe and write the device copy
@@ -278,6 +278,17 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
                             opal_hip_event_elapsed_ms(marks[0], marks[2 * j]), opal_hip_event_elapsed_ms(marks[2 * j], marks[2 * j + 1]));
             for (void* ev : marks) opal_hip_event_destroy(ev);
         }
+        return 0;
+    }
+    if (c.stream) {
+        // the caller runs this range beside something else (the long sequences of a database whose bulk is streamed): every
+        // class on the caller's stream, longest sequences first
+        if (!gate_items(db, c.stream, 0, 2 * db->numPairs)) return OPAL_ERR_NO_SIMD_SUPPORT;
+        for (size_t ki = 0; ki < classes.size(); ki++)
+            if (launch_class(c, width, swEndPass, detectWrap, work, classes[ki], maySkew && skew_ok(classes[ki].first), ovfCounter, c.stream, ki + 1 < classes.size())) {
+                db->quiesce();
+                return OPAL_ERR_NO_SIMD_SUPPORT;
+            }
         return 0;
     }
     // everything this range reads must have landed (no-op unless a fill is still in flight)
@@ -459,12 +470,32 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
     // SW score-only searches with long queries stream their sequences through persistent waves (plain 16-bit arithmetic)
     StreamPlan splan;
     if (mode == OPAL_MODE_SW && fits16) splan = plan_stream(Q, A, mode, wantEnd, db->residues, db->pairLen.empty() ? 0 : db->pairLen[0], db->numSeqs);
+    // A database with a long tail (Swiss-Prot: sequences of 35 000 residues among 350-residue ones): one sequence would pin its
+    // lanes for longer than the whole search takes, so plan_stream says no -- to the whole database. OPAL_HIP_STREAM_HEAD=1
+    // streams its BULK all the same: the longest items [0, headItems) go to the class kernels (which give them more lanes)
+    // on a side stream, the rest streams beside them; the head is the smallest of 128 / 512 / 2048 / 8192 items that lets the
+    // rest stream. NOT the default: the persistent workgroups of the stream take every CU, and whether the head's launch gets
+    // its workgroups in before them is up to the dispatch order of two hardware queues -- P18080 x the Swiss-Prot shape ran
+    // 13.9 ms per search under the profiler (which serialises submission), 14.4 / 15.4 / 18.9 ms without it, against a
+    // steady 15.3 ms on the class kernels alone (profiles/r03_stream_head.txt).
+    int headItems = 0;
+    if (mode == OPAL_MODE_SW && fits16 && !splan.G && narrow != 16 && !chunkedQuery && getenv("OPAL_HIP_STREAM_HEAD")) {
+        long long headRes = 0;
+        int at = 0;
+        for (int cut : {128, 512, 2048, 8192}) {
+            if ((long long)cut * 8 > db->numSeqs) break;
+            for (; at < cut; at++) headRes += db->pairLen[(size_t)at];
+            if (headRes * 4 > db->residues) break;
+            const StreamPlan rest = plan_stream(Q, A, mode, wantEnd, db->residues - headRes, db->pairLen[(size_t)cut], db->numSeqs - cut);
+            if (rest.G && rest.passes == 1) { splan = rest; headItems = cut; break; }
+        }
+    }
     // While the database is still arriving (opalSearchDatabase) a streaming launch would have to wait for the last chunk: at 16
     // lanes per sequence or fewer, where streaming gains 2-4 % over the class kernels, the sliced class launches that start
     // on the first chunks are the better trade (C4 shard: the copy of 218 MB takes a third of the call).
     if (splan.G && splan.G <= 16 && db->gate.active && db->gate.chunks() >= 4 && narrow == 17 && !getenv("OPAL_HIP_NO_SLICES")) {
         const char* en = getenv("OPAL_HIP_STREAM");
-        if (!(en && *en == '1')) splan = StreamPlan();
+        if (!(en && *en == '1')) { splan = StreamPlan(); headItems = 0; }
     }
     const bool plain = narrow != 16 || splan.G;
     const int satLimit = plain ? (int)(32767 - maxS) : 32767;
@@ -490,9 +521,21 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                 OpalHipLaunch a;
                 fill_launch(a, c, splan.width, wantEnd, 0, nullptr, db->ovfCount.p);
                 a.lanes_per_seq = splan.G; a.rows_per_lane = splan.rows;
-                a.first_item = 0; a.num_items = 2 * P;
+                a.first_item = headItems; a.num_items = 2 * P - headItems;
                 if (debug_on())
-                    fprintf(stderr, "[opal] streaming launch width=%d G=%d rows=%d end=%d items=%d\n", splan.width, splan.G, splan.rows, wantEnd, 2 * P);
+                    fprintf(stderr, "[opal] streaming launch width=%d G=%d rows=%d end=%d items=[%d,+%d)\n", splan.width, splan.G, splan.rows, wantEnd,
+                            a.first_item, a.num_items);
+                void* headJoin = nullptr;
+                if (headItems > 0) {  // the long head on the class kernels, on a side stream, submitted first
+                    void* fork = db->event(8);
+                    void* side = db->stream(0);
+                    headJoin = db->event(9);
+                    SearchCtx ch = c;
+                    ch.stream = side;
+                    if (!fork || !side || !headJoin || opal_hip_event_record(fork, st) || opal_hip_stream_wait_event(side, fork)) return OPAL_ERR_NO_SIMD_SUPPORT;
+                    if (launch_range(ch, narrow, wantEnd, 0, nullptr, 0, headItems, seqLenOf, db->ovfCount.p)) return OPAL_ERR_NO_SIMD_SUPPORT;
+                    if (opal_hip_event_record(headJoin, side)) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
+                }
                 if (!gate_items(db, st, 0, 2 * P)) return OPAL_ERR_NO_SIMD_SUPPORT;
                 if (splan.passes > 1) {
                     // a query beyond one wave: row chunks from the top, the first one partial (as launch_chunked cuts them), a
@@ -512,6 +555,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                     }
                 } else
                 rc = opal_hip_launch_stream(&a, db->ovfCount.p + 2) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
+                if (headJoin && opal_hip_stream_wait_event(st, headJoin)) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
                 count(CNT_STREAM_SW);
             }
             else if (narrow == 16) rc = launch_range(c, 16, wantEnd, 0, nullptr, 0, nNarrow, pairLenOf, db->ovfCount.p);
