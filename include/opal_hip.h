@@ -98,8 +98,9 @@ typedef struct OpalHipLaunch {
     /* request at least this much LDS per workgroup (0: the query profile's own size): the scheduler pads the
        request to keep an odd number of workgroups from sharing a CU */
     int lds_bytes_min;
-    /* opal_hip_launch_stream, NW/HW/OV only: items [side_first_item, +side_num_items) (sequences too long for the skewed
-       arithmetic of the stream) run on the unskewed class body inside the same launch, ahead of the streaming workgroups */
+    /* opal_hip_launch_stream: items [side_first_item, +side_num_items) run on the class body inside the same launch, ahead
+       of the streaming workgroups. NW/HW/OV: sequences too long for the skewed arithmetic of the stream, same geometry;
+       SW (width 17, lanes_per_seq <= 16): the longest sequences of a long-tailed database, on 4 x lanes_per_seq lanes */
     int side_first_item, side_num_items;
     /* Clock probe (NULL: off): two device counters; wave 0 of every workgroup adds the shader cycles and the constant-rate
        ticks (opal_hip_wall_clock_hz per second) of its lifetime to [0] / [1] -- their ratio is the clock the chip held

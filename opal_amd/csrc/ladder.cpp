@@ -471,24 +471,28 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
     StreamPlan splan;
     if (mode == OPAL_MODE_SW && fits16) splan = plan_stream(Q, A, mode, wantEnd, db->residues, db->pairLen.empty() ? 0 : db->pairLen[0], db->numSeqs);
     // A database with a long tail (Swiss-Prot: sequences of 35 000 residues among 350-residue ones): one sequence would pin its
-    // lanes for longer than the whole search takes, so plan_stream says no -- to the whole database. OPAL_HIP_STREAM_HEAD=1
-    // streams its BULK all the same: the longest items [0, headItems) go to the class kernels (which give them more lanes)
-    // on a side stream, the rest streams beside them; the head is the smallest of 128 / 512 / 2048 / 8192 items that lets the
-    // rest stream. NOT the default: the persistent workgroups of the stream take every CU, and whether the head's launch gets
-    // its workgroups in before them is up to the dispatch order of two hardware queues -- P18080 x the Swiss-Prot shape ran
-    // 13.9 ms per search under the profiler (which serialises submission), 14.4 / 15.4 / 18.9 ms without it, against a
-    // steady 15.3 ms on the class kernels alone (profiles/r03_stream_head.txt).
+    // lanes for longer than the whole search takes, so plan_stream says no -- to the whole database. Its BULK streams all
+    // the same: the longest items [0, headItems) run on the class body (4G lanes each) as the first workgroups of the
+    // streaming launch itself, the rest streams behind them. The head is the smallest of 128 / 512 / 2048 items that lets the
+    // rest stream. (As a launch of its own on a side stream the head started before or after the stream's persistent workgroups
+    // from run to run: P18080 x the Swiss-Prot shape 13.9 ms under the profiler, 14.4 / 15.4 / 18.9 ms without it, against
+    // 15.3 ms on the class kernels alone -- profiles/r03_stream_head.txt.)
     int headItems = 0;
-    if (mode == OPAL_MODE_SW && fits16 && !splan.G && narrow != 16 && !chunkedQuery && getenv("OPAL_HIP_STREAM_HEAD")) {
+    if (mode == OPAL_MODE_SW && fits16 && !splan.G && !chunkedQuery && !getenv("OPAL_HIP_NO_STREAM_HEAD")) {
         long long headRes = 0;
         int at = 0;
-        for (int cut : {128, 512, 2048, 8192}) {
+        for (int cut : {128, 512, 2048}) {
             if ((long long)cut * 8 > db->numSeqs) break;
             for (; at < cut; at++) headRes += db->pairLen[(size_t)at];
             if (headRes * 4 > db->residues) break;
             const StreamPlan rest = plan_stream(Q, A, mode, wantEnd, db->residues - headRes, db->pairLen[(size_t)cut], db->numSeqs - cut);
-            if (rest.G && rest.passes == 1) { splan = rest; headItems = cut; break; }
+            if (rest.G && rest.passes == 1 && rest.width == 17 && rest.G <= 16 && rest.rows <= (wantEnd ? 36 : 39)) { splan = rest; headItems = cut; break; }  // (the shapes of inst_stream17head.hip)
         }
+    }
+    if (const char* hi = getenv("OPAL_HIP_STREAM_HEAD_ITEMS")) {  // test hook: a head of that many items on a (forced) stream
+        const int n = atoi(hi);
+        if (mode == OPAL_MODE_SW && splan.G && splan.passes == 1 && splan.width == 17 && splan.G <= 16 && splan.rows <= (wantEnd ? 36 : 39) && n > 0 && n < 2 * P)
+            headItems = n;
     }
     // While the database is still arriving (opalSearchDatabase) a streaming launch would have to wait for the last chunk: at 16
     // lanes per sequence or fewer, where streaming gains 2-4 % over the class kernels, the sliced class launches that start
@@ -525,17 +529,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                 if (debug_on())
                     fprintf(stderr, "[opal] streaming launch width=%d G=%d rows=%d end=%d items=[%d,+%d)\n", splan.width, splan.G, splan.rows, wantEnd,
                             a.first_item, a.num_items);
-                void* headJoin = nullptr;
-                if (headItems > 0) {  // the long head on the class kernels, on a side stream, submitted first
-                    void* fork = db->event(8);
-                    void* side = db->stream(0);
-                    headJoin = db->event(9);
-                    SearchCtx ch = c;
-                    ch.stream = side;
-                    if (!fork || !side || !headJoin || opal_hip_event_record(fork, st) || opal_hip_stream_wait_event(side, fork)) return OPAL_ERR_NO_SIMD_SUPPORT;
-                    if (launch_range(ch, narrow, wantEnd, 0, nullptr, 0, headItems, seqLenOf, db->ovfCount.p)) return OPAL_ERR_NO_SIMD_SUPPORT;
-                    if (opal_hip_event_record(headJoin, side)) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
-                }
+                a.side_first_item = 0; a.side_num_items = headItems;  // (the long head: class body, first workgroups of the launch)
                 if (!gate_items(db, st, 0, 2 * P)) return OPAL_ERR_NO_SIMD_SUPPORT;
                 if (splan.passes > 1) {
                     // a query beyond one wave: row chunks from the top, the first one partial (as launch_chunked cuts them), a
@@ -555,7 +549,6 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                     }
                 } else
                 rc = opal_hip_launch_stream(&a, db->ovfCount.p + 2) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
-                if (headJoin && opal_hip_stream_wait_event(st, headJoin)) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
                 count(CNT_STREAM_SW);
             }
             else if (narrow == 16) rc = launch_range(c, 16, wantEnd, 0, nullptr, 0, nNarrow, pairLenOf, db->ovfCount.p);

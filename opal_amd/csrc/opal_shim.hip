@@ -505,7 +505,8 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
         (!a->chunk_flags || (a->boundary && a->chunk_rows >= 1 && a->chunk_row0 >= 0 && a->chunk_row0 + a->chunk_rows <= a->query_length &&
                              /* a partial chunk is the first one (SW/HW/OV: padded above) or the last one (NW: padded below) */
                              (a->chunk_rows == G * a->rows_per_lane || (a->chunk_flags & (a->mode == MODE_NW ? 2 : 1)) == 0))))
-        fn = pick_stream(a->width, a->mode, a->want_end, a->rows_per_lane, a->chunk_flags);
+        fn = (a->mode == MODE_SW && a->side_num_items > 0) ? (a->width == 17 && !a->chunk_flags ? opal_stream_s17head(a->rows_per_lane, a->want_end) : nullptr)
+                                                           : pick_stream(a->width, a->mode, a->want_end, a->rows_per_lane, a->chunk_flags);
     if (!fn) {
         snprintf(g_err, sizeof g_err, "unlaunchable streaming shape: width=%d G=%d rows=%d Q=%d", a->width, G, a->rows_per_lane, a->query_length);
         fprintf(stderr, "[opal-hip] %s\n", g_err);
@@ -543,6 +544,17 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
     const int perBlock = STREAM_WAVES * (64 / G);
     int blocks = (a->num_items + perBlock - 1) / perBlock;
     if (blocks > cus) blocks = cus;
+    size_t ldsLaunch = lds;
+    if (a->mode == MODE_SW && a->side_num_items > 0) {
+        /* the head of a long-tailed database on the class body, 4G lanes x ceil(rows/4) rows, first in the grid */
+        if (4 * G > 64) { snprintf(g_err, sizeof g_err, "side items: SW streams at 16 lanes per sequence or fewer only"); return 2; }
+        const int perSide = STREAM_SIDE_WAVES * (64 / (4 * G));
+        sp.side = KClass{log2G + 2, a->side_first_item, a->side_num_items, 0};
+        sp.sideBlocks = (a->side_num_items + perSide - 1) / perSide;
+        const size_t need = lds_bytes(17, 4 * G, (a->rows_per_lane + 3) / 4, a->alphabet_length);
+        if (need > ldsLaunch) ldsLaunch = need;
+        if (ldsLaunch > 160 * 1024) { snprintf(g_err, sizeof g_err, "side items: profile needs %zu bytes of LDS", ldsLaunch); return 2; }
+    }
     if (a->mode != MODE_SW && a->side_num_items > 0) {
         const int perSide = STREAM_SIDE_WAVES * (64 / G);
         sp.side = KClass{log2G, a->side_first_item, a->side_num_items, 0};
@@ -550,8 +562,8 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
         if (blocks + sp.sideBlocks > cus && blocks > 1) blocks = std::max(1, cus - sp.sideBlocks);  // every workgroup resident from the start
     }
     if (const char* e = getenv("OPAL_HIP_STREAM_BLOCKS")) { const int b = atoi(e); if (b >= 1) blocks = b; }  // test hook
-    if (lds > 64 * 1024 && raise_lds_limit((const void*)fn)) return 1;
-    hipLaunchKernelGGL(fn, dim3(blocks + sp.sideBlocks), dim3(STREAM_WAVES * 64), lds, (hipStream_t)a->stream, sp);
+    if (ldsLaunch > 64 * 1024 && raise_lds_limit((const void*)fn)) return 1;
+    hipLaunchKernelGGL(fn, dim3(blocks + sp.sideBlocks), dim3(STREAM_WAVES * 64), ldsLaunch, (hipStream_t)a->stream, sp);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("streaming kernel launch", e);
 }

@@ -30,11 +30,13 @@
 struct StreamParams {
     KParams base;  // work == nullptr; firstItem/numItems: the item range (pair*2+half); log2G: lanes per sequence
     int* next;     // device counter (zeroed before the launch): next item of the range to hand out
-    // NW/HW/OV only: the first `sideBlocks` workgroups of the grid run the UNSKEWED class body on the item range `side`
-    // (sequences too long for the skewed arithmetic), STREAM_SIDE_WAVES waves each; the streaming workgroups follow
+    // The first `sideBlocks` workgroups of the grid run the class body on the item range `side`, STREAM_SIDE_WAVES waves each;
+    // the streaming workgroups follow. NW/HW/OV: the unskewed body, same geometry (sequences too long for the skewed
+    // arithmetic); SW, width 17: 4G lanes x S/4 rows (the longest sequences of a long-tailed database)
     KClass side;
     int sideBlocks;
 };
+#define STREAM_SW_SIDE_MAX_ROWS 39  // SW streams instantiated with the class body for side items: rows 1..39 (40: one register short)
 #define STREAM_SIDE_WAVES 4  // one wave per SIMD: these few sequences are the critical path, they run at the lone-wave rate
 typedef void (*StreamFn)(const StreamParams);
 
@@ -136,8 +138,9 @@ __device__ __forceinline__ void stream_fetch(SlotStream& st, const KParams& p, i
 // every lane one column. Separator and pad columns carry zeros, as the top boundary of local alignment does everywhere.
 // A sequence's score is the maximum over the chunks (read-modify-write of outScore: one chunk at a time); with end
 // locations the best cell so far stays unless this chunk's is better (higher score, or the same in a smaller column).
-template <int WIDTH, int S, bool SWEND = false, bool CHUNK = false>
+template <int WIDTH, int S, bool SWEND = false, bool CHUNK = false, bool SIDE = false>
 __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const StreamParams sp) {
+    static_assert(!SIDE || (WIDTH == 17 && !CHUNK), "side items: single-launch SW streams of width 17");
     using V = Vec<WIDTH>;
     using reg = typename V::reg;
     using elem = typename V::elem;
@@ -147,6 +150,16 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     constexpr int LANE_BYTES = opal_lane_bytes(ES, S, WIDTH == 18);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const KParams& p = sp.base;
+    if constexpr (SIDE) {  // (instantiations of their own, inst_stream17head.hip: inside the plain kernels the extra body cost C4 1.1 %)
+        if ((int)blockIdx.x < sp.sideBlocks) {
+            // The head of a long-tailed database (Swiss-Prot: 35 000 residues among 350): sequences that would pin their G lanes
+            // for longer than the whole search takes run on the class body instead, on 4G lanes x S/4 rows, as the FIRST
+            // workgroups of this very grid -- inside one launch the dispatch order is ours; as a launch of their own on a
+            // side stream they started before or after the persistent workgroups from run to run (13.9 / 15.4 / 18.9 ms).
+            opal_dp_body<17, MODE_SW, SWEND ? FLAG_SWEND : 0, (S + 3) / 4>(p, sp.side, (int)blockIdx.x, STREAM_SIDE_WAVES);
+            return;
+        }
+    }
 
     const int log2G = p.log2G;
     const int G = 1 << log2G;
@@ -797,6 +810,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
 }
 
 StreamFn opal_stream_s17(int rows);     // width 17 (4-byte profile entries), score only: rows 1..40
+StreamFn opal_stream_s17head(int rows, int want_end);  // with the class body for side items (SIDE): rows 1..39, with end locations 1..36
 StreamFn opal_stream_s17chunk(int rows);  // one row chunk of a longer query (CHUNK), width 17, score only: rows 16..40
 StreamFn opal_stream_s17chunkend(int rows);  // ... with end locations: rows 16..32
 StreamFn opal_stream_s18(int rows);     // width 18 (2-byte entries), score only: rows 20..40

@@ -605,6 +605,35 @@ def test_streaming_global_row_chunks(mode, qlen, geometry, ours, oracle, monkeyp
         np.testing.assert_array_equal(got[1], want[1])
 
 
+@pytest.mark.parametrize("qlen,lanes,head", [(100, "4", "50"), (300, "8", "64"), (513, "16", "37"), (560, "16", "128")])
+def test_streaming_with_a_head_on_the_class_body(qlen, lanes, head, ours, oracle, monkeypatch):
+    """A long-tailed database: the longest sequences run on the class body (4 x the lanes) as the first workgroups of the
+    streaming launch, the rest streams behind them -- forced here with a head of a given size (the 36 000-residue, the
+    5000-residue sequence and the near copies of the query are in it), score and end locations, 16-bit overflows included."""
+    from opal_amd.score_matrix import blosum50
+    q, db = _stream_db(qlen)
+    m = blosum50()[1]
+    monkeypatch.setenv("OPAL_HIP_STREAM", "1")
+    monkeypatch.setenv("OPAL_HIP_LANES_PER_SEQ", lanes)
+    monkeypatch.setenv("OPAL_HIP_NARROW", "17")
+    monkeypatch.setenv("OPAL_HIP_STREAM_HEAD_ITEMS", head)
+    for go, ge in ((11, 1), (3, 1)):
+        for st in (0, 1):
+            got = ours.search(q, db, go, ge, m, st, MODES["SW"])[:4]
+            want = oracle.search(q, db, go, ge, m, st, MODES["SW"])
+            if st == 0:
+                assert got[0] == want[0] == 0
+                np.testing.assert_array_equal(got[1], want[1], err_msg=f"stream head q{qlen} G={lanes} head={head} gaps {go}/{ge}")
+            else:
+                _check(got, want, "SW", f"stream head + end q{qlen} G={lanes} head={head} gaps {go}/{ge}")
+    # scores beyond 16 bits in the head and behind it: both parts append to the same re-run list
+    m60 = blosum50()[1] * 60
+    got = ours.search(q, db, 660, 60, m60, 0, MODES["SW"])[:4]
+    want = oracle.search(q, db, 660, 60, m60, 0, MODES["SW"])
+    assert got[0] == want[0] == 0 and (want[1] > 32767).sum() >= 2
+    np.testing.assert_array_equal(got[1], want[1])
+
+
 def test_streaming_is_what_long_queries_run_on(ours):
     """Without any forcing, a long query on a database large enough for the longest sequence not to dominate takes the
     streaming path (with or without end locations); a short query and a small database do not."""
