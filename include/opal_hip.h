@@ -274,6 +274,11 @@ int opalx_debug_order(const int* lens, int n, int* seq, int* len, unsigned long 
 /* Test hook, no device needed: stress of the library's host thread pool (`rounds` jobs of 1..300 tasks, synchronous and
    asynchronous in turn, from `callers` threads at once). 0 if every task of every job ran exactly once. */
 int opalx_debug_pool_selftest(int rounds, int callers);
+/* Test hook, no device needed: what the scheduler would stream a search on (planner.cpp, plan_stream): out[0..3] = width
+   (17 / 18; 0: the class kernels), lanes per sequence, rows per lane, passes (> 1: the query runs in that many row chunks).
+   `residues`, `longest`, `num_seqs` describe the database. Returns 0. */
+int opalx_debug_plan_stream(int query_length, int alphabet_length, int mode, int want_end, long long residues, int longest,
+                            int num_seqs, int* out);
 void opalx_db_destroy(OpalxDb* db);
 /* Clock probe for measurements (bench.py): while enabled, every search on this handle also measures the shader clock
    its DP kernels ran at (cycle counter / constant-rate counter over the lifetime of one wave per workgroup) and reads it

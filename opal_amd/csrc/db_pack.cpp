@@ -502,6 +502,14 @@ extern "C" void opalx_db_destroy(OpalxDb* db) {
     delete db;
 }
 
+// Test hook (no device needed): the streaming plan of a search, see include/opal_hip.h.
+extern "C" int opalx_debug_plan_stream(int query_length, int alphabet_length, int mode, int want_end, long long residues, int longest,
+                                       int num_seqs, int* out) {
+    const opal_host::StreamPlan sp = opal_host::plan_stream(query_length, alphabet_length, mode, want_end, residues, longest, num_seqs);
+    out[0] = sp.G ? sp.width : 0; out[1] = sp.G; out[2] = sp.rows; out[3] = sp.G ? sp.passes : 0;
+    return 0;
+}
+
 // Test hook (no device needed): the ordering of opalx_db_create* / opalSearchDatabase on plain host arrays. Fills
 // seq / len / off (capacity entries each) in item order; returns the number of items (sequences of length > 0, rounded up
 // to even), or -1 if capacity is too small.

@@ -260,3 +260,40 @@ def test_host_code_sanitized():
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", "not sanitized"], env=env,
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
+
+
+def test_streaming_plan_of_the_scheduler(monkeypatch):
+    """planner.cpp::plan_stream on the host alone: which searches stream (and on what geometry), which stay on the class kernels."""
+    import ctypes as C
+    L = C.CDLL(LIB)
+    L.opalx_debug_plan_stream.restype = C.c_int
+    L.opalx_debug_plan_stream.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    for e in ("OPAL_HIP_STREAM", "OPAL_HIP_LANES_PER_SEQ", "OPAL_HIP_NARROW", "OPAL_HIP_STREAM_CHUNKS", "OPAL_HIP_NO_STREAM_CHUNKS"):
+        monkeypatch.delenv(e, raising=False)
+    SW, NW = 3, 0
+    def plan(q, mode=SW, end=0, nseq=100000, mean=350, longest=3776, a=24):
+        out = (C.c_int * 4)()
+        assert L.opalx_debug_plan_stream(q, a, mode, end, nseq * mean, longest, nseq, out) == 0
+        return tuple(out)
+    # a 300-aa query on 100 000 sequences: three sequences per slot -- class kernels; on a million: streams on 8 lanes
+    assert plan(300) == (0, 0, 0, 0)
+    w, g, rows, passes = plan(300, nseq=1000000)
+    assert (w, g, passes) == (17, 8, 1) and g * rows >= 300
+    # 2000 aa: 64 lanes, 2-byte profile entries, one launch
+    assert plan(2000) == (18, 64, 32, 1)
+    # beyond one wave: row chunks of equal size on 32 lanes, 4-byte entries (SW with and without end locations, NW)
+    assert plan(3000) == (17, 32, 32, 3)
+    assert plan(3000, end=1) == (17, 32, 32, 3)
+    assert plan(3000, mode=NW, end=1) == (17, 32, 32, 3)
+    w, g, rows, passes = plan(10000)
+    assert w == 17 and passes >= 8 and passes * g * rows >= 10000 and (passes - 1) * g * rows < 10000
+    # a small database: the longest sequence would outlast the whole search on its lanes -- class kernels
+    assert plan(2000, nseq=300) == (0, 0, 0, 0)
+    assert plan(3000, nseq=300) == (0, 0, 0, 0)
+    # a 35 000-residue sequence among 540 000 (the published shape), 513-aa query: not as a whole ...
+    assert plan(513, nseq=541762, mean=356, longest=35213) == (0, 0, 0, 0)
+    # ... but what is left behind its 128 longest sequences streams on 16 lanes
+    w, g, rows, passes = plan(513, nseq=541762 - 128, mean=355, longest=9000)
+    assert (w, g, passes) == (17, 16, 1) and rows == 33
+    # an alphabet whose profile leaves no room for a streaming geometry
+    assert plan(3000, a=250) == (0, 0, 0, 0)
