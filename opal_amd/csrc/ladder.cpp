@@ -695,11 +695,19 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
             db->quiesce();
             return OPAL_ERR_NO_SIMD_SUPPORT;
         }
+        void* join16 = nullptr;
         if (gplan.G && gplan.passes > 1 && q32 > p32) {
-            // (streamed row chunks: the 16-bit sequences that cannot be skewed take the class kernels' chunks, after the 32-bit ones)
-            const int e = narrow == 16 ? launch_range(c32, 16, 0, 0, nullptr, p32, q32 - p32, pairLenOf, db->ovfCount.p)
-                                       : launch_range(c32, narrow, 0, 0, nullptr, 2 * p32, 2 * (q32 - p32), seqLenOf, db->ovfCount.p);
-            if (e) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
+            // (streamed row chunks: the 16-bit sequences that cannot be skewed take the class kernels' chunks -- on a second side
+            // stream, beside the 32-bit ones: each of these launches is one lone-wave tail, 3.5-4 ms next to a stream, and four
+            // of them in a row took as long as the three streamed chunks, 15 ms)
+            SearchCtx c16 = c32;
+            if (c32.stream && 2 * p32 > nBad) {
+                void* side2 = db->stream(1);
+                if (side2 && !opal_hip_stream_wait_event(side2, db->event(8))) { c16.stream = side2; join16 = db->event(10); }
+            }
+            const int e = narrow == 16 ? launch_range(c16, 16, 0, 0, nullptr, p32, q32 - p32, pairLenOf, db->ovfCount.p)
+                                       : launch_range(c16, narrow, 0, 0, nullptr, 2 * p32, 2 * (q32 - p32), seqLenOf, db->ovfCount.p);
+            if (e || (join16 && opal_hip_event_record(join16, c16.stream))) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
         }
         if (c32.stream && (!join32 || opal_hip_event_record(join32, c32.stream))) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
         if (P > q32) {
@@ -708,7 +716,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                                        : launch_range(c, narrow, 0, 0, nullptr, 2 * p32, 2 * (P - p32), seqLenOf, db->ovfCount.p);
             if (e) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
         }
-        if (c32.stream && opal_hip_stream_wait_event(st, join32)) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
+        if ((c32.stream && opal_hip_stream_wait_event(st, join32)) || (join16 && opal_hip_stream_wait_event(st, join16))) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
     }
     if (evStop) { opal_hip_event_record(evStop, st); db->asyncEvents = db->asyncTimed; }
     // (a caller that copies the results back on the same stream and waits for that copy needs no wait of its own here)

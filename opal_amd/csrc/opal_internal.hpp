@@ -214,7 +214,7 @@ struct OpalxDb {
     void* copyStream2 = nullptr;  // odd chunks (the per-copy set-up of one overlaps the transfer of the other)
     void* auxStream = nullptr;
     void* streams[3] = {nullptr, nullptr, nullptr};
-    void* events[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // 0 fork, 1-3 joins, 4-5 timing, 6 aux join, 7 fill, 8-9 fork / join of a 32-bit prefix beside row chunks
+    void* events[11] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // 0 fork, 1-3 joins, 4-5 timing, 6 aux join, 7 fill, 8-10 fork / joins of the 32-bit and unskewable prefixes beside row chunks
     void* main() {
         if (!mainStream) mainStream = opal_hip_stream_create();
         return mainStream;

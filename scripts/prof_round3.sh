@@ -27,6 +27,8 @@ for c in $CFGS; do
     w32)   ARGS="--workload c2 --seqs 20000"; export OPAL_HIP_FORCE_WIDTH=32 ;;
     q3000) ARGS="--workload c5 --total-seqs 100000 --qlen 3000" ;;
     q3000nw) ARGS="--workload c5 --total-seqs 100000 --qlen 3000 --mode NW --search-type 1" ;;
+    q3000end) ARGS="--workload c5 --total-seqs 100000 --qlen 3000 --search-type 1" ;;
+    sprot) ARGS="--workload sprot" ;;
   esac
   D=$OUT/$c; mkdir -p $D
   python3 $B $ARGS $COMMON > $D/bench.json 2> $D/bench.err
