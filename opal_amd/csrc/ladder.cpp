@@ -460,7 +460,8 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
         if (narrow == 18 && !fits(18)) narrow = 16;
         // Queries that no single launch holds at any width (more than 64 lanes x 40 rows) run in row chunks: on the plain
         // kernels with 2-byte profile entries, whose chunk profiles leave room for twice the waves of the 4-byte ones and which,
-        // unlike the packed pairs, issue at full rate (3000-aa query x 100 000 sequences: ... GCUPS against 5 260 at width 16)
+        // unlike the packed pairs, issue at full rate (3000-aa query x 100 000 sequences, class-kernel chunks: SW + end 5 110 against
+        // 3 470 GCUPS at width 16, SW score 5 320 against 4 700; what streams its chunks -- stream_kernel.hpp -- does not come here)
         chunkedQuery = !fits(17) && !fits(18) && !fits(16);
         if (!getenv("OPAL_HIP_NARROW") && !(force && atoi(force) == 17) && chunkedQuery) {
             narrow = mode == OPAL_MODE_HW ? 17 : 18;  // (HW: no 2-byte-profile chunk kernels beyond 16 rows per lane, inst_s18multi.hip)
