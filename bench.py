@@ -67,6 +67,7 @@ def parse_args(argv=None):
     ap.add_argument("--gap-ext", type=int, default=1)
     ap.add_argument("--mode", default="SW")
     ap.add_argument("--search-type", type=int, default=None)
+    ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2], help="N = 1: searches queued on the handle (2: step i is enqueued behind step i-1, then the host waits for step i-1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--query-fasta", default=None, help="use the first record of this FASTA file as the query")
@@ -395,6 +396,7 @@ def main():
     step_no = [0]
 
     pending = [None]  # (N > 1) the result buffer whose exchange is still to be issued
+    inflight = [0]    # (N = 1) searches enqueued and not yet waited for
 
     def exchange(b):
         # the path's only exchange: ONE gather of the per-sequence result block to rank 0, which puts the
@@ -411,8 +413,21 @@ def main():
             done[b].synchronize()
         score, endq, endt = out[:npad], (out[npad:2 * npad] if want_end else None), (out[2 * npad:] if want_end else None)
         if not multi:
-            rc, kms = pdb.search_device(query, args.gap_open, args.gap_ext, matrix, args.search_type, mode, score.data_ptr(),
-                                        endq.data_ptr() if want_end else 0, endt.data_ptr() if want_end else 0)
+            # Two searches in flight: step i is enqueued behind step i-1 on the library's stream (no host round trip between
+            # them on the GPU), then the host waits for step i-1 and reads its kernel time. A search is still one complete
+            # pass -- header upload, every DP launch, results in HBM -- and the K timed steps end with a wait for the last one.
+            rc = pdb.search_device_async(query, args.gap_open, args.gap_ext, matrix, args.search_type, mode, score.data_ptr(),
+                                         endq.data_ptr() if want_end else 0, endt.data_ptr() if want_end else 0)
+            kms = None
+            if rc == 0 and (inflight[0] == 1 or args.in_flight == 1):
+                rc, kms = pdb.wait()
+            elif rc == 0:
+                inflight[0] = 1
+            if rc != 0:
+                raise SystemExit(f"search failed rc={rc}")
+            if kms is not None:
+                kernel_ms.append(kms)
+            return
         else:
             # the search is only ENQUEUED; while the GPU works on it the host issues the previous step's exchange (its
             # Python / RCCL call overhead, ~0.2 ms, would otherwise sit between two searches), then waits for the search
@@ -431,6 +446,12 @@ def main():
         if multi and pending[0] is not None:
             exchange(pending[0])
             pending[0] = None
+        if not multi and inflight[0] == 1:  # the last step's search
+            rc, kms = pdb.wait()
+            inflight[0] = 0
+            if rc != 0:
+                raise SystemExit(f"search failed rc={rc}")
+            kernel_ms.append(kms)
 
     def fence():
         if multi:
@@ -545,7 +566,9 @@ def main():
                                    f"{args.gap_open}/{args.gap_ext}, 16-bit first rung, 32-bit re-run",
                        "cells_per_step": total_cells, "cells_per_step_rank0": cells,
                        "parallelism": f"db-shard x{world} (64-seq groups dealt by residue count), 1 gather" if world > 1 else
-                                      "one GPU, results written at their database index"},
+                                      ("one GPU, results written at their database index; " +
+                                       ("two searches queued on the handle: step i enqueued behind step i-1, then step i-1 waited for" if args.in_flight == 2
+                                        else "one search at a time: enqueued, waited for"))},
             "verified": verified,
             "verify": {"sample": f"{len(pick)} sequences of every rank's shard (fixed seeds) vs oracle/opal_oracle.c, verdicts all-reduced"
                                  + ("; the gathered block vs rank 0's own values" if world > 1 else ""),

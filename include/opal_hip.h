@@ -191,6 +191,7 @@ void* opal_hip_event_create(void);
 void* opal_hip_event_create_untimed(void);   /* ordering only (hipEventDisableTiming) */
 void opal_hip_event_destroy(void* ev);
 int opal_hip_event_record(void* ev, void* stream);
+int opal_hip_event_sync(void* ev);   /* host-waits for the event */
 float opal_hip_event_elapsed_ms(void* start, void* stop); /* synchronises on `stop` */
 
 /* Start locations on the device (rev_kernel.hip): for every listed sequence, the score-limited reverse pass of
@@ -307,10 +308,13 @@ int opalx_search_device(OpalxDb* db, const unsigned char* query, int query_lengt
 
 /* The same without the wait: the kernels are enqueued on the handle's stream and the call returns, so that the caller
    can do other host work (bench.py: the previous step's gather) while the GPU searches; opalx_db_wait waits for the search
-   and reports its kernel time. One search in flight per handle: call opalx_db_wait before the next search on it. A search
-   that needs a host decision midway (a 16-bit rung whose scores can saturate: the re-run list is read back) waits
-   internally and is complete on return. Return codes as opalx_search_device (a 32-bit wrap is reported by the call that
-   detects it). */
+   and reports its kernel time. Up to OPALX_ASYNC_DEPTH - 1 searches may be queued on a handle (each into result buffers
+   of its own): they run one after the other on the handle's stream, with no host round trip between them, and every
+   opalx_db_wait waits for the OLDEST one not yet waited for (first in, first out); with none outstanding it waits for the
+   stream. One more opalx_search_device_async than that returns OPAL_ERR_NO_SIMD_SUPPORT and enqueues nothing. A search that
+   needs a host decision midway (a 16-bit rung whose scores can saturate: the re-run list is read back) waits internally
+   and is complete on return. Return codes as opalx_search_device (a 32-bit wrap is reported by the call that detects it). */
+#define OPALX_ASYNC_DEPTH 4
 int opalx_search_device_async(OpalxDb* db, const unsigned char* query, int query_length,
                               int gap_open, int gap_ext, const int* score_matrix, int alphabet_length,
                               int search_type, int mode, int* d_score, int* d_end_query, int* d_end_target);

@@ -149,7 +149,8 @@ class PreparedDb:
                                                     C.c_void_p(d_score), C.c_void_p(d_end_q or None), C.c_void_p(d_end_t or None))
 
     def wait(self):
-        """opalx_db_wait: wait for the search launched last. Returns (rc, kernel_ms)."""
+        """opalx_db_wait: wait for the OLDEST search enqueued by search_device_async and not yet waited for (up to three may be
+        queued on a handle). Returns (rc, kernel_ms of that search)."""
         ms = C.c_float(0)
         rc = _lib.lib().opalx_db_wait(self._h, C.byref(ms))
         return rc, ms.value

@@ -168,6 +168,9 @@ void db_release(OpalxDb* db) {
     opal_hip_stream_destroy(db->copyStream2); db->copyStream2 = nullptr;
     opal_hip_stream_destroy(db->auxStream); db->auxStream = nullptr;
     for (void*& ev : db->events) { opal_hip_event_destroy(ev); ev = nullptr; }
+    for (void*& ev : db->asyncEv) { opal_hip_event_destroy(ev); ev = nullptr; }
+    for (int i = 0; i < OPALX_ASYNC_DEPTH; i++) { opal_hip_event_destroy(db->hdrEv[i]); db->hdrEv[i] = nullptr; db->hdrEvSet[i] = false; }
+    db->asyncHead = db->asyncTail = 0;
     for (void*& ev : db->gate.events) { opal_hip_event_destroy(ev); ev = nullptr; }
     db->gate.events.clear();
 }

@@ -343,12 +343,20 @@ int ensure_query_buffers(OpalxDb* db, const unsigned char* query, int Q, const i
     const size_t mb = (size_t)A * A * sizeof(int);
     const size_t head = 32;  // {counters[4], clock probe[2 x u64]}
     const size_t bytes = (head + mb + (size_t)std::max(Q, 1) + 15) / 16 * 16;
-    if (!db->header.ensure(bytes, 1.5) || !db->hHeader.ensure(bytes, 1.5)) return 1;
-    unsigned char* h = db->hHeader.p;
+    // (searches may be queued behind each other, opalx_search_device_async: a buffer that has to grow waits for them first)
+    if ((db->header.cap < bytes || db->hHeader.cap < OPALX_ASYNC_DEPTH * bytes) && (db->header.p || db->hHeader.p) && opal_hip_stream_sync(db->main())) return 1;
+    if (!db->header.ensure(bytes, 1.5) || !db->hHeader.ensure(OPALX_ASYNC_DEPTH * bytes, 1.5)) return 1;
+    // the pinned staging slot of this search: free once the upload recorded behind its last use has run
+    const int slot = (int)(db->hdrSeq++ % OPALX_ASYNC_DEPTH);
+    if (db->hdrEvSet[slot] && opal_hip_event_sync(db->hdrEv[slot])) return 1;
+    unsigned char* h = db->hHeader.p + (size_t)slot * (db->hHeader.cap / OPALX_ASYNC_DEPTH / 16 * 16);
     memset(h, 0, head);
     memcpy(h + head, M, mb);
     if (Q) memcpy(h + head + mb, query, (size_t)Q);
     if (opal_hip_memcpy_h2d(db->header.p, h, head + mb + (size_t)Q, db->main())) return 1;
+    if (!db->hdrEv[slot]) db->hdrEv[slot] = opal_hip_event_create_untimed();
+    db->hdrEvSet[slot] = db->hdrEv[slot] && !opal_hip_event_record(db->hdrEv[slot], db->main());
+    if (!db->hdrEvSet[slot] && opal_hip_stream_sync(db->main())) return 1;  // (no event: the slot is free once the stream is idle)
     db->ovfCount.p = (int*)db->header.p;
     db->matrix.p = (int*)(db->header.p + head);
     db->query.p = db->header.p + head + mb;
@@ -511,7 +519,12 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
     void* evStart = nullptr; void* evStop = nullptr;
     const bool timed = kernelMs || db->asyncTimed;  // (asyncTimed: opalx_search_device_async -- opalx_db_wait reads the events)
     db->asyncEvents = false;
-    if (timed) { evStart = db->event(4); evStop = db->event(5); }
+    if (db->asyncTimed) {  // (queued searches time themselves with the events of their own slot)
+        const int slot = (int)(db->asyncHead % OPALX_ASYNC_DEPTH);
+        for (int i = 0; i < 2; i++)
+            if (!db->asyncEv[2 * slot + i]) db->asyncEv[2 * slot + i] = opal_hip_event_create();
+        evStart = db->asyncEv[2 * slot]; evStop = db->asyncEv[2 * slot + 1];
+    } else if (timed) { evStart = db->event(4); evStop = db->event(5); }
     if (evStart) opal_hip_event_record(evStart, st);
 
     if (mode == OPAL_MODE_SW) {

@@ -128,10 +128,14 @@ extern "C" int opalx_search_device_async(OpalxDb* db, const unsigned char* query
                                          int* d_score, int* d_end_query, int* d_end_target) {
     if (!db) return OPAL_ERR_NO_SIMD_SUPPORT;
     if (search_type != OPAL_SEARCH_SCORE && (!d_end_query || !d_end_target)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (db->asyncHead - db->asyncTail >= OPALX_ASYNC_DEPTH - 1) return OPAL_ERR_NO_SIMD_SUPPORT;  // the queue of this handle is full
     db->asyncTimed = true;
     const int rc = search_core(db, query, query_length, gap_open, gap_ext, score_matrix, alphabet_length, search_type, mode,
                                d_score, d_end_query, d_end_target, nullptr, /*finalSync=*/false);
     db->asyncTimed = false;
+    if (db->asyncEvents) db->asyncHead++;  // (its events were recorded: opalx_db_wait will wait for them)
+    else { db->quiesce(); db->asyncTail = db->asyncHead; }  // (failed before its end: nothing of this handle stays in flight)
+    db->asyncEvents = false;
     return rc;
 }
 
@@ -139,9 +143,12 @@ extern "C" int opalx_db_wait(OpalxDb* db, float* kernel_ms) {
     if (kernel_ms) *kernel_ms = 0.f;
     if (!db) return OPAL_ERR_NO_SIMD_SUPPORT;
     void* st = db->main();
-    if (!st || opal_hip_stream_sync(st)) return OPAL_ERR_NO_SIMD_SUPPORT;
-    if (kernel_ms && db->asyncEvents) *kernel_ms = opal_hip_event_elapsed_ms(db->event(4), db->event(5));
-    db->asyncEvents = false;
+    if (!st) return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (db->asyncTail == db->asyncHead) return opal_hip_stream_sync(st) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;  // nothing queued: the stream
+    const int slot = (int)(db->asyncTail % OPALX_ASYNC_DEPTH);
+    db->asyncTail++;
+    if (opal_hip_event_sync(db->asyncEv[2 * slot + 1])) return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (kernel_ms) *kernel_ms = opal_hip_event_elapsed_ms(db->asyncEv[2 * slot], db->asyncEv[2 * slot + 1]);
     return 0;
 }
 

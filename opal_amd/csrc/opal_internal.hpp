@@ -165,8 +165,16 @@ struct OpalxDb {
     opal_host::PinVec<uint64_t> hPairOff;
     size_t numTokens = 0;
     bool tokensValid = false;
-    bool asyncTimed = false;   // a search launched by opalx_search_device_async is in flight (its events 4/5 get recorded)
-    bool asyncEvents = false;  // ... and they were
+    bool asyncTimed = false;   // search_core is running for opalx_search_device_async: it times itself with the events of slot asyncHead
+    bool asyncEvents = false;  // ... and recorded them
+    // searches queued by opalx_search_device_async and not yet waited for: [asyncTail, asyncHead), slot = index % OPALX_ASYNC_DEPTH
+    unsigned asyncHead = 0, asyncTail = 0;
+    void* asyncEv[2 * OPALX_ASYNC_DEPTH] = {};   // their start / stop events (timed)
+    // the pinned staging copies of the search header (query, matrix, zeroed counters): one slot per search in flight, reused
+    // only after the upload recorded behind it has run
+    unsigned hdrSeq = 0;
+    void* hdrEv[OPALX_ASYNC_DEPTH] = {};
+    bool hdrEvSet[OPALX_ASYNC_DEPTH] = {};
     bool clockProbe = false;   // opalx_db_clock_probe
     bool timelineProbe = false;
     opal_host::DevBuf<unsigned long long> timeline;  // [2 x 65536 workgroups], zeroed before a probed search

@@ -155,6 +155,10 @@ extern "C" void* opal_hip_event_create_untimed(void) {
     return (void*)ev;
 }
 extern "C" void opal_hip_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+extern "C" int opal_hip_event_sync(void* ev) {
+    hipError_t e = hipEventSynchronize((hipEvent_t)ev);
+    return e == hipSuccess ? 0 : fail("hipEventSynchronize", e);
+}
 extern "C" int opal_hip_event_record(void* ev, void* stream) {
     hipError_t e = hipEventRecord((hipEvent_t)ev, (hipStream_t)stream);
     return e == hipSuccess ? 0 : fail("hipEventRecord", e);

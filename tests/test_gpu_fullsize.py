@@ -527,3 +527,51 @@ def test_one_launch_kernels_equal_separate_launches(mode, c2, oracle, monkeypatc
     np.testing.assert_array_equal(s[pick], so)
     np.testing.assert_array_equal(eq[pick], oq)
     np.testing.assert_array_equal(et[pick], ot)
+
+
+def test_queued_async_searches_first_in_first_out():
+    """opalx_search_device_async: up to three searches queue up on a handle (different queries, modes and result buffers), run
+    one after the other with no host round trip in between, and every opalx_db_wait returns the oldest one's kernel time;
+    a fourth is refused without disturbing the queue; results equal those of the synchronous call."""
+    import torch
+    from opal_amd import synth
+    from opal_amd.api import PreparedDb
+    from opal_amd.score_matrix import blosum50
+    n = 30000
+    res, offs, lens = synth.database(n, seed=42)
+    m = blosum50()[1]
+    pdb = PreparedDb(res, offs)
+    jobs = [(synth.query(200, seed=1), 0, 3), (synth.query(300, seed=2), 1, 0), (synth.query(450, seed=3), 1, 3)]   # (query, search type, mode)
+    want = []
+    for q, st, mode in jobs:
+        out = torch.zeros(3 * n, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        rc, _ = pdb.search_device(q, 11, 1, m, st, mode, out.data_ptr(), out[n:].data_ptr() if st else 0, out[2 * n:].data_ptr() if st else 0)
+        assert rc == 0
+        want.append(out.cpu().numpy().copy())
+    for rounds in range(3):
+        outs = [torch.zeros(3 * n, dtype=torch.int32, device="cuda") for _ in jobs]
+        torch.cuda.synchronize()
+        for (q, st, mode), out in zip(jobs, outs):
+            assert pdb.search_device_async(q, 11, 1, m, st, mode, out.data_ptr(), out[n:].data_ptr() if st else 0, out[2 * n:].data_ptr() if st else 0) == 0
+        extra = torch.zeros(n, dtype=torch.int32, device="cuda")
+        assert pdb.search_device_async(jobs[0][0], 11, 1, m, 0, 3, extra.data_ptr()) != 0   # the queue is full
+        times = []
+        for _ in jobs:
+            rc, kms = pdb.wait()
+            assert rc == 0 and kms > 0
+            times.append(kms)
+        assert times[2] > times[0]          # 450-aa NW with end locations against 200-aa SW scores: first in, first out
+        assert pdb.wait() == (0, 0.0)       # nothing outstanding: waits for the stream
+        for out, w in zip(outs, want):
+            np.testing.assert_array_equal(out.cpu().numpy(), w)
+    # a longer query than any before: the header buffers grow behind queued searches
+    big = synth.query(1500, seed=9)
+    a = torch.zeros(n, dtype=torch.int32, device="cuda"); b = torch.zeros(n, dtype=torch.int32, device="cuda"); c = torch.zeros(n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    assert pdb.search_device_async(jobs[0][0], 11, 1, m, 0, 3, a.data_ptr()) == 0
+    assert pdb.search_device_async(big, 11, 1, m, 0, 3, b.data_ptr()) == 0
+    assert pdb.wait()[0] == 0 and pdb.wait()[0] == 0
+    assert pdb.search_device(big, 11, 1, m, 0, 3, c.data_ptr())[0] == 0
+    np.testing.assert_array_equal(a.cpu().numpy(), want[0][:n])
+    np.testing.assert_array_equal(b.cpu().numpy(), c.cpu().numpy())
