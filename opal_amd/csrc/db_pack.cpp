@@ -152,6 +152,7 @@ bool device_ok() {
 }
 
 void db_release(OpalxDb* db) {
+    db->quiesce();  // (searches queued by opalx_search_device_async and never waited for: nothing may still read these buffers)
     db->res.release(); db->dSeqOff.release(); db->dPairLen.release(); db->dPairSeq.release();
     db->pairLen.release(); db->pairSeq.release(); db->seqOff.release();
     db->tokens.release(); db->pairOff.release(); db->hPairOff.release();
