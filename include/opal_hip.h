@@ -137,6 +137,18 @@ int opal_hip_launch_stream(const OpalHipLaunch* args, int* next_counter);
 
 #define OPAL_HIP_MAX_ROWS 40
 
+/* Role-swapped SW score search (swap_kernel.hpp) for the few longest targets of a search with a short query: the TARGET
+   on the rows of a wave (row chunks of 64 lanes x rows_per_lane residues, top to bottom), the query on the columns; one
+   workgroup per item of [first_item, +num_items). Read from `args`: query / matrix / gaps, the packed database, first_item,
+   num_items, rows_per_lane (from opal_hip_swap_rows), out_score, the overflow list, sat_limit / neg_pad, stream,
+   clock_probe. opal_hip_swap_rows: the default rows per lane (8 / 16 / 24 / 40 exist) for this query length and
+   alphabet -- the largest shape within 64 KiB of LDS, so that the launch shares its CUs (0: none -- query beyond
+   OPAL_HIP_SWAP_MAX_QUERY or alphabet too large). */
+#define OPAL_HIP_SWAP_MAX_QUERY 1024
+int opal_hip_swap_rows(int query_length, int alphabet_length);
+size_t opal_hip_swap_lds_bytes(int rows_per_lane, int query_length, int alphabet_length);  /* (> 160 KiB: not launchable) */
+int opal_hip_launch_swap(const OpalHipLaunch* args);
+
 int opal_hip_device_count(void);
 /* Select `device` for the calling thread. 0 on success. */
 int opal_hip_set_device(int device);
@@ -262,11 +274,11 @@ OpalxDb* opalx_db_create_flat_device(const unsigned char* d_residues, const int6
 void opalx_release_cached(void);
 /* Number of searches of this process that ran on the streaming SW kernel (diagnostics and tests). */
 long long opalx_stream_launch_count(void);
-/* What the searches of this process ran on, cumulative (diagnostics and tests). Fills out[0 .. min(capacity, 9)):
+/* What the searches of this process ran on, cumulative (diagnostics and tests). Fills out[0 .. min(capacity, 10)):
    [0] searches on the streaming SW kernels, [1] on the streaming NW/HW/OV kernels, [2] one-launch class kernels,
    [3] class kernels launched one class at a time, [4] row-chunk launches of queries beyond one wave, [5] launches of the
    32-bit rung, [6] alignments traced on the device, [7] alignments traced or started by the host, [8] opalSearchDatabase
-   calls that found their database already on the device. Returns 9. */
+   calls that found their database already on the device, [9] targets searched on the role-swapped kernel. Returns 10. */
 int opalx_counters(long long* out, int capacity);
 /* Test hook, no device needed: the order the library gives `n` sequences of lengths `lens` (stable, longest first; zero
    lengths left out; an absent last item when their number is odd: seq -1, len 0). Fills seq / len / off (byte offset in

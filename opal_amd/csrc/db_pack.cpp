@@ -168,6 +168,7 @@ void db_release(OpalxDb* db) {
     opal_hip_stream_destroy(db->copyStream); db->copyStream = nullptr;
     opal_hip_stream_destroy(db->copyStream2); db->copyStream2 = nullptr;
     opal_hip_stream_destroy(db->auxStream); db->auxStream = nullptr;
+    opal_hip_stream_destroy(db->swapStream); db->swapStream = nullptr;
     for (void*& ev : db->events) { opal_hip_event_destroy(ev); ev = nullptr; }
     for (void*& ev : db->asyncEv) { opal_hip_event_destroy(ev); ev = nullptr; }
     for (int i = 0; i < OPALX_ASYNC_DEPTH; i++) { opal_hip_event_destroy(db->hdrEv[i]); db->hdrEv[i] = nullptr; db->hdrEvSet[i] = false; }
@@ -184,6 +185,7 @@ bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::funct
     db->gate.reuse = false;
     db->gate.zeroCopy = false;
     db->gate.kernelFilled = false;
+    db->gate.kernelFilledFrom = INT_MAX;
     db->tokensValid = false;
     const double tf0 = now_ms();
     // The SAME database as last time? (A caller that sends many queries against one database through the plain
@@ -391,7 +393,11 @@ bool db_fill_finish(OpalxDb* db) {
             if (db->gate.state[(size_t)c].load(std::memory_order_acquire) < 0) ok = false;
         // (a zero-copy fill leaves a complete device copy only if its kernels wrote every item, or every chunk was copied on demand)
         bool deviceComplete = !db->gate.zeroCopy || db->gate.kernelFilled;
-        if (!deviceComplete) { deviceComplete = true; for (int c = 0; c < db->gate.chunks(); c++) deviceComplete &= db->gate.copied[(size_t)c].load() != 0; }
+        if (!deviceComplete) {  // (a chunk the kernels wrote only from some item on must have been copied as well)
+            deviceComplete = true;
+            for (int c = 0; c < db->gate.chunks(); c++)
+                deviceComplete &= db->gate.copied[(size_t)c].load() != 0 || db->gate.cutItem[(size_t)c] >= db->gate.kernelFilledFrom;
+        }
         db->lastValid = ok && db->cached && deviceComplete;
         db->speculate = !(db->gate.reuse && db->gate.uploaded.load() > 0);  // (the database was edited under the same lengths: the next call waits for its comparison)
         if (debug_on()) fprintf(stderr, "[opal] fill: %d of %d chunks uploaded%s\n", db->gate.uploaded.load(), db->gate.chunks(), db->gate.reuse ? " (the others unchanged since the last call)" : "");

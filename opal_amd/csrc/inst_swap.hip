@@ -1,0 +1,21 @@
+// Role-swapped SW score kernels (swap_kernel.hpp): the target on the rows, 64 lanes x 8 / 16 / 24 / 40 residues per row chunk.
+#include "swap_kernel.hpp"
+
+SwapFn opal_swap_kernel(int rows) {
+    switch (rows) {
+    case 8: return opal_swap_sw<8>;
+    case 16: return opal_swap_sw<16>;
+    case 24: return opal_swap_sw<24>;
+    case 40: return opal_swap_sw<40>;
+    }
+    return nullptr;
+}
+size_t opal_swap_lds(int rows, int Q, int A) {
+    switch (rows) {
+    case 8: return opal_swap_lds_bytes<8>(Q, A);
+    case 16: return opal_swap_lds_bytes<16>(Q, A);
+    case 24: return opal_swap_lds_bytes<24>(Q, A);
+    case 40: return opal_swap_lds_bytes<40>(Q, A);
+    }
+    return (size_t)1 << 30;
+}

@@ -195,6 +195,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
         // -- on the kernels instantiated with that store: SW score searches that run as one grid, inst_uber_swzc.hip)
         zc.zeroCopy = g.zeroCopy && oneGrid && width == 17 && c.mode == OPAL_MODE_SW && !swEndPass && opal_hip_uber_supported(OPAL_MODE_SW, 16, 0, bulk.rows);
         if (zc.zeroCopy && firstItem == 0 && numItems == 2 * db->numPairs) db->gate.kernelFilled = true;  // ... and write the device copy)
+        else if (zc.zeroCopy && firstItem + numItems == 2 * db->numPairs) db->gate.kernelFilledFrom = firstItem;  // (the items before: the swapped launch asked for their chunks' copies)
         // chunks per slice, the rest in the last one (C2: 17 chunks of 2 MB). The FIRST slice holds the long classes: its
         // longest sequence is the critical path of the whole search, so it is as small as it can be (it starts as soon as
         // one chunk has landed) and runs on a high-priority side stream of its own; the others take `main` and `aux` in
@@ -566,7 +567,29 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                 count(CNT_STREAM_SW);
             }
             else if (narrow == 16) rc = launch_range(c, 16, wantEnd, 0, nullptr, 0, nNarrow, pairLenOf, db->ovfCount.p);
-            else rc = launch_range(c, narrow, wantEnd, 0, nullptr, 0, nNarrow, seqLenOf, db->ovfCount.p);
+            else {
+                // A short query against a database with a real length tail: the few targets that would outlast the search on
+                // the class kernels run with the roles swapped (swap_kernel.hpp) on a high-priority stream of their own,
+                // submitted first; everything else as usual beside them.
+                int swapRows = 0;
+                const int swapN = (narrow == 17 && !wantEnd && !chunkedQuery) ? plan_swap(Q, A, seqLenOf, 0, nNarrow, db->residues, &swapRows) : 0;
+                void* joinSwap = nullptr;
+                if (swapN > 0) {
+                    void* fork = db->event(11);
+                    void* side = db->swap();
+                    OpalHipLaunch a;
+                    fill_launch(a, c, 18, 0, 0, nullptr, db->ovfCount.p);
+                    a.rows_per_lane = swapRows; a.first_item = 0; a.num_items = swapN; a.stream = side;
+                    if (!fork || !side || opal_hip_event_record(fork, st) || opal_hip_stream_wait_event(side, fork) || !gate_items(db, side, 0, swapN) ||
+                        opal_hip_launch_swap(&a) || !(joinSwap = db->event(12)) || opal_hip_event_record(joinSwap, side)) {
+                        db->quiesce();
+                        return OPAL_ERR_NO_SIMD_SUPPORT;
+                    }
+                    count(CNT_SWAPPED, swapN);
+                }
+                rc = launch_range(c, narrow, wantEnd, 0, nullptr, swapN, nNarrow - swapN, seqLenOf, db->ovfCount.p);
+                if (!rc && joinSwap && opal_hip_stream_wait_event(st, joinSwap)) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
+            }
             if (rc) return rc;
             int cnt = 0;
             // The re-run list can only be non-empty if some score can reach the rung's limit at all: with

@@ -71,6 +71,8 @@ static int run_shard(int device, const unsigned char* query, int Q, unsigned cha
         // the database looked like the previous call's (same lengths) and was searched before its residues had been
         // compared; some differ: they are on the device by now (after the copy streams), the search is done again
         pdb->quiesce();
+        // (width 16: the speculative search may have built its pair tokens from residues the copy streams were still replacing)
+        pdb->tokensValid = false;
         if (debug_on()) fprintf(stderr, "[opal] shard: the database had changed under the same lengths: searching again\n");
         if (opal_hip_memset32(dS, INT_MIN, nn, st) || (wantEnd && opal_hip_memset32(dQ, -1, 2 * nn, st))) return OPAL_ERR_NO_SIMD_SUPPORT;
         rc = search_core(pdb, query, Q, Go, Ge, M, A, searchType, mode, dS, wantEnd ? dQ : nullptr, wantEnd ? dT : nullptr, nullptr,

@@ -50,7 +50,8 @@ enum Counter {
     CNT_WIDTH32,         // launches of the 32-bit rung
     CNT_DEVICE_TRACED,   // alignments traced on the device
     CNT_HOST_TRACED,     // alignments traced (or started) by the host
-    CNT_REUSED_FILLS,    // opalSearchDatabase calls that found their database already on the device (same lengths; changed chunks re-uploaded)
+    CNT_REUSED_FILLS,
+    CNT_SWAPPED,         // targets searched on the role-swapped kernel (the longest ones of a search with a short query)    // opalSearchDatabase calls that found their database already on the device (same lengths; changed chunks re-uploaded)
     CNT_COUNT
 };
 extern std::atomic<long long> g_counters[CNT_COUNT];
@@ -127,6 +128,7 @@ struct UploadGate {
     bool zeroCopy = false;                     // the sliced launches of this fill's search read the pinned staging buffer directly:
                                                // the pool only gathers, a chunk is copied when something asks for its device copy (gate_items)
     bool kernelFilled = false;                 // ... and they covered every item: the kernels have written the whole device copy
+    int kernelFilledFrom = INT_MAX;            // ... or every item from this one on (the items before it: chunks copied on demand)
     std::unique_ptr<std::atomic<int>[]> copied; // chunk c's copy has been enqueued
     bool speculated = false;                   // ... and its search was launched without waiting for the comparison
     size_t stateCap = 0;
@@ -221,8 +223,9 @@ struct OpalxDb {
     void* copyStream = nullptr;
     void* copyStream2 = nullptr;  // odd chunks (the per-copy set-up of one overlaps the transfer of the other)
     void* auxStream = nullptr;
+    void* swapStream = nullptr;   // the role-swapped launch of a search's longest targets (high priority, beside everything else)
     void* streams[3] = {nullptr, nullptr, nullptr};
-    void* events[11] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // 0 fork, 1-3 joins, 4-5 timing, 6 aux join, 7 fill, 8-10 fork / joins of the 32-bit and unskewable prefixes beside row chunks
+    void* events[13] = {};  // 0 fork, 1-3 joins, 4-5 timing, 6 aux join, 7 fill, 8-10 fork / joins of the 32-bit and unskewable prefixes beside row chunks, 11-12 fork / join of the swapped launch
     void* main() {
         if (!mainStream) mainStream = opal_hip_stream_create();
         return mainStream;
@@ -235,6 +238,10 @@ struct OpalxDb {
     void* aux() {
         if (!auxStream) auxStream = opal_hip_stream_create();
         return auxStream;
+    }
+    void* swap() {
+        if (!swapStream) swapStream = opal_hip_stream_create_high();
+        return swapStream;
     }
     void* stream(int i) {
         if (!streams[i]) { const char* e = getenv("OPAL_HIP_SIDE_STREAM_PRIO"); streams[i] = (e && *e == '0') ? opal_hip_stream_create() : opal_hip_stream_create_high(); }
@@ -250,6 +257,7 @@ struct OpalxDb {
         if (copyStream) opal_hip_stream_sync(copyStream);
         if (copyStream2) opal_hip_stream_sync(copyStream2);
         if (auxStream) opal_hip_stream_sync(auxStream);
+        if (swapStream) opal_hip_stream_sync(swapStream);
         if (mainStream) opal_hip_stream_sync(mainStream);
     }
 };
@@ -349,6 +357,7 @@ std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass, int sk
 bool plan_chunks(int width, int mode, int swEndPass, int Q, int A, long long nItems, double meanLen, int maxLen, int* G, int* rows, int* wpb);
 struct StreamPlan { int width = 0, G = 0, rows = 0, passes = 1; };  // passes > 1: the query runs in that many row chunks
 StreamPlan plan_stream(int Q, int A, int mode, int wantEnd, long long residues, int longest, int numSeqs);
+int plan_swap(int Q, int A, LenView lenOf, int first, int count, long long residues, int* rowsOut);  // items for swap_kernel.hpp (0: none)
 
 bool args_fit_int32(int Go, int Ge, const int* M, int A);
 int ensure_query_buffers(OpalxDb* db, const unsigned char* query, int Q, const int* M, int A);

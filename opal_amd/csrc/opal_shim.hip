@@ -13,6 +13,7 @@
 
 #include "dp_kernel.hpp"
 #include "stream_kernel.hpp"
+#include "swap_kernel.hpp"
 #include "opal_hip.h"
 
 static thread_local char g_err[512] = "";
@@ -570,4 +571,42 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
     hipLaunchKernelGGL(fn, dim3(blocks + sp.sideBlocks), dim3(STREAM_WAVES * 64), ldsLaunch, (hipStream_t)a->stream, sp);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("streaming kernel launch", e);
+}
+
+// ------------------------------------------------------------------ role-swapped SW score search (swap_kernel.hpp)
+// Rows per lane: a chunk profile of 64 x rows residues for every query letter. The workgroup shares its CU with the
+// search's other launches (whose workgroups need the LDS it leaves free: with 40 rows -- 133 KB -- every swapped target
+// blocked a whole CU for the bulk launch, 20 % of the chip for most of a Swiss-Prot-shaped search), and its own per-step
+// overhead is small, so the default is the largest shape within 64 KB (16 rows for a protein alphabet: 55 KB).
+extern "C" int opal_hip_swap_rows(int query_length, int alphabet_length) {
+    if (query_length < 1 || query_length > OPAL_HIP_SWAP_MAX_QUERY || alphabet_length < 1) return 0;
+    for (int rows : {40, 24, 16, 8})
+        if (opal_swap_lds(rows, query_length, alphabet_length) <= 64 * 1024) return rows;
+    return opal_swap_lds(8, query_length, alphabet_length) <= 160 * 1024 ? 8 : 0;
+}
+extern "C" size_t opal_hip_swap_lds_bytes(int rows_per_lane, int query_length, int alphabet_length) {
+    return opal_swap_lds(rows_per_lane, query_length, alphabet_length);
+}
+extern "C" int opal_hip_launch_swap(const OpalHipLaunch* a) {
+    SwapFn fn = opal_swap_kernel(a->rows_per_lane);
+    const size_t lds = opal_swap_lds(a->rows_per_lane, a->query_length, a->alphabet_length);
+    if (!fn || a->mode != MODE_SW || a->want_end || a->work || a->query_length < 1 || a->query_length > OPAL_HIP_SWAP_MAX_QUERY || lds > 160 * 1024) {
+        snprintf(g_err, sizeof g_err, "unlaunchable swapped shape: rows=%d Q=%d A=%d", a->rows_per_lane, a->query_length, a->alphabet_length);
+        fprintf(stderr, "[opal-hip] %s\n", g_err);
+        return 2;
+    }
+    if (a->num_items <= 0) return 0;
+    SwapParams p;
+    memset(&p, 0, sizeof p);
+    p.query = a->query; p.matrix = a->score_matrix; p.Q = a->query_length; p.A = a->alphabet_length;
+    p.Go = a->gap_open; p.Ge = a->gap_ext;
+    p.res = a->residues; p.seqOff = a->seq_offset; p.pairLen = a->pair_len; p.pairSeq = a->pair_seq;
+    p.firstItem = a->first_item; p.numItems = a->num_items;
+    p.outScore = a->out_score; p.ovfCount = a->overflow_count; p.ovfItems = a->overflow_items;
+    p.satLimit = a->sat_limit; p.negPad = a->neg_pad;
+    p.clk = a->clock_probe;
+    if (lds > 64 * 1024 && raise_lds_limit((const void*)fn)) return 1;
+    hipLaunchKernelGGL(fn, dim3(a->num_items), dim3(SWAP_WAVES * 64), lds, (hipStream_t)a->stream, p);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("swapped kernel launch", e);
 }

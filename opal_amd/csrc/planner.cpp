@@ -229,6 +229,51 @@ std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass, int sk
     return out;
 }
 
+/*
+ * The role-swapped kernel (swap_kernel.hpp): how many of the longest items of [first, first + count) -- sorted longest first
+ * -- leave the class kernels for it. A search with a short query keeps its length classes inside the one-launch chain (G0,
+ * 2 G0, 4 G0 lanes per sequence); a target that would outlast the whole search even on the widest of them, alone on its
+ * wave, is the critical path of the search (Swiss-Prot shape: 35 213 residues against a 110-aa query, 16 lanes x 7 rows:
+ * 14 M clocks for a search of 7 M). Those targets go to the swapped kernel -- one workgroup each, the target on the rows,
+ * (Q + 63) steps per chunk of 64 x rows residues -- provided it is the faster place for the longest of them and there are
+ * no more of them than CUs (one workgroup fills most of a CU's LDS: the kernel is for a handful of outliers, not a class).
+ */
+int plan_swap(int Q, int A, LenView lenOf, int first, int count, long long residues, int* rowsOut) {
+    *rowsOut = 0;
+    const char* en = getenv("OPAL_HIP_SWAP");  // "0": never; "N" > 0 (test hook): the N longest items whatever the model says
+    if (en && *en == '0') return 0;
+    int rows = opal_hip_swap_rows(Q, A);
+    if (const char* re = getenv("OPAL_HIP_SWAP_ROWS")) {  // test / tuning hook: another instantiated shape
+        const int r = atoi(re);
+        if ((r == 8 || r == 16 || r == 24 || r == 40) && opal_hip_swap_lds_bytes(r, Q, A) <= 160 * 1024) rows = r;
+    }
+    if (!rows || count <= 0) return 0;
+    *rowsOut = rows;
+    if (en && atoi(en) > 0) return std::min(atoi(en), count);
+    int G0 = 1;
+    while (G0 < 64 && (Q + G0 - 1) / G0 > OPAL_HIP_MAX_ROWS) G0 *= 2;
+    const int S0 = (Q + G0 - 1) / G0;
+    const int Gw = std::min(64, 4 * G0);
+    const int Sw = (Q + Gw - 1) / Gw;
+    const double totalClocks = (double)residues / (64 / G0) * step_clocks(17, S0) / 1024.0;
+    const char* budEnv = getenv("OPAL_HIP_TAIL_FRACTION");
+    const double budget = std::max(totalClocks * (budEnv && *budEnv ? atof(budEnv) : 0.7), 20000.0);
+    auto classClocks = [&](int len) { return (len + Gw - 1) * lone_step_clocks(17, Sw); };
+    auto swapClocks = [&](int len) { return (double)((len + 64 * rows - 1) / (64 * rows)) * (Q + 63) * lone_step_clocks(18, rows); };
+    const int longest = lenOf(first);
+    // (a clear win only: at 64 lanes on the chain the two are within 10 % of each other -- 390-aa query, 35 213 residues)
+    if (classClocks(longest) <= budget || swapClocks(longest) >= 0.7 * classClocks(longest)) return 0;
+    // the search cannot end before its longest target has, wherever that runs: whatever fits THAT time stays on the chain
+    const double limit = std::max(budget, swapClocks(longest));
+    int n = 0;
+    while (n < count && n <= 240 && classClocks(lenOf(first + n)) > limit) n++;
+    if (n > 240) return 0;
+    if (debug_on())
+        fprintf(stderr, "[opal] swap plan: Q=%d, chain up to %d lanes x %d rows, budget %.0f clocks: the %d longest targets (%d .. %d residues) on the swapped kernel, %d rows per lane (longest: %.0f clocks there, %.0f on the chain)\n",
+                Q, Gw, Sw, budget, n, longest, lenOf(first + n - 1), rows, swapClocks(longest), classClocks(longest));
+    return n;
+}
+
 // Streaming SW score search (stream_kernel.hpp): which geometry, if any. Long queries need 32 or 64 lanes per sequence,
 // where the class kernels lose (G-1)/(L+G-1) of their steps to pipeline fill and drain; the streaming kernel has no
 // such loss, so it is chosen by the cost of a column step per useful query row alone.

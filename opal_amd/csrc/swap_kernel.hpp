@@ -1,0 +1,206 @@
+// swap_kernel.hpp -- gfx950: local alignment (SW) with the ROLES SWAPPED, for the few longest targets of a search with a
+// short query.
+//
+// Role: the same cells as dp_kernel.hpp's SW kernels (reference src/opal.cpp:164-470 searchDatabaseSW_; recurrence
+// :280-327), for the pairs those kernels are worst at. A class kernel puts the QUERY on the rows of a wave (lanes x rows
+// per lane) and walks the target column by column: a 35 213-residue target against a 110-aa query is 35 276 dependent
+// steps of one lone wave holding 2 rows per lane -- 4.8 ms for a search whose DP work is 3 ms on the whole chip
+// (Swiss-Prot-shaped databases, the reference's published queries O74807 / P19930: aligner_comparison.md:27-34).
+// Local alignment is symmetric under transposition (gap penalties are the same for both sequences; S(a, b) keeps a = query
+// letter, b = target letter), so here
+//   * the TARGET is the rows: one wave holds 64 lanes x S consecutive target residues (a "row chunk" of 64*S residues),
+//     H[r][c-1] and E[r][c] of its rows in VGPRs as in dp_kernel.hpp, and works through the target's row chunks from
+//     the top; a chunk's bottom row (H and the F input of the row below, one word per QUERY column) stays in LDS for
+//     the chunk below -- it is Q words;
+//   * the QUERY is the columns: Q + 63 steps per row chunk, i.e. ceil(L / (64 S)) * (Q + 63) steps of S rows each instead of
+//     L + 63 steps of ceil(Q / 64) rows: 14 x 173 long steps instead of 35 276 short ones, and a step's fixed cost
+//     (lane hand-off, address, LDS round trip) is paid 15x less often;
+//   * the profile is the TARGET's: TP[query letter a][lane k][row j] = scoreMatrix[a][target[t0 + k S + j]] (2-byte
+//     entries, the layout and the aligned ds_read_b128 of Vec<18>), staged per row chunk by the whole workgroup (4 waves);
+//     the DP itself runs on wave 0 (the other waves wait at the barrier and cost nothing);
+//   * the column's query letter reaches lane k at step c + k as an LDS address read from a per-search table (qoff), one
+//     step ahead, instead of through a lane queue.
+// One workgroup per target (the profile of a 2560-row chunk fills most of a CU's LDS); the host sends only the handful of
+// targets here whose lone-wave time on the class kernels would exceed the search (planner.cpp: swap_prefix).
+// Scores only (end cells: the class kernels); scores at the 16-bit limit go to the 32-bit re-run list like everywhere else.
+#pragma once
+#include "dp_kernel.hpp"
+
+struct SwapParams {
+    const unsigned char* query;
+    const int* matrix;
+    int Q, A, Go, Ge;
+    const unsigned char* res;
+    const uint64_t* seqOff;
+    const int* pairLen;
+    const int* pairSeq;
+    int firstItem, numItems;  // items [firstItem, +numItems): one workgroup each
+    int* outScore;
+    int* ovfCount;
+    int* ovfItems;
+    int satLimit, negPad;
+    unsigned long long* clk;  // clock probe (dp_kernel.hpp)
+};
+typedef void (*SwapFn)(const SwapParams);
+
+#define SWAP_WAVES 4          // waves per workgroup: all stage the chunk profile, wave 0 runs the DP
+#define SWAP_MAX_QUERY 1024   // longest query the host sends here (LDS tables: 8 bytes per query column)
+
+// LDS: the target profile of one row chunk, the column address table (Q + 128 words: 63 pad columns in front, 65 behind),
+// the chunk boundary row (Q + 66 words), the score matrix as 16-bit entries, the probe slot.
+template <int S>
+__host__ __device__ inline int opal_swap_stride() { return opal_profile_stride(2, 64, S, 1); }
+template <int S>
+__host__ __device__ inline size_t opal_swap_lds_bytes(int Q, int A) {
+    return (size_t)(A + 1) * (size_t)opal_swap_stride<S>() + 4 * (size_t)(Q + 128) + 4 * (size_t)(Q + 66) + (((size_t)A * A * 2 + 15) & ~(size_t)15) + 48;
+}
+
+template <int S>
+__global__ void __launch_bounds__(SWAP_WAVES * 64, 1) opal_swap_sw(const SwapParams p) {
+    using V = Vec<18>;
+    using reg = typename V::reg;
+    constexpr int ES = 2, RB = 8;
+    constexpr int SPAD = (S + RB - 1) / RB * RB;
+    constexpr int LANE_BYTES = opal_lane_bytes(ES, S, 1);
+    constexpr int NBLK = SPAD / RB;
+    static_assert(S % 2 == 0, "rows per lane: even (the staging writes row pairs)");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int stride = opal_swap_stride<S>();
+    const int Q = p.Q, A = p.A;
+    unsigned* const qoff = reinterpret_cast<unsigned*>(lds + (size_t)(A + 1) * stride);
+    unsigned* const bnd = qoff + (Q + 128);
+    unsigned short* const mat16 = reinterpret_cast<unsigned short*>(bnd + (Q + 66));
+    unsigned char* const clkSlot = reinterpret_cast<unsigned char*>(mat16) + (((size_t)A * A * 2 + 15) & ~(size_t)15);
+    clk_begin(p.clk, nullptr, clkSlot);
+
+    const int item = p.firstItem + (int)blockIdx.x;
+    const int seq = p.pairSeq[item];
+    const int L = seq >= 0 ? p.pairLen[item] : 0;
+    const uint64_t tb = p.seqOff[item];
+    const unsigned ldsBase = (unsigned)(uintptr_t)(opal_lds_u8*)lds;
+    const unsigned padOff = ldsBase + (unsigned)(A * stride);
+    const int negPad = p.negPad;
+
+    // ---- once per target: matrix as 16-bit entries, column address table, zero boundary (= the top boundary of local
+    // alignment for the first chunk), the pad letter's profile row (pad COLUMNS: before column 0 and behind column Q-1)
+    for (int i = threadIdx.x; i < A * A; i += blockDim.x) mat16[i] = (unsigned short)p.matrix[i];
+    for (int i = threadIdx.x; i < Q + 128; i += blockDim.x) {
+        const int c = i - 63;
+        qoff[i] = (c >= 0 && c < Q) ? ldsBase + (unsigned)p.query[c] * (unsigned)stride : padOff;
+    }
+    for (int i = threadIdx.x; i < Q + 66; i += blockDim.x) bnd[i] = 0u;
+    for (int i = threadIdx.x; i < 64 * SPAD / 2; i += blockDim.x) {
+        const int k = i / (SPAD / 2), j2 = i - k * (SPAD / 2);
+        const unsigned v = (unsigned)negPad & 0xffffu;
+        *reinterpret_cast<unsigned*>(lds + (size_t)A * stride + k * LANE_BYTES + j2 * 4) = v | (v << 16);
+    }
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int k = lane;
+    const unsigned Qs = (unsigned)p.Go & 0xffffu, Rs = (unsigned)p.Ge & 0xffffu;
+    reg mx = 0;
+    const int chunkRows = 64 * S;
+    const int nchunks = (L + chunkRows - 1) / chunkRows;
+    const unsigned qoffLane = (unsigned)(uintptr_t)(opal_lds_u8*)reinterpret_cast<unsigned char*>(qoff) + 4u * (unsigned)(63 - k);
+    const unsigned bndBase = (unsigned)(uintptr_t)(opal_lds_u8*)reinterpret_cast<unsigned char*>(bnd);
+    typedef __attribute__((address_space(3))) unsigned lds_u32;
+
+    for (int ch = 0; ch < nchunks; ch++) {
+        const int t0 = ch * chunkRows;
+        const int rowsHere = min(chunkRows, L - t0);
+        __syncthreads();  // the previous chunk's DP is over (and, first time round, the tables above are written)
+        // ---- stage TP for rows [t0, t0 + 64 S): a thread owns a pair of rows (one 32-bit store per letter)
+        for (int i = threadIdx.x; i < 64 * S / 2; i += blockDim.x) {
+            const int kk = i / (S / 2), j2 = i - kk * (S / 2);
+            const int t = t0 + kk * S + 2 * j2;
+            const int b0 = t < L ? (int)p.res[tb + (uint64_t)t] : -1;
+            const int b1 = t + 1 < L ? (int)p.res[tb + (uint64_t)t + 1] : -1;
+            unsigned char* dst = lds + kk * LANE_BYTES + j2 * 4;
+            const unsigned np = (unsigned)negPad & 0xffffu;
+            for (int a = 0; a < A; a++) {
+                const unsigned v0 = b0 >= 0 ? (unsigned)mat16[a * A + b0] : np;
+                const unsigned v1 = b1 >= 0 ? (unsigned)mat16[a * A + b1] : np;
+                *reinterpret_cast<unsigned*>(dst + (size_t)a * stride) = v0 | (v1 << 16);
+            }
+        }
+        __syncthreads();
+        if (wave != 0) continue;
+        __builtin_amdgcn_s_setprio(3);  // this wave is the critical path of the search: ahead of whatever shares its SIMD
+
+        // ---- the DP of this row chunk on wave 0: Q + usedLanes - 1 steps, lane k on column s - k
+        const int usedLanes = (rowsHere + S - 1) / S;
+        const int nsteps = Q + usedLanes - 1;
+        const bool hasNext = ch + 1 < nchunks;
+        reg Hp[S], En[S];
+#pragma unroll
+        for (int j = 0; j < S; j++) { Hp[j] = 0; En[j] = 0; }
+        reg outH = 0, outF = 0, diagIn = 0;
+        // addresses and boundary words are read one step ahead; the first row block of a step's profile column too
+        unsigned offCur = *(lds_u32*)(uintptr_t)(qoffLane) + (unsigned)(k * LANE_BYTES);
+        unsigned offNxt = *(lds_u32*)(uintptr_t)(qoffLane + 4u) + (unsigned)(k * LANE_BYTES);
+        unsigned bndCur = *(lds_u32*)(uintptr_t)(bndBase);
+        int4 pfirst = lds_ld16(offCur);
+        for (int s = 0; s < nsteps; s++) {
+            const unsigned offc = offCur;
+            const int4 pcur = pfirst;
+            const unsigned off2 = *(lds_u32*)(uintptr_t)(qoffLane + 4u * (unsigned)(s + 2)) + (unsigned)(k * LANE_BYTES);
+            const unsigned bndNxt = *(lds_u32*)(uintptr_t)(bndBase + 4u * (unsigned)(s + 1));
+            pfirst = lds_ld16(offNxt);
+
+            reg inH = (reg)shr1((unsigned)outH);
+            reg inF = (reg)shr1((unsigned)outF);
+            inH = (k == 0) ? (reg)(bndCur & 0xffffu) : inH;
+            inF = (k == 0) ? (reg)(bndCur >> 16) : inF;
+            reg f = inF;
+            int4 pc = pcur;
+            reg d = V::adds(diagIn, (reg)pc.x), t = 0;
+            static_for<NBLK>([&](auto rbc) {
+                constexpr int rb = decltype(rbc)::value;
+                int4 pn = pc;
+                if constexpr (rb + 1 < NBLK) pn = lds_ld16(offc + (rb + 1) * RB * ES);
+                reg Pv[RB + 1];
+                Pv[0] = (reg)pc.x; Pv[1] = (reg)pc.x >> 16; Pv[2] = (reg)pc.y; Pv[3] = (reg)pc.y >> 16;
+                Pv[4] = (reg)pc.z; Pv[5] = (reg)pc.z >> 16; Pv[6] = (reg)pc.w; Pv[7] = (reg)pc.w >> 16;
+                Pv[RB] = (reg)pn.x;
+                static_for<RB / 4>([&](auto subc) {
+                    constexpr int j0 = rb * RB + decltype(subc)::value * 4;
+                    if constexpr (j0 < S) {
+                        constexpr int n = (S - j0) < 4 ? (S - j0) : 4;
+                        constexpr bool last = j0 + n == S;
+                        const reg* Pn = &Pv[j0 - rb * RB + 1];
+                        V::template rows<ROWS_SW, n, last>(&Hp[j0], &En[j0], Pn, f, mx, d, t, Qs, Rs);
+                    }
+                });
+                pc = pn;
+            });
+            outH = Hp[S - 1];
+            outF = f;
+            // the bottom row of a full chunk: lane 63 finishes column s - 63
+            if (hasNext && k == 63 && s >= 63) {
+                const unsigned w = ((unsigned)outH & 0xffffu) | ((unsigned)outF << 16);
+                *(lds_u32*)(uintptr_t)(bndBase + 4u * (unsigned)(s - 63)) = w;
+            }
+            diagIn = inH;
+            offCur = offNxt; offNxt = off2; bndCur = bndNxt;
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+
+    // ---- result: the maximum over the lanes of wave 0 (every chunk accumulated into mx)
+    if (wave == 0) {
+        const int sc = wave_max_i32(V::half(mx, 0));
+        if (lane == 0 && seq >= 0) {
+            if (sc >= p.satLimit) {  // (opal.cpp:364-370): hand over to width 32
+                const int at = atomicAdd(p.ovfCount, 1);
+                p.ovfItems[at] = item;
+            } else {
+                p.outScore[seq] = sc;
+            }
+        }
+    }
+    clk_end(clkSlot);
+}
+
+SwapFn opal_swap_kernel(int rows);         // inst_swap.hip: rows per lane 8 / 16 / 24 / 40 (nullptr: not instantiated)
+size_t opal_swap_lds(int rows, int Q, int A);  // LDS bytes of that shape

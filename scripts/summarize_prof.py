@@ -27,7 +27,7 @@ for sub in ("sq1", "sq2", "grbm", "fetch", "write"):
     for f in glob.glob(f"{d}/{sub}/*/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "opal_dp" not in k and "opal_rev" not in k and "opal_sw_stream" not in k and "opal_gl_stream" not in k:
+            if "opal_dp" not in k and "opal_rev" not in k and "opal_sw_stream" not in k and "opal_gl_stream" not in k and "opal_swap" not in k:
                 continue
             counters[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta[k] = {"vgpr": r.get("VGPR_Count") or r.get("Arch_VGPR_Count"), "lds": r.get("LDS_Block_Size"), "wg": r.get("Workgroup_Size"),

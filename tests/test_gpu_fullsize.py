@@ -417,6 +417,40 @@ def test_same_database_again_uploads_only_what_changed(oracle):
     assert reused() == r0 + 4
 
 
+@pytest.mark.parametrize("narrow", [None, "16", "18"])
+def test_same_lengths_mutated_residues_long_query(narrow, oracle, monkeypatch):
+    """The repeat-search path of a re-seen database at the widths a 2000-aa query runs on: the speculative search of a
+    database recognised by its lengths builds the width-16 pair tokens from whatever the device holds; when the comparison
+    finds changed chunks the search is repeated -- on tokens rebuilt from the new residues (they used to stay marked valid:
+    stale scores). Score-only and score + end, SW and NW, by default (packed pairs for SW score / NW, width 18 for SW + end)
+    and with the narrow rung forced."""
+    import opal_amd
+    from opal_amd import synth
+    from opal_amd.score_matrix import blosum50
+    if narrow:
+        monkeypatch.setenv("OPAL_HIP_NARROW", narrow)
+    monkeypatch.setenv("OPAL_HIP_STREAM", "0")  # (the class kernels: the streaming ones never read pair tokens)
+    m = blosum50()[1]
+    n = 6000
+    res, offs, lens = synth.database(n, seed=42, first=400000)
+    db = [res[offs[i]:offs[i + 1]].copy() for i in range(n)]
+    q = synth.query(2000, seed=11)
+    pick = np.arange(0, n, 150)
+    for rnd in range(3):
+        for mode, st in (("SW", 0), ("SW", 1), ("NW", 1)):
+            rc, results = opal_amd.search_database(q, db, 11, 1, m, st, opal_amd.MODES[mode])
+            assert rc == 0
+            got = opal_amd.result_fields(results, "score", "endLocationQuery", "endLocationTarget")
+            orc, so, oq, ot = oracle.search(q, [db[i] for i in pick], 11, 1, m, st, opal_amd.MODES[mode])
+            np.testing.assert_array_equal(got[0][pick], so, err_msg=f"round {rnd} {mode} st={st} narrow={narrow}")
+            if st:
+                np.testing.assert_array_equal(got[1][pick], oq)
+                np.testing.assert_array_equal(got[2][pick], ot)
+            # every sequence changes under the same lengths before the next search (which will speculate, then repeat)
+            for i in range(n):
+                db[i][:] = synth._residues(5000 + 17 * rnd + i, 0, len(db[i]))
+
+
 def test_same_lengths_different_residues_across_threads_and_alignment(oracle):
     """The nasty corner of the database recognition: databases with IDENTICAL lengths and DIFFERENT residues, searched from
     three host threads that keep exchanging cached contexts -- every call finds "the same database" by its lengths,

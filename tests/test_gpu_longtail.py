@@ -23,13 +23,13 @@ pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(os.path.dirname(HERE), "opal_amd", "csrc", "libopal.so")
-NAMES = ["stream_sw", "stream_global", "one_launch", "class_launches", "chunk_launches", "width32", "device_traced", "host_traced"]
+NAMES = ["stream_sw", "stream_global", "one_launch", "class_launches", "chunk_launches", "width32", "device_traced", "host_traced", "reused_fills", "swapped"]
 
 
 def counters():
     from opal_amd import _lib
-    buf = (C.c_longlong * 8)()
-    _lib.lib().opalx_counters(buf, 8)
+    buf = (C.c_longlong * 10)()
+    _lib.lib().opalx_counters(buf, 10)
     return dict(zip(NAMES, [int(v) for v in buf]))
 
 

@@ -1,0 +1,119 @@
+"""The role-swapped SW kernel (opal_amd/csrc/swap_kernel.hpp) against the oracle: the longest targets of a search with a
+short query run with the TARGET on the rows of a wave (row chunks of 64 lanes x 8 / 16 / 24 / 40 residues) and the query on the
+columns. Local-alignment scores are symmetric under that transposition (reference recurrence src/opal.cpp:280-327; S(a, b)
+keeps a = query letter), so every score must equal the oracle's -- for targets that are an exact number of row chunks, one
+residue more or less, a single partial chunk, with near copies of the query straddling chunk boundaries, and with scores
+beyond the 16-bit rung (re-run list)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from oracle_lib import MODES
+
+pytestmark = pytest.mark.gpu
+
+LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "opal_amd", "csrc", "libopal.so")
+
+
+@pytest.fixture(scope="module")
+def ours():
+    return oracle_lib.OpalABI(LIB)
+
+
+def _swapped(ours):
+    buf = (C.c_longlong * 10)()
+    ours.lib.opalx_counters(buf, 10)
+    return int(buf[9])
+
+
+def _database(q, rows, seed):
+    """300 ordinary sequences and 14 long ones whose lengths sit on and around the row-chunk size 64 x rows; some carry
+    mutated copies of the query across a chunk boundary (the alignment then crosses from one chunk's lanes into the next
+    chunk through the boundary row in LDS)."""
+    from opal_amd import synth
+    rng = np.random.RandomState(seed)
+    res, offs, lens = synth.database(300, seed=seed)
+    db = [res[offs[i]:offs[i + 1]] for i in range(300)]
+    chunk = 64 * rows
+    longs = [chunk, chunk - 1, chunk + 1, 2 * chunk, 2 * chunk + 7, 3 * chunk - 5, chunk // 2, chunk + rows, chunk + rows + 1,
+             5 * chunk + 123, 7000, 9001, 3 * chunk, 4 * chunk + 1]
+    for n, L in enumerate(longs):
+        t = synth.query(L, seed=1000 + seed + n).copy()
+        if n % 2 == 0 and len(q) >= 8:
+            # a mutated copy of the query across the first chunk boundary (or in the middle of a short target)
+            cp = q.copy()
+            hit = rng.rand(len(cp)) < 0.15
+            cp[hit] = rng.randint(0, 20, hit.sum())
+            at = min(max(0, (chunk if L > chunk else L // 2) - len(cp) // 2), L - len(cp)) if L >= len(cp) else 0
+            t[at:at + min(len(cp), L - at)] = cp[: min(len(cp), L - at)]
+        if n % 3 == 0 and L > 2 * len(q):
+            t[L - len(q):] = q  # ... and an exact copy at the very end (the last rows of the last chunk)
+        db.append(t)
+    order = rng.permutation(len(db))
+    return [db[i] for i in order]
+
+
+@pytest.mark.parametrize("rows", ["40", "24", "16", "8"])
+@pytest.mark.parametrize("qlen", [1, 7, 64, 110, 195, 320, 700])
+def test_swapped_kernel_vs_oracle(qlen, rows, ours, oracle, monkeypatch):
+    from opal_amd import synth
+    from opal_amd.score_matrix import blosum50
+    q = synth.query(qlen, seed=qlen)
+    db = _database(q, int(rows), seed=qlen + int(rows))
+    m = blosum50()[1]
+    monkeypatch.setenv("OPAL_HIP_SWAP", "20")  # the 20 longest: the 14 long ones and a few ordinary ones (single partial chunk)
+    monkeypatch.setenv("OPAL_HIP_SWAP_ROWS", rows)
+    for go, ge in ((11, 1), (3, 1), (0, 0), (5, 5)):
+        before = _swapped(ours)
+        got = ours.search(q, db, go, ge, m, 0, MODES["SW"])[:4]
+        assert _swapped(ours) - before == 20, "the swapped kernel did not run"
+        want = oracle.search(q, db, go, ge, m, 0, MODES["SW"])
+        assert got[0] == want[0] == 0
+        np.testing.assert_array_equal(got[1], want[1], err_msg=f"swapped q{qlen} rows={rows} gaps {go}/{ge}")
+        assert (got[2] == -1).all() and (got[3] == -1).all()
+
+
+def test_swapped_kernel_saturated_scores_rerun(ours, oracle, monkeypatch):
+    """Scores at the 16-bit limit leave the swapped kernel through the re-run list and come back from the 32-bit rung."""
+    from opal_amd import synth
+    from opal_amd.score_matrix import blosum50
+    q = synth.query(200, seed=3)
+    db = _database(q, 40, seed=77)
+    m = blosum50()[1] * 60
+    monkeypatch.setenv("OPAL_HIP_SWAP", "20")
+    got = ours.search(q, db, 660, 60, m, 0, MODES["SW"])[:4]
+    want = oracle.search(q, db, 660, 60, m, 0, MODES["SW"])
+    assert got[0] == want[0] == 0 and (want[1] > 32767).sum() >= 3
+    np.testing.assert_array_equal(got[1], want[1])
+
+
+def test_swapped_kernel_is_what_a_long_tail_runs_on(ours, oracle, monkeypatch):
+    """Without forcing: a short query against a database with a few very long targets sends exactly those to the swapped
+    kernel (planner.cpp plan_swap); with end locations, a longer query or no tail it stays away."""
+    from opal_amd import synth
+    from opal_amd.score_matrix import blosum50
+    res, offs, lens = synth.database(20000, seed=42)
+    db = [res[offs[i]:offs[i + 1]] for i in range(20000)]
+    tail = [synth.query(L, seed=L) for L in (35213, 30000, 22000, 12000)]
+    m = blosum50()[1]
+    q = synth.query(110, seed=7)
+    monkeypatch.delenv("OPAL_HIP_SWAP", raising=False)
+    short = [s[:1000] for s in db]  # (no tail at all: nothing outlasts the search on the chain by enough to move)
+    for st, seqs, expect in ((0, db + tail, True), (1, db + tail, False), (0, short, False)):
+        before = _swapped(ours)
+        got = ours.search(q, seqs, 3, 1, m, st, MODES["SW"])[:4]
+        n = _swapped(ours) - before
+        assert (n >= 3) == expect, (st, len(seqs), n)
+        idx = list(range(len(seqs) - 4, len(seqs))) + list(range(0, len(seqs) - 4, 397))
+        want = oracle.search(q, [seqs[i] for i in idx], 3, 1, m, st, MODES["SW"])
+        assert got[0] == 0
+        np.testing.assert_array_equal(got[1][idx], want[1])
+        if st:
+            np.testing.assert_array_equal(got[2][idx], want[2])
+            np.testing.assert_array_equal(got[3][idx], want[3])
+    before = _swapped(ours)
+    assert ours.search(synth.query(600, seed=7), db + tail, 3, 1, m, 0, MODES["SW"])[0] == 0
+    assert _swapped(ours) == before, "a 600-aa query reaches 64 lanes on the class kernels"
