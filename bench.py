@@ -386,7 +386,7 @@ def main():
     # {score, endQ, endT} blocks, padded to the largest shard. Two result buffers used in turn (N > 1): the search runs on
     # the library's own stream, the gather on torch's, so step i+1 must not overwrite what step i's gather is still
     # reading; a buffer is reused two steps later, after waiting on the event recorded behind its last reader.
-    outs = [torch.zeros(nres * npad, dtype=torch.int32, device=dev) for _ in range(2 if multi else 1)]
+    outs = [torch.zeros(nres * npad, dtype=torch.int32, device=dev) for _ in range(2 if (multi or args.in_flight > 1) else 1)]
     done = [None, None]
     done_ev = [torch.cuda.Event(), torch.cuda.Event()] if multi else None  # (reused: no event creation per step)
     # position of every database sequence in the gathered [rank][value][npad] block: ONE index operation per step
@@ -398,12 +398,21 @@ def main():
     pending = [None]  # (N > 1) the result buffer whose exchange is still to be issued
     inflight = [0]    # (N = 1) searches enqueued and not yet waited for
 
+    xev = []      # (N > 1) timed event pairs around every exchange of the timed region (torch's stream), made before it starts
+    xused = [0]
+
     def exchange(b):
         # the path's only exchange: ONE gather of the per-sequence result block to rank 0, which puts the
         # blocks back into database order with the deal's permutation (one index_select for all result vectors)
+        pair = xev[xused[0]] if xused[0] < len(xev) else None
+        if pair:
+            pair[0].record()
         plan.gather(outs[b] if backend == "nccl" else outs[b].cpu(), rank)
         done[b] = done_ev[b]
         done[b].record()
+        if pair:
+            pair[1].record()
+            xused[0] += 1
 
     def step():
         b = step_no[0] % len(outs)
@@ -462,6 +471,14 @@ def main():
         step()
     flush()
     kernel_ms.clear()
+    # Every result buffer is POISONED before the timed region (outside it): the warm-up steps have already written the right
+    # answers, so a timed step that did nothing would otherwise still verify. The check below reads what the LAST timed steps
+    # wrote (one buffer per search in flight) and fails on any value the timed region left untouched.
+    POISON = -2147483647
+    for o in outs:
+        o.fill_(POISON)
+    if multi:
+        xev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -480,6 +497,12 @@ def main():
     import oracle_lib
     oracle_lib.build_oracle()
     mine = outs[(step_no[0] - 1) % len(outs)].cpu().numpy().reshape(nres, npad)[:, :n]
+    untouched = bool((mine == POISON).any())  # (a value the timed region never wrote)
+    if len(outs) > 1 and args.steps >= 2:     # ... and the step before the last one wrote the other buffer: the same answers
+        other = outs[(step_no[0] - 2) % len(outs)].cpu().numpy().reshape(nres, npad)[:, :n]
+        untouched = untouched or not bool((other == mine).all())
+    if untouched:
+        sys.stderr.write(f"bench.py: rank {rank}: the timed steps left result values unwritten (or two steps disagree)\n")
     rng = np.random.RandomState(1 + rank)
     nsamp = min(n, (300 if args.qlen <= 600 else 120) // (1 if world == 1 else 2))
     pick = np.sort(rng.choice(n, nsamp, replace=False))
@@ -488,7 +511,7 @@ def main():
     sres, soffs, _ = synth.database_subset(owned[pick], 42, lens=lens[pick], stride=stride)
     sdb = [sres[soffs[i]:soffs[i + 1]] for i in range(len(pick))]
     orc_rc, os_, oq, ot = oracle_lib.Oracle().search(query, sdb, args.gap_open, args.gap_ext, matrix, args.search_type, mode)
-    ok_local = bool(orc_rc == 0 and (mine[0][pick] == os_).all())
+    ok_local = bool(orc_rc == 0 and (mine[0][pick] == os_).all()) and not untouched
     if want_end:
         ok_local = ok_local and bool((mine[1][pick] == oq).all() and (mine[2][pick] == ot).all())
     if not ok_local:
@@ -498,10 +521,24 @@ def main():
         dist.all_reduce(vflag, op=dist.ReduceOp.MIN)
     verified = bool(int(vflag.item()) == 1)
 
+    # what an N > 1 line needs to be READ: every rank's mean kernel time (all-reduced one-hot vector), the share of cells
+    # the deal gave every rank, the time of the exchange on rank 0's stream
+    my_kms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    rank_kms = torch.zeros(world, dtype=torch.float64, device=rdev)
+    rank_kms[rank] = my_kms
+    if multi:
+        dist.all_reduce(rank_kms, op=dist.ReduceOp.SUM)
+    rank_kms = [float(v) for v in rank_kms.cpu().numpy()]
+    rank_cells = [float(args.qlen) * float(all_lens[o].astype(np.int64).sum()) for o in owned_lists]
+    exchange_ms = None
+    if multi and xused[0] > 0:
+        torch.cuda.synchronize()
+        exchange_ms = float(np.mean([a.elapsed_time(b) for a, b in xev[:xused[0]]]))
+
     status = 0
     if rank == 0:
         gcups = total_cells * args.steps / dt / 1e9
-        kms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+        kms = my_kms
         kernel_gcups = cells / (kms * 1e-3) / 1e9
         gall = plan.glob.cpu().numpy() if multi else mine
         gscore = np.ascontiguousarray(gall[0])
@@ -569,6 +606,15 @@ def main():
                                       ("one GPU, results written at their database index; " +
                                        ("two searches queued on the handle: step i enqueued behind step i-1, then step i-1 waited for" if args.in_flight == 2
                                         else "one search at a time: enqueued, waited for"))},
+            "in_flight": 1 if multi else args.in_flight,
+            "ranks": {"kernel_ms": {"min": round(min(rank_kms), 4), "max": round(max(rank_kms), 4), "mean": round(float(np.mean(rank_kms)), 4),
+                                    "per_rank": [round(v, 4) for v in rank_kms]},
+                      "cells_per_step": {"min": min(rank_cells), "max": max(rank_cells)},
+                      "imbalance": round(max(rank_cells) / (sum(rank_cells) / len(rank_cells)), 5),
+                      "exchange_ms": round(exchange_ms, 4) if exchange_ms is not None else None,
+                      "what": "kernel_ms: every rank's mean DP time per step (HIP events on its launch stream); imbalance: largest share of "
+                              "cells / mean share (the deal, opal_amd/shard.py); exchange_ms: the gather + the one index_select of a step on "
+                              "rank 0's stream (timed events), issued while the GPU already runs the next search"},
             "verified": verified,
             "verify": {"sample": f"{len(pick)} sequences of every rank's shard (fixed seeds) vs oracle/opal_oracle.c, verdicts all-reduced"
                                  + ("; the gathered block vs rank 0's own values" if world > 1 else ""),
@@ -600,6 +646,27 @@ def main():
             if not e2e_ok:
                 res_line["verified"] = False
                 status = 3
+        if world > 1 and not args.no_e2e and total <= 1000000:
+            # N > 1: the same call with the library itself sharding the database over the node's GPUs (OPAL_HIP_DEVICES: one
+            # host thread and one cached context per GPU, the host is the gather root -- the results live in host structs).
+            # The other ranks wait on the rendezvous store, on the CPU: their GPUs are free for this process.
+            try:
+                hres, hoffs, _ = synth.database_subset(np.arange(total, dtype=np.int64), 42, lens=all_lens, stride=stride)
+                os.environ["OPAL_HIP_DEVICES"] = ",".join(["0"] * world) if os.environ.get("BENCH_SHARE_GPU") == "1" else "all"
+                e2e_ms, same_ms, e2e_ok = e2e_call(query, hres, hoffs, matrix, args.gap_open, args.gap_ext, args.search_type, mode, gscore, calls=3)
+                res_line["e2e"] = {"ms": round(e2e_ms, 3), "gcups": round(total_cells / (e2e_ms * 1e-3) / 1e9, 1), "scores_match": e2e_ok,
+                                   "same_database_ms": round(same_ms, 3), "same_database_gcups": round(total_cells / (same_ms * 1e-3) / 1e9, 1),
+                                   "what": f"ONE opalSearchDatabase call from this process over {world} GPUs (OPAL_HIP_DEVICES={os.environ['OPAL_HIP_DEVICES']}: "
+                                           "the library deals 64-sequence groups by residue count, one host thread + cached context per GPU, "
+                                           "results merged on the host), whole database, steady clock, best of 3; ms: a database the library has "
+                                           "not seen; same_database_ms: the same database again"}
+                if not e2e_ok:
+                    res_line["verified"] = False
+                    status = 3
+            except Exception as e:  # noqa: BLE001 -- the line must still be printed
+                res_line["e2e"] = {"error": repr(e)[:300]}
+            finally:
+                os.environ.pop("OPAL_HIP_DEVICES", None)
         if world == 1 and not args.no_e2e and args.workload == "c2" and (args.mode, args.search_type) == ("SW", 0):
             # SURVEY.md 8d asks for both gap settings of the workload; the other one is timed here, outside the
             # K timed steps (11/1: nothing exceeds the 8-bit range of the reference; 3/1: the reference's CLI default)
@@ -642,6 +709,12 @@ def main():
                 res_host = d_res.cpu().numpy()
             res_line["cpu_baseline"] = cpu_baseline(query, res_host, offs, matrix, args.gap_open, args.gap_ext, mode)
     if multi:
+        # (rank 0 may still be timing the in-library N-GPU call above: the others wait on the store, not on their GPUs)
+        store = dist.distributed_c10d._get_default_store()
+        if rank == 0:
+            store.set("bench_rank0_done", "1")
+        else:
+            store.wait(["bench_rank0_done"])
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -211,11 +211,12 @@ def test_c5_long_query_buckets(c4shard, oracle):
     assert (s[sorted(planted)] > 32767).all()
 
 
-def test_c4_eight_way_equals_unsharded(monkeypatch):
+def test_c4_eight_way_equals_unsharded(monkeypatch, oracle):
     """BASELINE.json configs[3] whole: P18080 x all 5 000 000 sequences. Once unsharded on the device-resident database
     (opalx_search_device), once through opalSearchDatabase itself with the in-library sharding over eight contexts
     (OPAL_HIP_DEVICES = eight times this box's one GPU: the deal, the per-shard pipelines and the host-side merge are
-    those of an 8-GPU call) -- identical score / end-cell arrays, SW score-only and HW with end locations."""
+    those of an 8-GPU call) -- identical score / end-cell arrays, SW score-only and HW with end locations; and both against
+    the oracle on 400 sequences drawn from ALL eight shards of the deal (50 each, the longest of every shard among them)."""
     import ctypes as C
     import torch
     import zlib
@@ -243,6 +244,22 @@ def test_c4_eight_way_equals_unsharded(monkeypatch):
         assert rc == 0
         want[mode] = out.cpu().numpy().reshape(3, n).copy()
     pdb.close()
+    # the oracle on a sample across the eight shards of the deal the 8-way call below will make (the same deal: shard.deal
+    # mirrors deal_groups, tests/test_host_logic.py)
+    from opal_amd import shard
+    parts = shard.deal(lens, 8)
+    rng = np.random.RandomState(8)
+    pick = np.sort(np.concatenate([np.concatenate([p[np.argsort(lens[p])[-2:]], rng.choice(p, 48, replace=False)]) for p in parts]))
+    assert len(pick) == 400
+    sres, soffs, _ = synth.database_subset(pick, 42, lens=lens[pick])
+    sdb = [sres[soffs[i]:soffs[i + 1]] for i in range(len(pick))]
+    for mode, st in (("SW", 0), ("HW", 1)):
+        orc, so, oq, ot = oracle.search(q, sdb, 3, 1, m, st, oracle_lib.MODES[mode])
+        assert orc == 0
+        np.testing.assert_array_equal(want[mode][0][pick], so, err_msg=f"{mode} vs oracle, sample over all eight shards")
+        if st:
+            np.testing.assert_array_equal(want[mode][1][pick], oq)
+            np.testing.assert_array_equal(want[mode][2][pick], ot)
     res_host = d_res.cpu().numpy()
     del d_res, out
     torch.cuda.empty_cache()
@@ -270,6 +287,78 @@ def test_c4_eight_way_equals_unsharded(monkeypatch):
     L.opalx_release_cached()
 
 
+def test_sprot_shape_full_size(oracle):
+    """The shape the reference was published on (reference aligner_comparison.md:6-34; bench.py --workload sprot): 541 762
+    synthetic sequences with a Swiss-Prot-like tail to 35 213 residues, BLOSUM50, gaps 3/1, the four published queries, the
+    scheduler's own choice of kernels (asserted through opalx_counters: the role-swapped kernel takes the tail of the two
+    short queries, the longer ones stream behind a head on the class body). SW scores for all four; SW / HW / OV / NW with
+    end locations for P19930. The oracle on ALL sequences beyond 5 000 residues and 300 random ones; size-independent
+    properties on everything."""
+    import ctypes as C
+    import torch
+    import cases
+    from opal_amd import _lib, synth
+    from opal_amd.api import PreparedDb
+    from opal_amd.fasta import read_fasta
+    from opal_amd.score_matrix import blosum50
+
+    names = ["stream_sw", "stream_global", "one_launch", "class_launches", "chunk_launches", "width32", "device_traced", "host_traced", "reused_fills", "swapped"]
+
+    def counters():
+        buf = (C.c_longlong * 10)()
+        _lib.lib().opalx_counters(buf, 10)
+        return dict(zip(names, [int(v) for v in buf]))
+    n = synth.SPROT_SEQS
+    dev = torch.device("cuda", 0)
+    lens = synth.lengths(42, 0, n, "sprot")
+    assert lens.max() == synth.SPROT_MAX_LEN
+    d_res, offs = synth.residues_device(np.arange(n, dtype=np.int64), lens, 42, dev, stride=synth.SPROT_STRIDE)
+    torch.cuda.synchronize()
+    pdb = PreparedDb(None, offs, device_ptr=d_res.data_ptr())
+    alphabet, m = blosum50()
+    long_ones = np.nonzero(lens > 5000)[0]
+    assert 200 < len(long_ones) < 300
+    pick = np.unique(np.concatenate([long_ones, np.random.RandomState(3).choice(n, 300, replace=False)]))
+    sres, soffs, _ = synth.database_subset(pick, 42, lens=lens[pick], stride=synth.SPROT_STRIDE)
+    sdb = [sres[soffs[i]:soffs[i + 1]] for i in range(len(pick))]
+    sw = {}
+    for name in ("O74807", "P19930", "Q3ZAI3", "P18080"):
+        q = read_fasta(os.path.join(cases.DATA, f"query_{name}.fasta"), alphabet)[0]
+        c0 = counters()
+        rc, s, eq, et = pdb.search(q, 3, 1, m, 0, oracle_lib.MODE_SW)
+        c1 = counters()
+        d = {k: c1[k] - c0[k] for k in names}
+        assert rc == 0 and (eq == -1).all() and (et == -1).all()
+        orc, so, _, _ = oracle.search(q, sdb, 3, 1, m, 0, oracle_lib.MODE_SW)
+        assert orc == 0
+        np.testing.assert_array_equal(s[pick], so, err_msg=f"{name}: SW score vs oracle ({len(pick)} sequences, every one beyond 5000 residues)")
+        assert (s > 0).all() and (s <= int(m.max()) * np.minimum(len(q), lens)).all()
+        print(f"\n{name} (Q={len(q)}): " + ", ".join(f"{k} {v}" for k, v in d.items() if v))
+        if len(q) <= 200:   # short queries: the tail on the swapped kernel, the rest on class kernels
+            assert d["swapped"] >= 10 and d["stream_sw"] == 0, d
+        else:               # the head (longest sequences) on the class body inside the streaming launch
+            assert d["stream_sw"] == 1 and d["swapped"] == 0, d
+        sw[name] = s
+    q = read_fasta(os.path.join(cases.DATA, "query_P19930.fasta"), alphabet)[0]
+    Q = len(q)
+    out = {}
+    for mode in ("SW", "OV", "HW", "NW"):
+        rc, s, eq, et = pdb.search(q, 3, 1, m, 1, oracle_lib.MODES[mode])
+        assert rc == 0, mode
+        orc, so, oq, ot = oracle.search(q, sdb, 3, 1, m, 1, oracle_lib.MODES[mode])
+        assert orc == 0
+        np.testing.assert_array_equal(s[pick], so, err_msg=mode)
+        np.testing.assert_array_equal(eq[pick], oq, err_msg=mode)
+        np.testing.assert_array_equal(et[pick], ot, err_msg=mode)
+        out[mode] = (s, eq, et)
+    np.testing.assert_array_equal(out["SW"][0], sw["P19930"], err_msg="SW score-only (swapped tail) != SW with end locations (class kernels)")
+    assert (out["SW"][0] >= out["OV"][0]).all() and (out["OV"][0] >= out["HW"][0]).all() and (out["HW"][0] >= out["NW"][0]).all()
+    assert (out["NW"][1] == Q - 1).all() and (out["NW"][2] == lens - 1).all() and (out["HW"][1] == Q - 1).all()
+    for mode in ("SW", "OV", "HW"):
+        s, eq, et = out[mode]
+        assert (eq >= 0).all() and (eq < Q).all() and (et >= 0).all() and (et < lens).all()
+
+
 def _run_bench(extra, env_extra=None):
     import json
     import subprocess
@@ -292,6 +381,15 @@ def test_two_rank_bench_on_one_gpu():
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
     assert one["verify"]["score_crc32"] == two["verify"]["score_crc32"]
     assert one["roofline"]["bound"] == "valu-issue" and 0 < one["roofline"]["frac"] < 1
+    # what an N > 1 line needs to be read: every rank's kernel time, the deal's imbalance, the time of the exchange
+    r = two["ranks"]
+    assert len(r["kernel_ms"]["per_rank"]) == 2 and 0 < r["kernel_ms"]["min"] <= r["kernel_ms"]["max"]
+    assert 1.0 <= r["imbalance"] < 1.02 and r["exchange_ms"] > 0
+    assert one["in_flight"] == 2 and two["in_flight"] == 1 and one["ranks"]["exchange_ms"] is None
+    # ... and the drop-in call over both "GPUs" from one process (OPAL_HIP_DEVICES=0,0 here), the other rank waiting on the store
+    two_e2e = _run_bench(["--gpus", "2", "--total-seqs", "30000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                         {"BENCH_SHARE_GPU": "1", "BENCH_BACKEND": "gloo"})
+    assert two_e2e["verified"] and two_e2e["e2e"]["scores_match"] and two_e2e["e2e"]["ms"] > 0, two_e2e.get("e2e")
     # the same with a long query: both ranks on the streaming kernels (persistent workgroups of two processes share the GPU)
     common = ["--workload", "c5", "--total-seqs", "60000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e"]
     one = _run_bench(["--gpus", "1"] + common)
