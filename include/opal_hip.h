@@ -292,6 +292,12 @@ int opalx_debug_pool_selftest(int rounds, int callers);
    `residues`, `longest`, `num_seqs` describe the database. Returns 0. */
 int opalx_debug_plan_stream(int query_length, int alphabet_length, int mode, int want_end, long long residues, int longest,
                             int num_seqs, int* out);
+/* The library's options (INTEGRATION.md lists them) carry the names of environment variables -- OPAL_HIP_DEVICES,
+   OPAL_HIP_DEBUG, the scheduler's test hooks ... The environment is read ONCE, when the library first needs an option; after
+   that this call is the way to change one from inside the process (value NULL: back to the default). Values are
+   validated as they are for the environment. Returns 0, 1 for an unknown name, 2 for a value that does not parse (nothing
+   changes then). Not to be called while a search is running. */
+int opalx_set_option(const char* name, const char* value);
 void opalx_db_destroy(OpalxDb* db);
 /* Clock probe for measurements (bench.py): while enabled, every search on this handle also measures the shader clock
    its DP kernels ran at (cycle counter / constant-rate counter over the lifetime of one wave per workgroup) and reads it

@@ -54,6 +54,15 @@ def _db_arrays(db):
     return (seqs, dummy), ptrs, lens
 
 
+def set_option(name, value=None):
+    """opalx_set_option: change one of the library's options (names of environment variables, e.g. OPAL_HIP_DEVICES; value
+    None = back to the default). The library reads the environment only once, at its first use. Raises on an unknown name
+    or a value that does not parse."""
+    rc = _lib.lib().opalx_set_option(name.encode(), None if value is None else str(value).encode())
+    if rc != 0:
+        raise ValueError(f"opalx_set_option({name!r}, {value!r}) -> {rc} ({'unknown option' if rc == 1 else 'invalid value'})")
+
+
 def search_database(query, db, gap_open, gap_ext, score_matrix, search_type=OPAL_SEARCH_SCORE,
                     mode=OPAL_MODE_SW, overflow_method=OPAL_OVERFLOW_BUCKETS, results=None):
     """opalSearchDatabase. `db` is a list of uint8 index arrays. Returns (rc, results_array)."""

@@ -50,7 +50,7 @@ static bool order_into(int n, const int* lens, OrderScratch& scratch, std::vecto
     // (measured on the GPU box's host, 100 000 / 625 000 sequences: 1 thread 0.235 / 1.46 ms, 4 threads 0.26 / 0.83 median --
     // a job of the pool costs ~0.1 ms in wake-ups, so only large databases are worth spreading)
     int T = n >= 400000 ? std::min(pool.width(), 4) : 1;
-    if (const char* e = getenv("OPAL_ORDER_THREADS")) { const int v = atoi(e); if (v >= 1) T = std::min(v, pool.width()); }  // tuning hook
+    if (opts().orderThreads >= 1) T = std::min(opts().orderThreads, pool.width());  // tuning hook
     while (T > 1 && (size_t)T * B > (4u << 20)) T /= 2;
     std::vector<int>& hist = scratch.hist;  // (kept in the context: no fresh pages per call)
     hist.assign((size_t)T * B, 0);
@@ -140,8 +140,7 @@ bool device_ok() {
     if (checked == 0) {
         if (opal_hip_device_count() > 0) {
             checked = 1;
-            const char* env = getenv("OPAL_HIP_DEVICE");
-            if (env && *env && opal_hip_set_device(atoi(env)) != 0) checked = -1;
+            if (opts().device >= 0 && opal_hip_set_device(opts().device) != 0) checked = -1;
         } else {
             checked = -1;
         }
@@ -194,7 +193,7 @@ bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::funct
     // are then COMPARED while they are gathered, and only the chunks that differ are uploaded again -- reading the
     // caller's bytes is unavoidable, sending 35 MB over PCIe (0.8-1.0 ms on C2) is not.
     const bool reuse = db->cached && kind == RAW_POINTERS && db->lastValid && db->lastLens.size() == (size_t)n && n > 0 &&
-                       !getenv("OPAL_HIP_NO_REUSE") && memcmp(db->lastLens.data(), lens, (size_t)n * sizeof(int)) == 0;
+                       !opts().noReuse && memcmp(db->lastLens.data(), lens, (size_t)n * sizeof(int)) == 0;
     db->lastValid = false;
     if (!reuse) {
         db->seqItemValid = false;
@@ -339,7 +338,7 @@ bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::funct
             gg.copied[(size_t)c].store(1, std::memory_order_relaxed);
             const size_t i0 = (size_t)gg.cutItem[(size_t)c], i1 = (size_t)gg.cutItem[(size_t)c + 1];
             const uint64_t b0 = off[i0], b1 = i1 < items ? off[i1] : total;
-            static const bool two = [] { const char* e = getenv("OPAL_HIP_COPY_STREAMS"); return !(e && *e == '1'); }();
+            const bool two = !opts().oneCopyStream;
             void* cs = (two && (c & 1)) ? db->copyStream2 : db->copyStream;
             if (b1 > b0 && opal_hip_memcpy_h2d(db->res.p + b0, h + b0, b1 - b0, cs)) good = false;
             if (good && opal_hip_event_record(gg.events[(size_t)c], cs)) good = false;
@@ -356,7 +355,7 @@ bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::funct
     // over PCIe as soon as they have been gathered (35 MB in 1.5 ms of DP is 23 GB/s; tokens are fetched a batch of columns
     // ahead), instead of waiting for the copies -- which still run, beside the search, for whatever reads the device copy
     // afterwards (start cells, traceback, the next call on the same database).
-    g.zeroCopy = async && !reuse && !getenv("OPAL_HIP_NO_ZERO_COPY");
+    g.zeroCopy = async && !reuse && !opts().noZeroCopy;
     g.active = true;
     HostPool& pool = HostPool::get();
     if (g.timed) opal_hip_event_record(db->event(7), db->copyStream);  // (debug reference: the copy stream when the gather begins)
@@ -366,7 +365,7 @@ bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::funct
         // A database found again is searched SPECULATIVELY: the launches do not wait for the comparison (no gate), the
         // caller repeats the search if db_fill_finish reports that a chunk had changed after all (fill_changed()).
         // (Not right after a call that was caught out: a caller that edits its database in place pays the repeated search once.)
-        if (reuse && db->speculate && !getenv("OPAL_HIP_NO_SPECULATION")) g.active = false;
+        if (reuse && db->speculate && !opts().noSpeculation) g.active = false;
         g.speculated = !g.active;
         pool.begin(npieces, db->gatherFn);
         db->gatherPending = true;
@@ -565,6 +564,8 @@ extern "C" int opalx_debug_pool_selftest(int rounds, int callers) {
 }
 
 extern "C" long long opalx_stream_launch_count(void) { return g_counters[CNT_STREAM_SW].load() + g_counters[CNT_STREAM_GLOBAL].load(); }
+
+extern "C" int opalx_set_option(const char* name, const char* value) { return set_option(name, value); }
 
 extern "C" int opalx_counters(long long* out, int capacity) {
     for (int i = 0; i < capacity && i < (int)CNT_COUNT; i++) out[i] = g_counters[i].load();

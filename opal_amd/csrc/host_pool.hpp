@@ -30,6 +30,8 @@
 
 #include <unistd.h>
 
+#include "options.hpp"
+
 class HostPool {
 public:
     static HostPool& get() {
@@ -43,7 +45,7 @@ public:
             unsigned nt = std::thread::hardware_concurrency();
             if (nt == 0) nt = 1;
             if (nt > 256) nt = 256;
-            if (const char* e = getenv("OPAL_HOST_THREADS")) { const int v = atoi(e); if (v >= 1) nt = (unsigned)v; }
+            if (opal_host::opts().hostThreads >= 1) nt = (unsigned)opal_host::opts().hostThreads;
             return (int)nt <= default_threads() ? &get() : new HostPool((int)nt);
         }();
         return *pool;
@@ -91,10 +93,7 @@ public:
         unsigned nt = std::thread::hardware_concurrency();
         if (nt == 0) nt = 1;
         if (nt > 64) nt = 64;  // memcpy-bound work: more threads than memory channels do not help
-        if (const char* e = getenv("OPAL_HOST_THREADS")) {
-            const int v = atoi(e);
-            if (v >= 1) nt = (unsigned)v;
-        }
+        if (opal_host::opts().hostThreads >= 1) nt = (unsigned)opal_host::opts().hostThreads;  // (read when the pool is created: once per process)
         return (int)nt;
     }
 

@@ -44,9 +44,10 @@ static int launch_chunked(const SearchCtx& c, int width, int swEndPass, int dete
         fprintf(stderr, "[opal] alphabet of %d letters does not fit the on-chip query profile at width %d\n", c.A, width);
         return OPAL_ERR_NO_SIMD_SUPPORT;
     }
-    if (const char* geo = getenv("OPAL_HIP_CHUNK_GEOMETRY")) {  // "G,S": test hook to force small chunks
-        int g = 0, r = 0, ldsPad = 0;
-        if (sscanf(geo, "%d,%d", &g, &r) == 2 && opal_hip_rows_supported(width, c.mode, swEndPass | 2, r) == r &&
+    if (opts().chunkG > 0) {  // OPAL_HIP_CHUNK_GEOMETRY "G,S": test hook to force small chunks
+        const int g = opts().chunkG, r = opts().chunkS;
+        int ldsPad = 0;
+        if (opal_hip_rows_supported(width, c.mode, swEndPass | 2, r) == r &&
             opal_hip_lds_bytes(width, g, r, c.A) <= 160 * 1024) {
             bestG = g; bestS = r;
             pick_occupancy(kernel_vgprs(width, c.mode, swEndPass, 1, 0, bestS), opal_hip_lds_bytes(width, bestG, bestS, c.A), &wpb, &ldsPad,
@@ -100,7 +101,7 @@ static int launch_class(const SearchCtx& c, int width, int swEndPass, int detect
     a.skew = skew;
     a.stream = stream;
     a.priority = side ? 1 : 0;
-    if (const char* pe = getenv("OPAL_HIP_SIDE_PRIO")) a.priority = side ? atoi(pe) : 0;  // tuning hook
+    if (opts().sidePrio >= 0) a.priority = side ? opts().sidePrio : 0;  // tuning hook
     if (debug_on())
         fprintf(stderr, "[opal] launch width=%d mode=%d end=%d items=[%d,+%d) G=%d rows=%d waves/block=%d ldsPad=%d%s%s\n", width,
                 c.mode, swEndPass, k.first, k.count, k.G, k.rows, k.wpb, k.ldsPad, skew ? " skew" : "", side ? " (side)" : "");
@@ -121,16 +122,15 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
         const long long L0 = lenOf(item);
         return std::min<long long>(c.Q, L0) * c.maxScore + (OPAL_HIP_MAX_ROWS + L0 + 64 + 4) * (long long)c.Ge < 32000;
     };
-    const bool maySkew = width == 17 && c.mode != OPAL_MODE_SW && !work && !getenv("OPAL_HIP_NO_SKEW");
+    const bool maySkew = width == 17 && c.mode != OPAL_MODE_SW && !work && !opts().noSkew;
     // One launch for all classes where a one-launch kernel exists (plain 16-bit, no re-run list): see dp_kernel.hpp.
-    const bool uberEligible = width == 17 && !work && !getenv("OPAL_HIP_NO_UBER") && !getenv("OPAL_HIP_LANES_PER_SEQ");
+    const bool uberEligible = width == 17 && !work && !opts().noUber && !opts().lanesPerSeq;
     std::vector<LaunchClass> classes;
     std::string key;
     if (!work) {  // (re-run lists differ from search to search: planned every time)
         char buf[160];
-        const char* e1 = getenv("OPAL_HIP_LANES_PER_SEQ"); const char* e2 = getenv("OPAL_HIP_TAIL_FRACTION"); const char* e3 = getenv("OPAL_HIP_TAIL_MODEL");
-        snprintf(buf, sizeof buf, "%d/%d/%d/%d/%d/%d/%d/%lld/%d/%d/%d|%s|%s|%s", width, c.mode, swEndPass, c.Q, c.A, c.Go, c.Ge, c.maxScore, firstItem, numItems,
-                 (int)uberEligible, e1 ? e1 : "", e2 ? e2 : "", e3 ? e3 : "");
+        snprintf(buf, sizeof buf, "%d/%d/%d/%d/%d/%d/%d/%lld/%d/%d/%d|%s", width, c.mode, swEndPass, c.Q, c.A, c.Go, c.Ge, c.maxScore, firstItem, numItems,
+                 (int)uberEligible, opts().plan_key().c_str());
         key = buf;
         auto it = db->planCache.find(key);
         if (it != db->planCache.end()) {
@@ -147,7 +147,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
             for (const LaunchClass& k : classes) v.insert(v.end(), {k.first, k.count, k.G, k.rows, k.wpb, k.ldsPad});
         }
     }
-    if (classes.empty() || getenv("OPAL_HIP_FORCE_CHUNKS")) {
+    if (classes.empty() || opts().forceChunks) {
         if (!gate_items(db, c.stream ? c.stream : db->main(), 0, 2 * db->numPairs)) return OPAL_ERR_NO_SIMD_SUPPORT;
         return launch_chunked(c, width, swEndPass, detectWrap, work, firstItem, numItems, lenOf, ovfCounter);
     }
@@ -188,7 +188,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
     // SLICES of whole upload chunks, every slice launched as soon as its chunks have been enqueued, on two streams in turn
     // (`main` and `aux`) so that a slice starts while the previous one drains. Sequences are sorted longest first, so
     // the first slice holds the long classes.
-    if (db->gate.active && !work && !c.stream && (width == 17 || width == 18) && db->gate.chunks() >= 4 && !getenv("OPAL_HIP_NO_SLICES")) {
+    if (db->gate.active && !work && !c.stream && (width == 17 || width == 18) && db->gate.chunks() >= 4 && !opts().noSlices) {
         const UploadGate& g = db->gate;
         SearchCtx zc = c;
         // (a database seen for the first time: the launches read the pinned staging buffer over PCIe and write the device copy
@@ -201,10 +201,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
         // one chunk has landed) and runs on a high-priority side stream of its own; the others take `main` and `aux` in
         // turn, so that a slice starts while the previous one drains.
         std::vector<int> pattern{1, 4};  // (measured on C2, 17 chunks: 1,4 | 1,3,5 | 1,2,4 | 1,3,5,4 all within 0.1 ms; 1,16 and one launch 0.3 ms slower)
-        if (const char* e = getenv("OPAL_HIP_SLICES")) {
-            pattern.clear();
-            for (const char* q = e; *q;) { char* endp = nullptr; const long v = strtol(q, &endp, 10); if (endp == q) break; if (v > 0) pattern.push_back((int)v); q = *endp ? endp + 1 : endp; }
-        }
+        if (!opts().slices.empty()) pattern = opts().slices;
         std::vector<int> cut{firstItem};
         int chunk = 0;
         for (int want : pattern) {
@@ -216,7 +213,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
         }
         // a database of many chunks (hundreds of MB: the copy takes as long as the search) goes on in slices of a sixth of
         // the chunks, none smaller than two resident rounds (65 536 sequences)
-        if (!getenv("OPAL_HIP_SLICES") && g.chunks() > 24) {
+        if (opts().slices.empty() && g.chunks() > 24) {
             const int group = std::max(5, g.chunks() / 6);
             while (chunk + group < g.chunks()) {
                 chunk += group;
@@ -228,7 +225,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
         void* fork = db->event(0);
         void* aux = db->aux();
         void* side = db->stream(0);
-        static const int how = [] { const char* e = getenv("OPAL_HIP_SLICE_STREAMS"); return !e ? 1 : !strcmp(e, "serial") ? 0 : !strcmp(e, "separate") ? 2 : 1; }();
+        const int how = opts().sliceStreams;
         if (!fork || !aux || !side || opal_hip_event_record(fork, db->main()) || opal_hip_stream_wait_event(aux, fork) ||
             opal_hip_stream_wait_event(side, fork))
             return OPAL_ERR_NO_SIMD_SUPPORT;
@@ -436,14 +433,14 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
     long long maxS = 0, minS = 0;
     for (int i = 0; i < A * A; i++) { maxS = std::max<long long>(maxS, M[i]); minS = std::min<long long>(minS, M[i]); }
     bool fits16 = Go <= 32767 && Ge <= 32767 && maxS <= 32767 && minS >= -32768;
-    if (const char* e = getenv("OPAL_HIP_FORCE_WIDTH")) { if (atoi(e) == 32) fits16 = false; }  // test / profiling hook
+    if (opts().forceWidth == 32) fits16 = false;  // test / profiling hook
 
     // Narrow rung: 17 = plain 16-bit, one sequence per lane (full-rate VALU, 4-byte LDS profile entries); 16 = packed
     // pairs (half-rate VALU, 2-byte entries: queries whose 4-byte profile exceeds LDS); 18 = plain with 2-byte entries
     // (+0.5 instructions per cell; experimental, on request only).
     int narrow = 17;
     bool chunkedQuery = false;  // no single launch holds the query at any width: row chunks
-    if (const char* e = getenv("OPAL_HIP_NARROW")) { const int v = atoi(e); narrow = (v == 16 || v == 18) ? v : 17; }
+    if (opts().narrow) narrow = opts().narrow;
     {
         auto fits = [&](int width) {  // does some single-launch geometry hold the query at this width?
             for (int G = 1; G <= 64; G *= 2) {
@@ -454,15 +451,15 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
             }
             return false;
         };
-        const char* force = getenv("OPAL_HIP_NARROW_FORCE");  // "17": run width 17 in row chunks rather than switching width
+        const bool force17 = opts().narrowForce == 17;  // run width 17 in row chunks rather than switching width
         // (width 18 measured SLOWER than the packed pairs on the 2000-aa workload, 15.1 vs 14.8 ms, so it is never
         // chosen automatically: OPAL_HIP_NARROW=18 selects it for experiments)
-        if (narrow == 17 && !fits(17) && !(force && atoi(force) == 17)) {
+        if (narrow == 17 && !fits(17) && !force17) {
             narrow = 16;
             // ... except where the plain kernels with 2-byte profile entries measure faster (2000-aa query, class kernels,
             // 100 000 / 20 000 sequences: SW + end 4 150 against 3 350 / 3 720 against 2 970 GCUPS, OV 4 270 : 4 130 / 3 810 : 3 660,
             // NW and HW 4 970 : 5 100 / 4 400 : 4 040)
-            if (!getenv("OPAL_HIP_NARROW") && fits(18) &&
+            if (!opts().narrow && fits(18) &&
                 ((mode == OPAL_MODE_SW && wantEnd) || mode == OPAL_MODE_OV || (mode != OPAL_MODE_SW && db->numSeqs < 50000)))
                 narrow = 18;
         }
@@ -472,9 +469,9 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
         // unlike the packed pairs, issue at full rate (3000-aa query x 100 000 sequences, class-kernel chunks: SW + end 5 110 against
         // 3 470 GCUPS at width 16, SW score 5 320 against 4 700; what streams its chunks -- stream_kernel.hpp -- does not come here)
         chunkedQuery = !fits(17) && !fits(18) && !fits(16);
-        if (!getenv("OPAL_HIP_NARROW") && !(force && atoi(force) == 17) && chunkedQuery) {
+        if (!opts().narrow && !force17 && chunkedQuery) {
             narrow = mode == OPAL_MODE_HW ? 17 : 18;  // (HW: no 2-byte-profile chunk kernels beyond 16 rows per lane, inst_s18multi.hip)
-            if (const char* cw = getenv("OPAL_HIP_CHUNK_WIDTH")) { const int v = atoi(cw); if (v == 16 || v == 17 || v == 18) narrow = v; }
+            if (opts().chunkWidth) narrow = opts().chunkWidth;
         }
     }
     // SW score-only searches with long queries stream their sequences through persistent waves (plain 16-bit arithmetic)
@@ -488,7 +485,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
     // from run to run: P18080 x the Swiss-Prot shape 13.9 ms under the profiler, 14.4 / 15.4 / 18.9 ms without it, against
     // 15.3 ms on the class kernels alone -- profiles/r03_stream_head.txt.)
     int headItems = 0;
-    if (mode == OPAL_MODE_SW && fits16 && !splan.G && !chunkedQuery && !getenv("OPAL_HIP_NO_STREAM_HEAD")) {
+    if (mode == OPAL_MODE_SW && fits16 && !splan.G && !chunkedQuery && !opts().noStreamHead) {
         long long headRes = 0;
         int at = 0;
         for (int cut : {128, 512, 2048}) {
@@ -499,17 +496,16 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
             if (rest.G && rest.passes == 1 && rest.width == 17 && rest.G <= 16 && rest.rows <= (wantEnd ? 36 : 39)) { splan = rest; headItems = cut; break; }  // (the shapes of inst_stream17head.hip)
         }
     }
-    if (const char* hi = getenv("OPAL_HIP_STREAM_HEAD_ITEMS")) {  // test hook: a head of that many items on a (forced) stream
-        const int n = atoi(hi);
+    if (opts().streamHeadItems > 0) {  // test hook: a head of that many items on a (forced) stream
+        const int n = opts().streamHeadItems;
         if (mode == OPAL_MODE_SW && splan.G && splan.passes == 1 && splan.width == 17 && splan.G <= 16 && splan.rows <= (wantEnd ? 36 : 39) && n > 0 && n < 2 * P)
             headItems = n;
     }
     // While the database is still arriving (opalSearchDatabase) a streaming launch would have to wait for the last chunk: at 16
     // lanes per sequence or fewer, where streaming gains 2-4 % over the class kernels, the sliced class launches that start
     // on the first chunks are the better trade (C4 shard: the copy of 218 MB takes a third of the call).
-    if (splan.G && splan.G <= 16 && db->gate.active && db->gate.chunks() >= 4 && narrow == 17 && !getenv("OPAL_HIP_NO_SLICES")) {
-        const char* en = getenv("OPAL_HIP_STREAM");
-        if (!(en && *en == '1')) { splan = StreamPlan(); headItems = 0; }
+    if (splan.G && splan.G <= 16 && db->gate.active && db->gate.chunks() >= 4 && narrow == 17 && !opts().noSlices) {
+        if (opts().stream != 1) { splan = StreamPlan(); headItems = 0; }
     }
     const bool plain = narrow != 16 || splan.G;
     const int satLimit = plain ? (int)(32767 - maxS) : 32767;
@@ -660,10 +656,9 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                 return std::min<long long>(Q, L) * maxS + (OPAL_HIP_MAX_ROWS + L + 64 + 4) * (long long)Ge < 32000;
             };
             while (q32 < P && !skew_safe(db->pairLen[2 * (size_t)q32])) { moved += db->pairLen[2 * (size_t)q32] + db->pairLen[2 * (size_t)q32 + 1]; q32++; }
-            const char* sen = getenv("OPAL_HIP_STREAM");
             // (a query in row chunks: the unskewable sequences run on the class kernels' chunks on a side stream BESIDE the
             // streamed ones, not inside the launch -- they may hold a sixth of the residues before they become the longer side)
-            if (q32 < P && (moved * (chunkedQuery ? 6 : 50) <= db->residues || (sen && *sen == '1')) && !getenv("OPAL_HIP_NO_SKEW")) {
+            if (q32 < P && (moved * (chunkedQuery ? 6 : 50) <= db->residues || opts().stream == 1) && !opts().noSkew) {
                 gplan = plan_stream(Q, A, mode, wantEnd, db->residues - moved, db->pairLen[2 * (size_t)q32], db->numSeqs - 2 * q32);
             }
             if (!gplan.G) q32 = p32;
@@ -723,7 +718,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
         // high-priority side stream. The two ranges share nothing but the buffers they index by their own sequences.
         void* join32 = nullptr;
         SearchCtx c32 = c;
-        if (chunkedQuery && P > q32 && (2 * p32 > nBad || (gplan.G && gplan.passes > 1 && q32 > p32)) && !getenv("OPAL_HIP_NO_SIDE_PREFIX")) {
+        if (chunkedQuery && P > q32 && (2 * p32 > nBad || (gplan.G && gplan.passes > 1 && q32 > p32)) && !opts().noSidePrefix) {
             void* fork = db->event(8);
             void* side = db->stream(0);
             if (fork && side && !opal_hip_event_record(fork, st) && !opal_hip_stream_wait_event(side, fork)) { c32.stream = side; join32 = db->event(9); }

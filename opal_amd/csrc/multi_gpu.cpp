@@ -10,8 +10,9 @@ namespace opal_host {
 // may be listed more than once (two contexts on one GPU): that is how the sharding is tested on a one-GPU box.
 std::vector<int> call_devices() {
     std::vector<int> out;
-    const char* env = getenv("OPAL_HIP_DEVICES");
-    if (!env || !*env) return out;
+    const std::string devs = opts().devices;  // (a copy: opalx_set_option may replace the string)
+    const char* env = devs.c_str();
+    if (!*env) return out;
     const int n = opal_hip_device_count();
     if (!strcmp(env, "all")) {
         for (int i = 0; i < n; i++) out.push_back(i);

@@ -48,7 +48,7 @@ static int run_shard(int device, const unsigned char* query, int Q, unsigned cha
         OpalxDb* db;
         ~FillGuard() { db_fill_finish(db); }
     } guard{pdb};
-    const bool async = !getenv("OPAL_HIP_SYNC_FILL");
+    const bool async = !opts().syncFill;
     if (!db_fill(pdb, n, lens, RAW_POINTERS, [db, ids](int i) { return (const unsigned char*)db[ids ? ids[i] : i]; }, nullptr, nullptr, async))
         return OPAL_ERR_NO_SIMD_SUPPORT;
     const double t2 = now_ms();
@@ -88,7 +88,7 @@ static int run_shard(int device, const unsigned char* query, int Q, unsigned cha
     bool haveStarts = false;
     std::vector<int> redo;
     int nredo = 0;
-    if (startQ && startT && rc == 0 && wantEnd && n > 0 && !getenv("OPAL_HIP_HOST_STARTS")) {
+    if (startQ && startT && rc == 0 && wantEnd && n > 0 && !opts().hostStarts) {
         redo.resize((size_t)n);
         haveStarts = search_starts(pdb, query, Q, Go, Ge, M, A, mode, dS, dQ, dT, dS + 3 * nn, dS + 4 * nn, redo.data(), &nredo) == 0;
     }

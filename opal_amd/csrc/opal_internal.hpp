@@ -26,6 +26,7 @@
 #include <thread>
 #include <vector>
 
+#include "options.hpp"
 #include "host_pool.hpp"
 #include "opal.h"
 #include "opal_hip.h"
@@ -35,10 +36,7 @@ namespace opal_host {
 inline double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
-inline bool debug_on() {
-    static const int on = [] { const char* e = getenv("OPAL_HIP_DEBUG"); return (e && *e && *e != '0') ? 1 : 0; }();
-    return on != 0;
-}
+inline bool debug_on() { return opts().debug; }
 
 // What the searches of this process ran on (diagnostics and tests: opalx_counters).
 enum Counter {
@@ -244,7 +242,7 @@ struct OpalxDb {
         return swapStream;
     }
     void* stream(int i) {
-        if (!streams[i]) { const char* e = getenv("OPAL_HIP_SIDE_STREAM_PRIO"); streams[i] = (e && *e == '0') ? opal_hip_stream_create() : opal_hip_stream_create_high(); }
+        if (!streams[i]) streams[i] = opal_host::opts().sideStreamsNormalPrio ? opal_hip_stream_create() : opal_hip_stream_create_high();
         return streams[i];
     }
     void* event(int i) {

@@ -15,6 +15,7 @@
 #include "stream_kernel.hpp"
 #include "swap_kernel.hpp"
 #include "opal_hip.h"
+#include "options.hpp"
 
 static thread_local char g_err[512] = "";
 
@@ -112,8 +113,7 @@ extern "C" int opal_hip_memset(void* dst, int value, size_t bytes, void* stream)
 extern "C" int opal_hip_stream_sync(void* stream) {
     // OPAL_HIP_SPIN_SYNC=1 (experiment): poll instead of blocking -- the wake-up of a blocked host thread costs tens of
     // microseconds on a search that takes 1.5 ms
-    static const int spin = [] { const char* e = getenv("OPAL_HIP_SPIN_SYNC"); return (e && *e == '1') ? 1 : 0; }();
-    if (spin) {
+    if (opal_host::opts().spinSync) {
         hipError_t q;
         while ((q = hipStreamQuery((hipStream_t)stream)) == hipErrorNotReady) __builtin_ia32_pause();
         return q == hipSuccess ? 0 : fail("hipStreamQuery", q);
@@ -455,7 +455,7 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
     const int jobs = (a->num_items + slots - 1) / slots;
     const int maxWpb = opal_max_waves_per_block(a->width);
     int wpb = (a->waves_per_block >= 1 && a->waves_per_block <= maxWpb) ? a->waves_per_block : WAVES_PER_BLOCK;
-    if (const char* e = getenv("OPAL_HIP_WAVES_PER_BLOCK")) { const int w = atoi(e); if (w >= 1 && w <= maxWpb) wpb = w; }
+    if (opal_host::opts().wavesPerBlock >= 1 && opal_host::opts().wavesPerBlock <= maxWpb) wpb = opal_host::opts().wavesPerBlock;
     const int blocks = (jobs + wpb - 1) / wpb;
     size_t lds = lds_bytes(a->width, G, a->rows_per_lane, a->alphabet_length);
     if (a->lds_bytes_min > 0 && (size_t)a->lds_bytes_min > lds && a->lds_bytes_min <= 160 * 1024) lds = (size_t)a->lds_bytes_min;
@@ -566,7 +566,7 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
         sp.sideBlocks = (a->side_num_items + perSide - 1) / perSide;
         if (blocks + sp.sideBlocks > cus && blocks > 1) blocks = std::max(1, cus - sp.sideBlocks);  // every workgroup resident from the start
     }
-    if (const char* e = getenv("OPAL_HIP_STREAM_BLOCKS")) { const int b = atoi(e); if (b >= 1) blocks = b; }  // test hook
+    if (opal_host::opts().streamBlocks >= 1) blocks = opal_host::opts().streamBlocks;  // test hook
     if (ldsLaunch > 64 * 1024 && raise_lds_limit((const void*)fn)) return 1;
     hipLaunchKernelGGL(fn, dim3(blocks + sp.sideBlocks), dim3(STREAM_WAVES * 64), ldsLaunch, (hipStream_t)a->stream, sp);
     hipError_t e = hipGetLastError();

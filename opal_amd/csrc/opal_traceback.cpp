@@ -212,7 +212,7 @@ static void align_one(const unsigned char* rQuery, int queryLength, const unsign
         find_alignment(alignQuery, bq, rTarget.data(), bt, Go, Ge, profR + (queryLength - aq), queryLength, INT_MAX, OPAL_MODE_NW, a, ws);
         if (a.score == res->score) { emit(res, a, aq, at); return; }
         // the given start does not carry the score: fall through to the full pass (never seen; kept for safety)
-        if (getenv("OPAL_HIP_DEBUG")) fprintf(stderr, "[opal] traceback: start (%d,%d) gives %d, expected %d; full pass\n", knownStartQ, knownStartT, a.score, res->score);
+        if (opal_host::opts().debug) fprintf(stderr, "[opal] traceback: start (%d,%d) gives %d, expected %d; full pass\n", knownStartQ, knownStartT, a.score, res->score);
     }
     const uint64_t bytes = (uint64_t)aq * (uint64_t)at;  // upper bound (the pass stops at the start column)
     budget.acquire(bytes);
@@ -235,12 +235,11 @@ extern "C" int opalx_find_alignments_masked(unsigned char query[], int queryLeng
     for (int l = 0; l < alphabetLength; l++)
         for (int r = 0; r < queryLength; r++) profR[(size_t)l * queryLength + r] = scoreMatrix[(int)rQuery[r] * alphabetLength + l];
     uint64_t total = 8ull << 30;
-    if (const char* e = getenv("OPAL_TRACEBACK_BYTES")) { const long long v = atoll(e); if (v > 0) total = (uint64_t)v; }
+    if (opal_host::opts().tracebackBytes > 0) total = (uint64_t)opal_host::opts().tracebackBytes;
     ByteBudget budget(total);
     std::atomic<int> failed{0};
     // (the wide pool did not help: 20 000 alignments took 480 ms on 256 threads against 380 ms on 64; OPAL_HOST_WIDE=1 selects it)
-    const char* wide = getenv("OPAL_HOST_WIDE");
-    HostPool& pool = (wide && *wide == '1' && dbLength >= 512) ? HostPool::get_wide() : HostPool::get();
+    HostPool& pool = (opal_host::opts().hostWide == 1 && dbLength >= 512) ? HostPool::get_wide() : HostPool::get();
     const int tasks = std::max(1, std::min(dbLength, pool.width() * 4));
     pool.parallel_for(tasks, [&](int t) {
         // one workspace per host thread for the life of the process: its buffers grow once (fresh pages and mmap calls

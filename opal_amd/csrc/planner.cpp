@@ -133,14 +133,14 @@ std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass, int sk
     if (count <= 0) return out;
     struct Cand { int G, rows, wpb, ldsPad; double eff; };
     std::vector<Cand> cands;
-    const char* forceG = getenv("OPAL_HIP_LANES_PER_SEQ");
+    const int forceG = opts().lanesPerSeq;
     double lenSum = 0;
     const int sample = std::max(1, count / 4096);
     int nsamp = 0;
     for (int i = 0; i < count; i += sample) { lenSum += lenOf(first + i); nsamp++; }
     const double lavg = lenSum / nsamp;
     for (int G = 1; G <= 64; G *= 2) {
-        if (forceG && *forceG && atoi(forceG) != G) continue;
+        if (forceG && forceG != G) continue;
         const int need = (Q + G - 1) / G;
         if (need > OPAL_HIP_MAX_ROWS) continue;
         // rows per lane: the smallest instantiated value, or up to 3 more if that one compiles to a register count
@@ -153,7 +153,7 @@ std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass, int sk
             prevRows = rows;
             const size_t lds = opal_hip_lds_bytes(width, G, rows, A);
             if (lds > 160 * 1024) continue;
-            if (G > 1 && (G / 2) * rows >= Q && !(forceG && *forceG)) continue;  // half the lanes would hold padding only
+            if (G > 1 && (G / 2) * rows >= Q && !forceG) continue;  // half the lanes would hold padding only
             int wpb = 4, ldsPad = 0;
             const int waves = pick_occupancy(kernel_vgprs(width, mode, swEndPass, 0, skew, rows), lds, &wpb, &ldsPad, opal_hip_max_waves_per_block(width));
             const double eff = ((double)Q / (G * rows)) * (rows / step_clocks(width, rows)) * (lavg / (lavg + G - 1)) * issue_factor(waves);
@@ -172,16 +172,14 @@ std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass, int sk
     const double simds = 1024.0;
     const int slotsBase = 64 / cands[base].G;
     const double totalClocks = lenSum * sample / slotsBase * step_clocks(width, cands[base].rows) / simds;
-    const char* budEnv = getenv("OPAL_HIP_TAIL_FRACTION");
-    const double budget = std::max(totalClocks * (budEnv && *budEnv ? atof(budEnv) : 0.7), 20000.0);
+    const double budget = std::max(totalClocks * (opts().tailFraction > 0 ? opts().tailFraction : 0.7), 20000.0);
     // walk from the longest item: the smallest geometry (>= base) whose lone-wave time fits the budget
     size_t ci = 0;
     int start = first;
     // A class of long sequences is a handful of waves, each the oldest wave of its SIMD and therefore running at the
     // lone-wave rate: that is the time a boundary candidate is judged by. (Round 2, C2 database, 100 000 / 50 000
     // sequences: 1.594 -> 1.567 ms and 1.013 -> 0.967 ms against the pipe-rate model; OPAL_HIP_TAIL_MODEL=pipe restores it.)
-    const char* tm = getenv("OPAL_HIP_TAIL_MODEL");
-    const bool pipeModel = tm && !strcmp(tm, "pipe");
+    const bool pipeModel = opts().tailPipeModel;
     auto fits = [&](size_t c, int len) {
         const double per = pipeModel ? step_clocks(width, cands[c].rows) : lone_step_clocks(width, cands[c].rows);
         return (len + cands[c].G - 1) * per <= budget;
@@ -193,8 +191,7 @@ std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass, int sk
     if (maxGFactor > 0) {
         size_t keep = cands.size();
         while (keep > base + 1 && cands[keep - 1].G > maxGFactor * cands[base].G) keep--;
-        const char* uo = getenv("OPAL_HIP_UBER_ONLY");
-        if (keep == cands.size() || fits(keep - 1, lenOf(first)) || (uo && *uo == '1')) cands.resize(keep);
+        if (keep == cands.size() || fits(keep - 1, lenOf(first)) || opts().uberOnly) cands.resize(keep);
     }
     auto cls = [&](int s, int n, size_t c) { return LaunchClass{s, n, cands[c].G, cands[c].rows, cands[c].wpb, cands[c].ldsPad}; };
     int i = first;
@@ -218,8 +215,7 @@ std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass, int sk
     // the same queue and run one after the other (2.3 ms instead of 1.6 ms on C2, depending on how many streams the
     // process had created: scripts/gpu_queue_probe.py). The side streams are therefore HIGH-priority streams, which
     // get queues of their own; with them three side streams work too but measure 1-3 % slower than two.
-    const char* nsEnv = getenv("OPAL_HIP_SIDE_STREAMS");  // tuning hook: 3 side streams
-    const size_t maxClasses = (nsEnv && atoi(nsEnv) == 3) ? 4 : 3;
+    const size_t maxClasses = opts().sideStreams == 3 ? 4 : 3;  // (tuning hook: 3 side streams)
     while (out.size() > maxClasses) {  // fold the two longest classes together
         out[1].count += out[0].count;
         out[1].first = out[0].first;
@@ -240,24 +236,20 @@ std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass, int sk
  */
 int plan_swap(int Q, int A, LenView lenOf, int first, int count, long long residues, int* rowsOut) {
     *rowsOut = 0;
-    const char* en = getenv("OPAL_HIP_SWAP");  // "0": never; "N" > 0 (test hook): the N longest items whatever the model says
-    if (en && *en == '0') return 0;
+    const int forced = opts().swap;  // 0: never; N > 0 (test hook): the N longest items whatever the model says
+    if (forced == 0) return 0;
     int rows = opal_hip_swap_rows(Q, A);
-    if (const char* re = getenv("OPAL_HIP_SWAP_ROWS")) {  // test / tuning hook: another instantiated shape
-        const int r = atoi(re);
-        if ((r == 8 || r == 16 || r == 24 || r == 40) && opal_hip_swap_lds_bytes(r, Q, A) <= 160 * 1024) rows = r;
-    }
+    if (opts().swapRows && opal_hip_swap_lds_bytes(opts().swapRows, Q, A) <= 160 * 1024) rows = opts().swapRows;  // test / tuning hook
     if (!rows || count <= 0) return 0;
     *rowsOut = rows;
-    if (en && atoi(en) > 0) return std::min(atoi(en), count);
+    if (forced > 0) return std::min(forced, count);
     int G0 = 1;
     while (G0 < 64 && (Q + G0 - 1) / G0 > OPAL_HIP_MAX_ROWS) G0 *= 2;
     const int S0 = (Q + G0 - 1) / G0;
     const int Gw = std::min(64, 4 * G0);
     const int Sw = (Q + Gw - 1) / Gw;
     const double totalClocks = (double)residues / (64 / G0) * step_clocks(17, S0) / 1024.0;
-    const char* budEnv = getenv("OPAL_HIP_TAIL_FRACTION");
-    const double budget = std::max(totalClocks * (budEnv && *budEnv ? atof(budEnv) : 0.7), 20000.0);
+    const double budget = std::max(totalClocks * (opts().tailFraction > 0 ? opts().tailFraction : 0.7), 20000.0);
     auto classClocks = [&](int len) { return (len + Gw - 1) * lone_step_clocks(17, Sw); };
     auto swapClocks = [&](int len) { return (double)((len + 64 * rows - 1) / (64 * rows)) * (Q + 63) * lone_step_clocks(18, rows); };
     const int longest = lenOf(first);
@@ -279,16 +271,15 @@ int plan_swap(int Q, int A, LenView lenOf, int first, int count, long long resid
 // such loss, so it is chosen by the cost of a column step per useful query row alone.
 StreamPlan plan_stream(int Q, int A, int mode, int wantEnd, long long residues, int longest, int numSeqs) {
     StreamPlan best;
-    const char* en = getenv("OPAL_HIP_STREAM");          // "0": never, "1": whenever a geometry exists (tests), unset: long queries
-    if (en && *en == '0') return best;
-    const bool force = en && *en == '1';
-    const char* forceG = getenv("OPAL_HIP_LANES_PER_SEQ");
-    const char* forceW = getenv("OPAL_HIP_NARROW");
+    if (opts().stream == 0) return best;     // OPAL_HIP_STREAM: 0 never, 1 whenever a geometry exists (tests), unset: long queries
+    const bool force = opts().stream == 1;
+    const int forceG = opts().lanesPerSeq;
+    const int forceW = opts().narrow;
     double bestCost = 1e30;
     for (int width : {17, 18}) {
-        if (forceW && *forceW && atoi(forceW) != width && (atoi(forceW) == 17 || atoi(forceW) == 18)) continue;
+        if (forceW && forceW != width && (forceW == 17 || forceW == 18)) continue;
         for (int G = 1; G <= 64; G *= 2) {
-            if (forceG && *forceG && atoi(forceG) != G) continue;
+            if (forceG && forceG != G) continue;
             const int need = (Q + G - 1) / G;
             if (need > OPAL_HIP_MAX_ROWS) continue;
             const int rows = opal_hip_stream_rows_supported(width, mode, wantEnd, need);
@@ -298,11 +289,11 @@ StreamPlan plan_stream(int Q, int A, int mode, int wantEnd, long long residues, 
             if (cost < bestCost) { bestCost = cost; best.width = width; best.G = G; best.rows = rows; }
         }
     }
-    if (!best.G && !(forceW && *forceW) && !getenv("OPAL_HIP_NO_STREAM_CHUNKS")) {
+    if (!best.G && !forceW && !opts().noStreamChunks) {
         // No single launch holds the query (more than 64 lanes x 40 rows, or a profile beyond LDS): row chunks, one streaming
         // launch each (stream_kernel.hpp, CHUNK), equal chunks at the fewest passes each geometry allows.
         for (int G = 16; G <= 64; G *= 2) {
-            if (forceG && *forceG && atoi(forceG) != G) continue;
+            if (forceG && forceG != G) continue;
             if (!force && (wantEnd || mode != OPAL_MODE_SW) && G < 32) continue;  // (as below: those run at 32 lanes or more)
             int cap = 0;
             for (int S = OPAL_HIP_MAX_ROWS; S >= 1 && !cap; S--)
@@ -323,10 +314,9 @@ StreamPlan plan_stream(int Q, int A, int mode, int wantEnd, long long residues, 
             if (cost < bestCost) { bestCost = cost; best.width = 17; best.G = G; best.rows = rows; best.passes = passes; }
         }
     }
-    if (const char* sc = getenv("OPAL_HIP_STREAM_CHUNKS")) {  // "G,S": test hook -- row chunks of G x S rows whatever the query length
-        int g = 0, r = 0;
-        if (sscanf(sc, "%d,%d", &g, &r) == 2 && g >= 1 && g <= 64 && (g & (g - 1)) == 0 &&
-            opal_hip_stream_rows_supported(17, mode, wantEnd | 2, r) == r && opal_hip_stream_lds_bytes(17, mode, g, r, A) <= 160 * 1024 && Q > g * r) {
+    if (opts().streamChunkG > 0) {  // OPAL_HIP_STREAM_CHUNKS "G,S": test hook -- row chunks of G x S rows whatever the query length
+        const int g = opts().streamChunkG, r = opts().streamChunkS;
+        if (opal_hip_stream_rows_supported(17, mode, wantEnd | 2, r) == r && opal_hip_stream_lds_bytes(17, mode, g, r, A) <= 160 * 1024 && Q > g * r) {
             best.width = 17; best.G = g; best.rows = r; best.passes = (Q + g * r - 1) / (g * r);
             return best;
         }

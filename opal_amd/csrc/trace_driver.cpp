@@ -43,7 +43,7 @@ int search_starts(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge
     const int doubtful = flags[0];
     int left = doubtful;
     const int* leftList = db->redo.p;
-    if (doubtful > 0 && !getenv("OPAL_HIP_NO_EXACT_ROW")) {
+    if (doubtful > 0 && !opts().noExactRow) {
         // Second pass over the doubtful ones (OV: a cell that is not an allowed end held the score in the stop column): their
         // stop column is final, the reference's row scan of that column is repeated exactly on the device. Only sequences
         // without a stop column at all stay for the host.
@@ -81,9 +81,9 @@ void device_traceback(OpalxDb* db, int Q, int Go, int Ge, int A, int mode, int n
     out.off.assign((size_t)n, 0);
     out.chunk.assign((size_t)n, 0);
     out.chunks.clear();
-    if (getenv("OPAL_HIP_HOST_TRACEBACK") || !db->seqItemValid || n <= 0) return;
+    if (opts().hostTraceback || !db->seqItemValid || n <= 0) return;
     uint64_t budget = 8ull << 30;
-    if (const char* e = getenv("OPAL_TRACEBACK_DEVICE_BYTES")) { const long long v = atoll(e); if (v > 0) budget = (uint64_t)v; }
+    if (opts().tracebackDeviceBytes > 0) budget = (uint64_t)opts().tracebackDeviceBytes;
     void* st = db->main();
     std::vector<int> items;
     std::vector<uint64_t> offs;  // [2 * batch]: flag-matrix offsets, then operation offsets

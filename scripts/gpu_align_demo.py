@@ -5,6 +5,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
+import opal_amd
 import torch  # noqa: F401  (libopal binds to torch's HIP runtime)
 from opal_amd import _lib, synth
 from opal_amd.api import OpalSearchResult, MODES
@@ -45,9 +46,9 @@ for mode in ("SW", "OV", "HW", "NW"):
     t_end = min(call(mode, 1)[0] for _ in range(3))
     res_by = {}
     for tag, env in (("device starts + box traceback", None), ("device starts, host box traceback", "T"), ("host full reverse pass", "1")):
-        os.environ.pop("OPAL_HIP_HOST_STARTS", None); os.environ.pop("OPAL_HIP_HOST_TRACEBACK", None)
-        if env == "1": os.environ["OPAL_HIP_HOST_STARTS"] = "1"
-        if env == "T": os.environ["OPAL_HIP_HOST_TRACEBACK"] = "1"
+        opal_amd.set_option("OPAL_HIP_HOST_STARTS", None); opal_amd.set_option("OPAL_HIP_HOST_TRACEBACK", None)
+        if env == "1": opal_amd.set_option("OPAL_HIP_HOST_STARTS", "1")
+        if env == "T": opal_amd.set_option("OPAL_HIP_HOST_TRACEBACK", "1")
         best, keep = None, None
         for rep in range(3):
             dt, out = call(mode, 2)

@@ -4,6 +4,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
+import opal_amd
 import torch
 from opal_amd import synth
 from opal_amd.api import PreparedDb
@@ -25,8 +26,9 @@ ST = int(os.environ.get("ST", "0"))  # 1: with end locations
 
 def run(q, go, ge, env, out, iters):
     for k in ("OPAL_HIP_STREAM", "OPAL_HIP_LANES_PER_SEQ", "OPAL_HIP_NARROW"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
+        opal_amd.set_option(k, None)
+    for k, v in env.items():
+        opal_amd.set_option(k, v)
     ks = []
     out.fill_(-7)
     for _ in range(iters):

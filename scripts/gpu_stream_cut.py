@@ -4,6 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch
+import opal_amd
 from opal_amd import synth
 from opal_amd.api import PreparedDb
 from opal_amd.score_matrix import blosum50
@@ -18,7 +19,7 @@ for cut in [int(c) for c in os.environ.get("CUTS", "700,1000,1500,6000").split("
     pdb = PreparedDb.from_sequences([res[offs[i]:offs[i + 1]] for i in keep])
     cells = float(len(q)) * float(lens[keep].sum())
     for s in ("0", "1"):
-        os.environ["OPAL_HIP_STREAM"] = s
+        opal_amd.set_option("OPAL_HIP_STREAM", s)
         ks = []
         for _ in range(30):
             rc, kms = pdb.search_device(q, 11, 1, m, 0, 3, out.data_ptr(), 0, 0)

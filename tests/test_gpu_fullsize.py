@@ -211,7 +211,7 @@ def test_c5_long_query_buckets(c4shard, oracle):
     assert (s[sorted(planted)] > 32767).all()
 
 
-def test_c4_eight_way_equals_unsharded(monkeypatch, oracle):
+def test_c4_eight_way_equals_unsharded(opal_opt, oracle):
     """BASELINE.json configs[3] whole: P18080 x all 5 000 000 sequences. Once unsharded on the device-resident database
     (opalx_search_device), once through opalSearchDatabase itself with the in-library sharding over eight contexts
     (OPAL_HIP_DEVICES = eight times this box's one GPU: the deal, the per-shard pipelines and the host-side merge are
@@ -269,7 +269,7 @@ def test_c4_eight_way_equals_unsharded(monkeypatch, oracle):
     arr = (OpalSearchResult * n)()
     words = np.frombuffer(arr, dtype=np.int32).reshape(n, 10)
     rptrs = np.ascontiguousarray(C.addressof(arr) + 40 * np.arange(n, dtype=np.uint64), dtype=np.uint64)
-    monkeypatch.setenv("OPAL_HIP_DEVICES", "0,0,0,0,0,0,0,0")
+    opal_opt.set("OPAL_HIP_DEVICES", "0,0,0,0,0,0,0,0")
     for mode, st in (("SW", 0), ("HW", 1)):
         words[:, 0] = 0
         words[:, 2:6] = -1
@@ -429,7 +429,7 @@ def test_bench_launcher_failing_rank_on_gpu():
     assert time.time() - t0 < 20
 
 
-def test_api_context_reuse_and_multi_device(oracle):
+def test_api_context_reuse_and_multi_device(oracle, opal_opt):
     """opalSearchDatabase keeps its device buffers between calls (cached contexts) and can shard one call over
     several GPUs (OPAL_HIP_DEVICES; "0,0" = two contexts on this box's one GPU): growing and shrinking databases,
     interleaved modes, and the sharded call must all give the single-call answers."""
@@ -452,7 +452,7 @@ def test_api_context_reuse_and_multi_device(oracle):
             np.testing.assert_array_equal(got[1][pick], oq)
             np.testing.assert_array_equal(got[2][pick], ot)
             want[(n, mode)] = got
-    os.environ["OPAL_HIP_DEVICES"] = "0,0"
+    opal_opt.set("OPAL_HIP_DEVICES", "0,0")
     try:
         res, offs, lens = synth.database(6000, seed=42, first=1000)
         db = [res[offs[i]:offs[i + 1]] for i in range(6000)]
@@ -463,7 +463,7 @@ def test_api_context_reuse_and_multi_device(oracle):
             for a, b in zip(got, want[(6000, mode)]):
                 np.testing.assert_array_equal(a, b)
     finally:
-        del os.environ["OPAL_HIP_DEVICES"]
+        opal_opt.unset("OPAL_HIP_DEVICES")
 
 
 def test_same_database_again_uploads_only_what_changed(oracle):
@@ -516,7 +516,7 @@ def test_same_database_again_uploads_only_what_changed(oracle):
 
 
 @pytest.mark.parametrize("narrow", [None, "16", "18"])
-def test_same_lengths_mutated_residues_long_query(narrow, oracle, monkeypatch):
+def test_same_lengths_mutated_residues_long_query(narrow, oracle, opal_opt):
     """The repeat-search path of a re-seen database at the widths a 2000-aa query runs on: the speculative search of a
     database recognised by its lengths builds the width-16 pair tokens from whatever the device holds; when the comparison
     finds changed chunks the search is repeated -- on tokens rebuilt from the new residues (they used to stay marked valid:
@@ -526,8 +526,8 @@ def test_same_lengths_mutated_residues_long_query(narrow, oracle, monkeypatch):
     from opal_amd import synth
     from opal_amd.score_matrix import blosum50
     if narrow:
-        monkeypatch.setenv("OPAL_HIP_NARROW", narrow)
-    monkeypatch.setenv("OPAL_HIP_STREAM", "0")  # (the class kernels: the streaming ones never read pair tokens)
+        opal_opt.set("OPAL_HIP_NARROW", narrow)
+    opal_opt.set("OPAL_HIP_STREAM", "0")  # (the class kernels: the streaming ones never read pair tokens)
     m = blosum50()[1]
     n = 6000
     res, offs, lens = synth.database(n, seed=42, first=400000)
@@ -634,7 +634,7 @@ def test_multi_gpu_handle_device_side_gather(c2):
 
 
 @pytest.mark.parametrize("mode", ["SW", "NW", "HW", "OV"])
-def test_one_launch_kernels_equal_separate_launches(mode, c2, oracle, monkeypatch):
+def test_one_launch_kernels_equal_separate_launches(mode, c2, oracle, opal_opt):
     """The one-launch ("uber") kernels -- all length classes of a search as ONE grid -- against the same search as
     separate launches on forked streams (OPAL_HIP_NO_UBER=1): identical scores and end cells on 30 000 sequences of the
     C2 database (three classes: the 5000-residue tail, the long ones, the bulk), score only and with end locations."""
@@ -644,14 +644,14 @@ def test_one_launch_kernels_equal_separate_launches(mode, c2, oracle, monkeypatc
     q, m = c2["q"], c2["m"]
     for st in (0, 1):
         for go in (11, 3):
-            monkeypatch.delenv("OPAL_HIP_NO_UBER", raising=False)
+            opal_opt.unset("OPAL_HIP_NO_UBER")
             a = pdb.search(q, go, 1, m, st, oracle_lib.MODES[mode])
-            monkeypatch.setenv("OPAL_HIP_NO_UBER", "1")
+            opal_opt.set("OPAL_HIP_NO_UBER", "1")
             b = pdb.search(q, go, 1, m, st, oracle_lib.MODES[mode])
             assert a[0] == b[0] == 0
             for x, y in zip(a[1:], b[1:]):
                 np.testing.assert_array_equal(x, y)
-    monkeypatch.delenv("OPAL_HIP_NO_UBER", raising=False)
+    opal_opt.unset("OPAL_HIP_NO_UBER")
     pick = _sample(c2["lens"][:n], 120, seed=9, n_edge=25)
     db = [c2["res"][c2["offs"][i]:c2["offs"][i + 1]] for i in pick]
     rc, s, eq, et = pdb.search(q, 3, 1, m, 1, oracle_lib.MODES[mode])

@@ -118,7 +118,7 @@ def test_longtail_search_score_and_end(qlen, base, gold, oracle):
 
 
 @pytest.mark.parametrize("qlen", longtail.QUERY_LENGTHS)
-def test_longtail_alignment(qlen, base, gold, oracle, monkeypatch):
+def test_longtail_alignment(qlen, base, gold, oracle, opal_opt):
     """OPAL_SEARCH_ALIGNMENT through the C ABI on 1 500 sequences + the planted ones: start cells and operation strings of
     the planted targets equal the reference's (SW/HW/OV; crc32 of the strings), every NW alignment re-scores to its
     score (35 213-column boxes), and the device traceback equals the host traceback string by string."""
@@ -148,9 +148,9 @@ def test_longtail_alignment(qlen, base, gold, oracle, monkeypatch):
             assert oracle.check_alignment(q, seqs[i], longtail.GAP_OPEN, longtail.GAP_EXT, m, s[i], sq[i], st[i], eq[i], et[i],
                                           np.frombuffer(ops[i], np.uint8)) == 0, f"Q={qlen} {mode} #{i} does not re-score"
         # the same call with the host traceback: identical starts and strings everywhere
-        monkeypatch.setenv("OPAL_HIP_HOST_TRACEBACK", "1")
+        opal_opt.set("OPAL_HIP_HOST_TRACEBACK", "1")
         rc2, s2, eq2, et2, _, (arr2, _) = ours.search(q, seqs, longtail.GAP_OPEN, longtail.GAP_EXT, m, 2, MODES[mode])
-        monkeypatch.delenv("OPAL_HIP_HOST_TRACEBACK")
+        opal_opt.unset("OPAL_HIP_HOST_TRACEBACK")
         sq2, st2, ops2 = ours.alignments(arr2)
         assert rc2 == 0
         np.testing.assert_array_equal(s, s2); np.testing.assert_array_equal(sq, sq2); np.testing.assert_array_equal(st, st2)

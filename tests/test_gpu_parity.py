@@ -60,7 +60,7 @@ def test_case_vs_golden_and_oracle(name, ours, oracle, golden):
 
 @pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 32, 64])
 @pytest.mark.parametrize("mode", ["SW", "NW", "HW", "OV"])
-def test_every_wave_geometry(lanes, mode, ours, oracle, monkeypatch):
+def test_every_wave_geometry(lanes, mode, ours, oracle, opal_opt):
     """Force each lanes-per-sequence value: results must not depend on how rows are spread over lanes."""
     from opal_amd import synth
     from opal_amd.score_matrix import blosum50
@@ -69,7 +69,7 @@ def test_every_wave_geometry(lanes, mode, ours, oracle, monkeypatch):
     db = [res[offs[i]:offs[i + 1]] for i in range(140)]
     q = synth.query(qlen, seed=lanes)
     m = blosum50()[1]
-    monkeypatch.setenv("OPAL_HIP_LANES_PER_SEQ", str(lanes))
+    opal_opt.set("OPAL_HIP_LANES_PER_SEQ", str(lanes))
     rc, s, eq, et, _, _ = ours.search(q, db, 3, 1, m, 1, MODES[mode])
     want = oracle.search(q, db, 3, 1, m, 1, MODES[mode])
     _check((rc, s, eq, et), want, mode, f"G={lanes} {mode}")
@@ -206,7 +206,7 @@ def test_device_start_locations_vs_golden(name, golden):
 
 
 @pytest.mark.parametrize("mode", ["SW", "NW", "HW", "OV"])
-def test_device_start_locations_differential(mode, ours, monkeypatch):
+def test_device_start_locations_differential(mode, ours, opal_opt):
     """n4 on a larger set: the alignment search with device start cells + box traceback gives the same start cells and
     operation strings as the same search with the host's full reverse pass (OPAL_HIP_HOST_STARTS=1)."""
     from opal_amd import synth
@@ -218,7 +218,7 @@ def test_device_start_locations_differential(mode, ours, monkeypatch):
     rc, s, eq, et, sset, (arr, _) = ours.search(q, db, 3, 1, m, 2, MODES[mode])
     assert rc == 0
     sq, st, ops = ours.alignments(arr)
-    monkeypatch.setenv("OPAL_HIP_HOST_STARTS", "1")
+    opal_opt.set("OPAL_HIP_HOST_STARTS", "1")
     rc2, s2, eq2, et2, sset2, (arr2, _) = ours.search(q, db, 3, 1, m, 2, MODES[mode])
     assert rc2 == 0
     sq2, st2, ops2 = ours.alignments(arr2)
@@ -304,20 +304,20 @@ def test_dropin_cli_output_equals_reference_cli(mode, level):
 @pytest.mark.parametrize("geometry,narrow", [("2,8", None), ("8,8", None), ("1,16", None), ("64,8", None), ("4,40", None),
                                              ("2,8", "18"), ("16,8", "18"), ("1,24", "18"), ("4,32", "18"), ("2,8", "16"), ("4,40", "16")])
 @pytest.mark.parametrize("mode", ["SW", "NW", "HW", "OV"])
-def test_query_chunks_forced(geometry, narrow, mode, ours, oracle, monkeypatch):
+def test_query_chunks_forced(geometry, narrow, mode, ours, oracle, opal_opt):
     """Long-query path on short inputs: force the query to be cut into many row chunks (boundary row through
     HBM) and compare with the oracle, 16-bit (plain with 4- and 2-byte profile entries, packed pairs) and 32-bit
     kernels, score and end locations."""
     if narrow:
-        monkeypatch.setenv("OPAL_HIP_NARROW", narrow)
+        opal_opt.set("OPAL_HIP_NARROW", narrow)
     from opal_amd import synth
     from opal_amd.score_matrix import blosum50
     res, offs, lens = synth.database(90, seed=321)
     db = [res[offs[i]:offs[i + 1]] for i in range(90)]
     q = synth.query(203, seed=11)
     m = blosum50()[1]
-    monkeypatch.setenv("OPAL_HIP_FORCE_CHUNKS", "1")
-    monkeypatch.setenv("OPAL_HIP_CHUNK_GEOMETRY", geometry)
+    opal_opt.set("OPAL_HIP_FORCE_CHUNKS", "1")
+    opal_opt.set("OPAL_HIP_CHUNK_GEOMETRY", geometry)
     got = ours.search(q, db, 3, 1, m, 1, MODES[mode])[:4]
     _check(got, oracle.search(q, db, 3, 1, m, 1, MODES[mode]), mode, f"chunks {geometry} {mode}")
     # 32-bit kernels: scores beyond int16
@@ -413,19 +413,19 @@ def test_reentrant_from_host_threads(ours, oracle):
 
 @pytest.mark.parametrize("mode", ["SW", "NW", "HW", "OV"])
 @pytest.mark.parametrize("qlen", [513, 1100, 2000])
-def test_width18_two_byte_profile_kernels(mode, qlen, ours, oracle, monkeypatch):
+def test_width18_two_byte_profile_kernels(mode, qlen, ours, oracle, opal_opt):
     """The plain-16-bit kernels with 2-byte profile entries (width 18: what 2000-aa queries run on), forced also for
     shorter queries: every rows-per-lane instantiation family (8/16/24/32/40), score + end location and score only."""
     from opal_amd import synth
     from opal_amd.score_matrix import blosum50
-    monkeypatch.setenv("OPAL_HIP_NARROW", "18")
+    opal_opt.set("OPAL_HIP_NARROW", "18")
     res, offs, lens = synth.database(260, seed=42, first=70000 + qlen)
     db = [res[offs[i]:offs[i + 1]] for i in range(260)] + [synth.query(qlen, seed=7)[: qlen - 3].copy()]
     q = synth.query(qlen, seed=7)
     m = blosum50()[1]
     for lanes in (("", "64") if qlen > 1280 else ("", "32", "64")):
         if lanes:
-            monkeypatch.setenv("OPAL_HIP_LANES_PER_SEQ", lanes)
+            opal_opt.set("OPAL_HIP_LANES_PER_SEQ", lanes)
         got = ours.search(q, db, 3, 1, m, 1, MODES[mode])[:4]
         _check(got, oracle.search(q, db, 3, 1, m, 1, MODES[mode]), mode, f"width 18 q{qlen} {mode} lanes={lanes or 'auto'}")
     if mode == "SW":
@@ -434,10 +434,10 @@ def test_width18_two_byte_profile_kernels(mode, qlen, ours, oracle, monkeypatch)
 
 
 @pytest.mark.parametrize("narrow", ["16", "17", "18"])
-def test_many_saturated_scores_rerun(narrow, ours, oracle, monkeypatch):
+def test_many_saturated_scores_rerun(narrow, ours, oracle, opal_opt):
     """Most of the database exceeds the 16-bit rung: the ballot-built re-run list must hold every one of them
     exactly once (scores and end locations come from the 32-bit kernels), the rest stays at 16 bit."""
-    monkeypatch.setenv("OPAL_HIP_NARROW", narrow)
+    opal_opt.set("OPAL_HIP_NARROW", narrow)
     rng = np.random.RandomState(5)
     q = rng.randint(0, 4, size=900).astype(np.uint8)
     m = cases.simple_matrix(4, 60, -40)
@@ -456,15 +456,15 @@ def test_many_saturated_scores_rerun(narrow, ours, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("mode", ["NW", "HW", "OV"])
-def test_unskewed_16bit_kernels_still_match(mode, ours, oracle, monkeypatch):
+def test_unskewed_16bit_kernels_still_match(mode, ours, oracle, opal_opt):
     """NW/HW/OV normally run in the diagonal-skewed representation; the plain one (used when the skew would
     leave the 16-bit range) must give the same answers."""
     q, db, m = cases.materialise(cases.CASES["synth_q300_db2000_o3"])
     db = db[:400]
-    monkeypatch.setenv("OPAL_HIP_NO_SKEW", "1")
+    opal_opt.set("OPAL_HIP_NO_SKEW", "1")
     got = ours.search(q, db, 3, 1, m, 1, MODES[mode])[:4]
     _check(got, oracle.search(q, db, 3, 1, m, 1, MODES[mode]), mode, f"no-skew {mode}")
-    monkeypatch.delenv("OPAL_HIP_NO_SKEW")
+    opal_opt.unset("OPAL_HIP_NO_SKEW")
     # large extension penalty: the skew bound fails for the long targets, holds for the short ones
     _, dbl = cases.random4(91, 10, 30, 4, 30, 2500)
     q4 = (np.arange(150) % 4).astype(np.uint8)
@@ -496,19 +496,19 @@ def _stream_db(qlen, n=500):
 
 @pytest.mark.parametrize("qlen,lanes,narrow", [(100, "4", "17"), (300, "8", "17"), (513, "16", "17"), (1000, "32", "17"), (1280, "32", "17"),
                                                (1330, "64", "17"), (1100, "64", "18"), (2000, "64", "18"), (2500, "64", "18")])
-def test_streaming_sw_score_kernels(qlen, lanes, narrow, ours, oracle, monkeypatch):
+def test_streaming_sw_score_kernels(qlen, lanes, narrow, ours, oracle, opal_opt):
     """The streaming SW score kernels (persistent workgroups, sequences handed out by a device counter and separated by
     two separator columns), forced for every lanes-per-sequence value and both profile widths; once more with a single
     workgroup, so that every slot works through many sequences."""
     from opal_amd.score_matrix import blosum50
     q, db = _stream_db(qlen)
     m = blosum50()[1]
-    monkeypatch.setenv("OPAL_HIP_STREAM", "1")
-    monkeypatch.setenv("OPAL_HIP_LANES_PER_SEQ", lanes)
-    monkeypatch.setenv("OPAL_HIP_NARROW", narrow)
+    opal_opt.set("OPAL_HIP_STREAM", "1")
+    opal_opt.set("OPAL_HIP_LANES_PER_SEQ", lanes)
+    opal_opt.set("OPAL_HIP_NARROW", narrow)
     for blocks in ("", "1"):
         if blocks:
-            monkeypatch.setenv("OPAL_HIP_STREAM_BLOCKS", blocks)
+            opal_opt.set("OPAL_HIP_STREAM_BLOCKS", blocks)
         for go, ge in ((11, 1), (3, 1)):
             got = ours.search(q, db, go, ge, m, 0, MODES["SW"])[:4]
             want = oracle.search(q, db, go, ge, m, 0, MODES["SW"])
@@ -521,7 +521,7 @@ def test_streaming_sw_score_kernels(qlen, lanes, narrow, ours, oracle, monkeypat
 
 @pytest.mark.parametrize("qlen,geometry", [(300, "16,16"), (700, "16,16"), (1000, "32,16"), (1290, "16,40"), (2100, "64,16"), (2000, "32,23"),
                                            (3000, None), (5200, None)])
-def test_streaming_sw_row_chunks(qlen, geometry, ours, oracle, monkeypatch):
+def test_streaming_sw_row_chunks(qlen, geometry, ours, oracle, opal_opt):
     """Queries beyond one wave stream through one launch per row chunk, the chunk's bottom row (H and F, one word per column)
     going through HBM: forced on shorter queries with small chunks (2 to 5 passes, a partial first chunk), and the natural
     case; once more with a single workgroup, so that every slot carries many sequences across every chunk boundary."""
@@ -529,13 +529,13 @@ def test_streaming_sw_row_chunks(qlen, geometry, ours, oracle, monkeypatch):
     q, db = _stream_db(qlen, n=300 if qlen > 2500 else 500)
     m = blosum50()[1]
     if geometry:
-        monkeypatch.setenv("OPAL_HIP_STREAM_CHUNKS", geometry)
+        opal_opt.set("OPAL_HIP_STREAM_CHUNKS", geometry)
     else:
-        monkeypatch.setenv("OPAL_HIP_STREAM", "1")
+        opal_opt.set("OPAL_HIP_STREAM", "1")
     cnt = (C.c_longlong * 9)()
     for blocks in ("", "1"):
         if blocks:
-            monkeypatch.setenv("OPAL_HIP_STREAM_BLOCKS", blocks)
+            opal_opt.set("OPAL_HIP_STREAM_BLOCKS", blocks)
         for go, ge in ((11, 1), (3, 1)):
             ours.lib.opalx_counters(cnt, 9)
             before = (cnt[0], cnt[4])
@@ -550,10 +550,10 @@ def test_streaming_sw_row_chunks(qlen, geometry, ours, oracle, monkeypatch):
             _check(got, oracle.search(q, db, go, ge, m, 1, MODES["SW"]), "SW", f"stream chunks + end q{qlen} {geometry} gaps {go}/{ge} blocks={blocks or 'auto'}")
 
 
-def test_streaming_row_chunks_saturated_scores(ours, oracle, monkeypatch):
+def test_streaming_row_chunks_saturated_scores(ours, oracle, opal_opt):
     """Scores that reach the 16-bit limit in the first, a middle or the last chunk are listed for the 32-bit re-run exactly
     once and come back exact; the others keep the maximum over the chunks."""
-    monkeypatch.setenv("OPAL_HIP_STREAM_CHUNKS", "16,20")
+    opal_opt.set("OPAL_HIP_STREAM_CHUNKS", "16,20")
     rng = np.random.RandomState(15)
     q = rng.randint(0, 4, size=1400).astype(np.uint8)
     m = cases.simple_matrix(4, 60, -40)
@@ -577,7 +577,7 @@ def test_streaming_row_chunks_saturated_scores(ours, oracle, monkeypatch):
 
 @pytest.mark.parametrize("mode", ["NW", "HW", "OV"])
 @pytest.mark.parametrize("qlen,geometry", [(1000, "16,24"), (1700, "32,24"), (2000, "16,37"), (3000, None), (4100, None)])
-def test_streaming_global_row_chunks(mode, qlen, geometry, ours, oracle, monkeypatch):
+def test_streaming_global_row_chunks(mode, qlen, geometry, ours, oracle, opal_opt):
     """NW/HW/OV queries beyond one wave stream their row chunks too: the boundary row goes through HBM as true values and
     changes skewed frame on the way (NW: the last chunk is the partial one, HW/OV: the first; OV's last-column maximum
     travels from chunk to chunk). The sequences that need 32 bits or cannot be skewed (a 5000-residue one, one beyond
@@ -587,12 +587,12 @@ def test_streaming_global_row_chunks(mode, qlen, geometry, ours, oracle, monkeyp
     q, db = _stream_db(qlen, n=300)
     m = blosum50()[1]
     if geometry:
-        monkeypatch.setenv("OPAL_HIP_STREAM_CHUNKS", geometry)
-    monkeypatch.setenv("OPAL_HIP_STREAM", "1")  # (a small database: its few long sequences hold more than the share the scheduler allows)
+        opal_opt.set("OPAL_HIP_STREAM_CHUNKS", geometry)
+    opal_opt.set("OPAL_HIP_STREAM", "1")  # (a small database: its few long sequences hold more than the share the scheduler allows)
     cnt = (C.c_longlong * 9)()
     for blocks in ("", "1"):
         if blocks:
-            monkeypatch.setenv("OPAL_HIP_STREAM_BLOCKS", blocks)
+            opal_opt.set("OPAL_HIP_STREAM_BLOCKS", blocks)
         for go, ge in ((11, 1), (3, 1)):
             ours.lib.opalx_counters(cnt, 9)
             before = (cnt[1], cnt[4])
@@ -606,17 +606,17 @@ def test_streaming_global_row_chunks(mode, qlen, geometry, ours, oracle, monkeyp
 
 
 @pytest.mark.parametrize("qlen,lanes,head", [(100, "4", "50"), (300, "8", "64"), (513, "16", "37"), (560, "16", "128")])
-def test_streaming_with_a_head_on_the_class_body(qlen, lanes, head, ours, oracle, monkeypatch):
+def test_streaming_with_a_head_on_the_class_body(qlen, lanes, head, ours, oracle, opal_opt):
     """A long-tailed database: the longest sequences run on the class body (4 x the lanes) as the first workgroups of the
     streaming launch, the rest streams behind them -- forced here with a head of a given size (the 36 000-residue, the
     5000-residue sequence and the near copies of the query are in it), score and end locations, 16-bit overflows included."""
     from opal_amd.score_matrix import blosum50
     q, db = _stream_db(qlen)
     m = blosum50()[1]
-    monkeypatch.setenv("OPAL_HIP_STREAM", "1")
-    monkeypatch.setenv("OPAL_HIP_LANES_PER_SEQ", lanes)
-    monkeypatch.setenv("OPAL_HIP_NARROW", "17")
-    monkeypatch.setenv("OPAL_HIP_STREAM_HEAD_ITEMS", head)
+    opal_opt.set("OPAL_HIP_STREAM", "1")
+    opal_opt.set("OPAL_HIP_LANES_PER_SEQ", lanes)
+    opal_opt.set("OPAL_HIP_NARROW", "17")
+    opal_opt.set("OPAL_HIP_STREAM_HEAD_ITEMS", head)
     for go, ge in ((11, 1), (3, 1)):
         for st in (0, 1):
             got = ours.search(q, db, go, ge, m, st, MODES["SW"])[:4]
@@ -652,11 +652,11 @@ def test_streaming_is_what_long_queries_run_on(ours):
 
 
 @pytest.mark.parametrize("narrow", ["17", "18"])
-def test_streaming_saturated_scores_rerun(narrow, ours, oracle, monkeypatch):
+def test_streaming_saturated_scores_rerun(narrow, ours, oracle, opal_opt):
     """Scores at the 16-bit limit leave the streaming kernel through the re-run list (one atomic per sequence, written by
     the last lane of the slot) and come back from the 32-bit kernels; the others stay."""
-    monkeypatch.setenv("OPAL_HIP_STREAM", "1")
-    monkeypatch.setenv("OPAL_HIP_NARROW", narrow)
+    opal_opt.set("OPAL_HIP_STREAM", "1")
+    opal_opt.set("OPAL_HIP_NARROW", narrow)
     rng = np.random.RandomState(5)
     q = rng.randint(0, 4, size=1400).astype(np.uint8)
     m = cases.simple_matrix(4, 60, -40)
@@ -680,22 +680,22 @@ def test_streaming_saturated_scores_rerun(narrow, ours, oracle, monkeypatch):
 @pytest.mark.parametrize("mode", ["NW", "HW", "OV"])
 @pytest.mark.parametrize("qlen,lanes,narrow", [(100, "4", "17"), (290, "8", "17"), (513, "16", "17"), (1000, "32", "17"), (1200, "64", "17"),
                                                (1330, "64", "18"), (2000, "64", "18"), (2360, "64", "18")])
-def test_streaming_global_kernels(mode, qlen, lanes, narrow, ours, oracle, monkeypatch):
+def test_streaming_global_kernels(mode, qlen, lanes, narrow, ours, oracle, opal_opt):
     """NW/HW/OV as a stream of sequences (boundary column reloaded from LDS at every sequence start, diagonal-skewed
     arithmetic with a local step per sequence), forced for every lanes-per-sequence value and both profile widths, with
     end locations and score only; once more with a single workgroup."""
     from opal_amd.score_matrix import blosum50
     q, db = _stream_db(qlen)
     m = blosum50()[1]
-    monkeypatch.setenv("OPAL_HIP_STREAM", "1")
-    monkeypatch.setenv("OPAL_HIP_LANES_PER_SEQ", lanes)
-    monkeypatch.setenv("OPAL_HIP_NARROW", narrow)
+    opal_opt.set("OPAL_HIP_STREAM", "1")
+    opal_opt.set("OPAL_HIP_LANES_PER_SEQ", lanes)
+    opal_opt.set("OPAL_HIP_NARROW", narrow)
     count = ours.lib.opalx_stream_launch_count
     count.restype = C.c_longlong
     before = count()
     for blocks in ("", "1"):
         if blocks:
-            monkeypatch.setenv("OPAL_HIP_STREAM_BLOCKS", blocks)
+            opal_opt.set("OPAL_HIP_STREAM_BLOCKS", blocks)
         # (gaps 12/4: the 5000-residue sequence no longer fits the skewed arithmetic and runs on the unskewed class body inside
         # the streaming launch, for the longer queries also at the smaller extension penalties)
         for go, ge, st in ((11, 1, 1), (3, 1, 1), (3, 1, 0), (12, 4, 1)):
@@ -706,7 +706,7 @@ def test_streaming_global_kernels(mode, qlen, lanes, narrow, ours, oracle, monke
 
 @pytest.mark.parametrize("mode", ["SW", "NW", "HW", "OV"])
 @pytest.mark.parametrize("qlen,go,ge", [(60, 3, 1), (333, 11, 1), (333, 1, 1), (1000, 3, 1), (1700, 5, 2), (200, 0, 0), (200, 5, 0), (200, 1, 3)])
-def test_device_traceback_equals_host_traceback(mode, qlen, go, ge, ours, oracle, monkeypatch):
+def test_device_traceback_equals_host_traceback(mode, qlen, go, ge, ours, oracle, opal_opt):
     """The operations traced on the device (trace_kernel.hip: box DP with one flag byte per cell in HBM, walk kernel) equal
     the host traceback's, for every rows-per-lane shape of the kernel, cheap gaps (long indels), a flag budget so small
     that the work is cut into many batches and the largest boxes are left to the host; every alignment re-scores."""
@@ -717,14 +717,14 @@ def test_device_traceback_equals_host_traceback(mode, qlen, go, ge, ours, oracle
     q = synth.query(qlen, seed=9)
     db = [res[offs[i]:offs[i + 1]] for i in range(n)] + [q[5:qlen - 3].copy(), np.concatenate([q[: qlen // 2], q[qlen // 2 + 7:]])]
     m = blosum50()[1]
-    monkeypatch.setenv("OPAL_HIP_HOST_TRACEBACK", "1")
+    opal_opt.set("OPAL_HIP_HOST_TRACEBACK", "1")
     rc, s, eq, et, sset, (arr, _) = ours.search(q, db, go, ge, m, 2, MODES[mode])
     assert rc == 0
     sq, st, ops = ours.alignments(arr)
-    monkeypatch.delenv("OPAL_HIP_HOST_TRACEBACK")
+    opal_opt.unset("OPAL_HIP_HOST_TRACEBACK")
     for budget in ("", "300000"):
         if budget:
-            monkeypatch.setenv("OPAL_TRACEBACK_DEVICE_BYTES", budget)
+            opal_opt.set("OPAL_TRACEBACK_DEVICE_BYTES", budget)
         rc2, s2, eq2, et2, sset2, (arr2, _) = ours.search(q, db, go, ge, m, 2, MODES[mode])
         assert rc2 == 0
         sq2, st2, ops2 = ours.alignments(arr2)
@@ -746,11 +746,11 @@ def test_device_traceback_equals_host_traceback(mode, qlen, go, ge, ours, oracle
 
 
 @pytest.mark.parametrize("seed", range(8))
-def test_randomized_differential_streaming(seed, ours, oracle, monkeypatch):
+def test_randomized_differential_streaming(seed, ours, oracle, opal_opt):
     """The randomized shapes once more with the streaming kernels forced wherever a geometry exists (other alphabets and
     matrices than BLOSUM50, gap extension 0 or larger than the opening, queries from 1 to 2400 residues, every mode and
     search type, alignment searches included)."""
-    monkeypatch.setenv("OPAL_HIP_STREAM", "1")
+    opal_opt.set("OPAL_HIP_STREAM", "1")
     rng = np.random.RandomState(7000 + seed)
     for _ in range(5):
         A = int(rng.choice([2, 4, 5, 20, 24, 31]))
@@ -773,9 +773,9 @@ def test_randomized_differential_streaming(seed, ours, oracle, monkeypatch):
         mode = str(rng.choice(["SW", "NW", "HW", "OV"])); st = int(rng.randint(0, 2))
         lanes = str(rng.choice(["", "", "16", "32", "64"]))
         if lanes:
-            monkeypatch.setenv("OPAL_HIP_LANES_PER_SEQ", lanes)
+            opal_opt.set("OPAL_HIP_LANES_PER_SEQ", lanes)
         else:
-            monkeypatch.delenv("OPAL_HIP_LANES_PER_SEQ", raising=False)
+            opal_opt.unset("OPAL_HIP_LANES_PER_SEQ")
         got = ours.search(q, db, go, ge, m, st, MODES[mode], int(rng.randint(0, 2)))[:4]
         want = oracle.search(q, db, go, ge, m, st, MODES[mode])
         what = f"stream seed {seed}: A={A} Q={qlen} n={n} gaps {go}/{ge} {mode} st={st} lanes={lanes or 'auto'}"
@@ -784,7 +784,7 @@ def test_randomized_differential_streaming(seed, ours, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("mode", ["SW", "OV"])
-def test_alignment_search_sharded_over_devices(mode, ours, monkeypatch):
+def test_alignment_search_sharded_over_devices(mode, ours, opal_opt):
     """OPAL_SEARCH_ALIGNMENT with the call sharded over several devices ("0,0": two contexts on this box's one GPU): the
     operations traced per shard land in the right result structs -- same start cells and operation strings as unsharded."""
     from opal_amd import synth
@@ -796,7 +796,7 @@ def test_alignment_search_sharded_over_devices(mode, ours, monkeypatch):
     rc, s, eq, et, sset, (arr, _) = ours.search(q, db, 3, 1, m, 2, MODES[mode])
     assert rc == 0
     sq, st, ops = ours.alignments(arr)
-    monkeypatch.setenv("OPAL_HIP_DEVICES", "0,0")
+    opal_opt.set("OPAL_HIP_DEVICES", "0,0")
     rc2, s2, eq2, et2, sset2, (arr2, _) = ours.search(q, db, 3, 1, m, 2, MODES[mode])
     assert rc2 == 0
     sq2, st2, ops2 = ours.alignments(arr2)
@@ -808,13 +808,13 @@ def test_alignment_search_sharded_over_devices(mode, ours, monkeypatch):
     assert ops == ops2
 
 
-def test_reentrant_streaming_and_alignment_from_host_threads(ours, oracle, monkeypatch):
+def test_reentrant_streaming_and_alignment_from_host_threads(ours, oracle, opal_opt):
     """Four host threads at once, every one on the streaming kernels (persistent workgroups of different searches share
     the GPU: each must still run to completion) or in an alignment search with the traceback on the device."""
     import threading
     from opal_amd import synth
     from opal_amd.score_matrix import blosum50
-    monkeypatch.setenv("OPAL_HIP_STREAM", "1")
+    opal_opt.set("OPAL_HIP_STREAM", "1")
     m = blosum50()[1]
     jobs = []
     for t in range(4):

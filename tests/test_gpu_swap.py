@@ -58,14 +58,14 @@ def _database(q, rows, seed):
 
 @pytest.mark.parametrize("rows", ["40", "24", "16", "8"])
 @pytest.mark.parametrize("qlen", [1, 7, 64, 110, 195, 320, 700])
-def test_swapped_kernel_vs_oracle(qlen, rows, ours, oracle, monkeypatch):
+def test_swapped_kernel_vs_oracle(qlen, rows, ours, oracle, opal_opt):
     from opal_amd import synth
     from opal_amd.score_matrix import blosum50
     q = synth.query(qlen, seed=qlen)
     db = _database(q, int(rows), seed=qlen + int(rows))
     m = blosum50()[1]
-    monkeypatch.setenv("OPAL_HIP_SWAP", "20")  # the 20 longest: the 14 long ones and a few ordinary ones (single partial chunk)
-    monkeypatch.setenv("OPAL_HIP_SWAP_ROWS", rows)
+    opal_opt.set("OPAL_HIP_SWAP", "20")  # the 20 longest: the 14 long ones and a few ordinary ones (single partial chunk)
+    opal_opt.set("OPAL_HIP_SWAP_ROWS", rows)
     for go, ge in ((11, 1), (3, 1), (0, 0), (5, 5)):
         before = _swapped(ours)
         got = ours.search(q, db, go, ge, m, 0, MODES["SW"])[:4]
@@ -76,21 +76,21 @@ def test_swapped_kernel_vs_oracle(qlen, rows, ours, oracle, monkeypatch):
         assert (got[2] == -1).all() and (got[3] == -1).all()
 
 
-def test_swapped_kernel_saturated_scores_rerun(ours, oracle, monkeypatch):
+def test_swapped_kernel_saturated_scores_rerun(ours, oracle, opal_opt):
     """Scores at the 16-bit limit leave the swapped kernel through the re-run list and come back from the 32-bit rung."""
     from opal_amd import synth
     from opal_amd.score_matrix import blosum50
     q = synth.query(200, seed=3)
     db = _database(q, 40, seed=77)
     m = blosum50()[1] * 60
-    monkeypatch.setenv("OPAL_HIP_SWAP", "20")
+    opal_opt.set("OPAL_HIP_SWAP", "20")
     got = ours.search(q, db, 660, 60, m, 0, MODES["SW"])[:4]
     want = oracle.search(q, db, 660, 60, m, 0, MODES["SW"])
     assert got[0] == want[0] == 0 and (want[1] > 32767).sum() >= 3
     np.testing.assert_array_equal(got[1], want[1])
 
 
-def test_swapped_kernel_is_what_a_long_tail_runs_on(ours, oracle, monkeypatch):
+def test_swapped_kernel_is_what_a_long_tail_runs_on(ours, oracle, opal_opt):
     """Without forcing: a short query against a database with a few very long targets sends exactly those to the swapped
     kernel (planner.cpp plan_swap); with end locations, a longer query or no tail it stays away."""
     from opal_amd import synth
@@ -100,7 +100,7 @@ def test_swapped_kernel_is_what_a_long_tail_runs_on(ours, oracle, monkeypatch):
     tail = [synth.query(L, seed=L) for L in (35213, 30000, 22000, 12000)]
     m = blosum50()[1]
     q = synth.query(110, seed=7)
-    monkeypatch.delenv("OPAL_HIP_SWAP", raising=False)
+    opal_opt.unset("OPAL_HIP_SWAP")
     short = [s[:1000] for s in db]  # (no tail at all: nothing outlasts the search on the chain by enough to move)
     for st, seqs, expect in ((0, db + tail, True), (1, db + tail, False), (0, short, False)):
         before = _swapped(ours)

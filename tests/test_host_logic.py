@@ -32,6 +32,22 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} is declared in include/ but not exported by libopal.so"
 
 
+def test_library_exports_nothing_but_its_c_interface():
+    """a drop-in library. Its dynamic symbol table holds the five functions of opal.h and the additive C
+    entries of opal_hip.h (opalx_*, opal_hip_*) -- no C++ internals of the host scheduler, no kernel launch stubs
+    (opal_amd/csrc/libopal.map): nothing that could interpose with the application it is linked into."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", LIB], capture_output=True, text=True, check=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    five = {"opalSearchDatabase", "opalSearchDatabaseCharSW", "opalInitSearchResult", "opalSearchResultIsEmpty", "opalSearchResultSetScore"}
+    assert five <= set(names)
+    stray = [n for n in names if n not in five and not n.startswith("opalx_") and not n.startswith("opal_hip_")]
+    assert not stray, stray[:10]
+    declared = set(_declared_functions("opal.h") + _declared_functions("opal_hip.h"))
+    undeclared = [n for n in names if n not in declared]
+    assert not undeclared, f"exported but not declared in include/: {undeclared[:10]}"
+
+
 def test_struct_layout_matches_reference_abi():
     # reference src/opal.h:47-74: 40 bytes, offsets 0/4/8/12/16/20/24/32
     assert C.sizeof(OpalSearchResult) == 40
@@ -262,14 +278,45 @@ def test_host_code_sanitized():
     assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
 
 
-def test_streaming_plan_of_the_scheduler(monkeypatch):
+def test_options_are_typed_and_validated(opal_opt):
+    """opalx_set_option (options.cpp): unknown names and values that do not parse are refused and change nothing; the
+    environment is not read again after the first use (a later setenv has no effect)."""
+    L = C.CDLL(LIB)
+    f = L.opalx_set_option
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_char_p]
+    assert f(b"OPAL_HIP_NO_SUCH_OPTION", b"1") == 1
+    for name, bad in ((b"OPAL_HIP_LANES_PER_SEQ", b"3"), (b"OPAL_HIP_NARROW", b"19"), (b"OPAL_HIP_STREAM", b"yes"), (b"OPAL_HIP_STREAM_CHUNKS", b"16"),
+                      (b"OPAL_HIP_STREAM_CHUNKS", b"16,41"), (b"OPAL_HIP_DEVICES", b"0;1"), (b"OPAL_HIP_TAIL_FRACTION", b"-1"), (b"OPAL_HIP_SWAP_ROWS", b"12"),
+                      (b"OPAL_HIP_SLICES", b"1,,2"), (b"OPAL_HIP_FORCE_WIDTH", b"16"), (b"OPAL_HOST_THREADS", b"0")):
+        assert f(name, bad) == 2, (name, bad)
+    for name, good in ((b"OPAL_HIP_LANES_PER_SEQ", b"16"), (b"OPAL_HIP_NARROW", b"18"), (b"OPAL_HIP_STREAM", b"1"), (b"OPAL_HIP_STREAM_CHUNKS", b"16,20"),
+                       (b"OPAL_HIP_DEVICES", b"all"), (b"OPAL_HIP_DEVICES", b"0,0"), (b"OPAL_HIP_TAIL_FRACTION", b"0.5"), (b"OPAL_HIP_SLICES", b"1,3,5")):
+        assert f(name, good) == 0, (name, good)
+        assert f(name, None) == 0
+    # the streaming plan follows the option, not the environment of the moment
+    L.opalx_debug_plan_stream.restype = C.c_int
+    L.opalx_debug_plan_stream.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    out = (C.c_int * 4)()
+    os.environ["OPAL_HIP_STREAM"] = "1"
+    try:
+        L.opalx_debug_plan_stream(300, 24, 3, 0, 100000 * 350, 3776, 100000, out)
+        assert tuple(out) == (0, 0, 0, 0), "the environment was read again"
+    finally:
+        del os.environ["OPAL_HIP_STREAM"]
+    opal_opt.set("OPAL_HIP_STREAM", "1")
+    L.opalx_debug_plan_stream(300, 24, 3, 0, 100000 * 350, 3776, 100000, out)
+    assert out[0] == 17 and out[1] >= 1
+
+
+def test_streaming_plan_of_the_scheduler(opal_opt):
     """planner.cpp::plan_stream on the host alone: which searches stream (and on what geometry), which stay on the class kernels."""
     import ctypes as C
     L = C.CDLL(LIB)
     L.opalx_debug_plan_stream.restype = C.c_int
     L.opalx_debug_plan_stream.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_int)]
     for e in ("OPAL_HIP_STREAM", "OPAL_HIP_LANES_PER_SEQ", "OPAL_HIP_NARROW", "OPAL_HIP_STREAM_CHUNKS", "OPAL_HIP_NO_STREAM_CHUNKS"):
-        monkeypatch.delenv(e, raising=False)
+        opal_opt.unset(e)
     SW, NW = 3, 0
     def plan(q, mode=SW, end=0, nseq=100000, mean=350, longest=3776, a=24):
         out = (C.c_int * 4)()
