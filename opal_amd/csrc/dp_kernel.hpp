@@ -187,6 +187,27 @@ template <> struct Vec<17> {
     static __device__ __forceinline__ reg subs(reg a, reg b) { reg r; asm("v_sub_u16_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
     static __device__ __forceinline__ reg subu(reg a, reg b) { reg r; asm("v_sub_u16_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b)); return r; }
     static __device__ __forceinline__ reg maxs(reg a, reg b) { reg r; asm("v_max_i16_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+    // the same with a wave-uniform second operand straight from an SGPR (no per-step v_mov to make a VGPR copy of it)
+    static __device__ __forceinline__ reg adds_s(reg a, unsigned s) { reg r; asm("v_add_u16_e32 %0, %2, %1" : "=v"(r) : "v"(a), "s"(s)); return r; }
+    static __device__ __forceinline__ reg subs_s(reg a, unsigned s) { reg r; asm("v_subrev_u16_e32 %0, %2, %1" : "=v"(r) : "v"(a), "s"(s)); return r; }  // a - s
+    // HW / OV, skewed frame: the running last-row maximum bf and its first column. A column c < limit whose last-row value h
+    // is STRICTLY larger takes over (first column wins, opal.cpp:824-834); bf then moves into the next step's frame (+ Ge).
+    // One statement: 16-bit compare (hipcc shifts both sides up and compares 32 bits), the gap as an SGPR operand, and the two
+    // wait states gfx950 wants between a compare and the select that reads its mask.
+    static __device__ __forceinline__ void track_best(reg h, reg& bf, int& col, int c, unsigned limit, unsigned Rs) {
+        unsigned long long m;
+        reg cand;
+        asm("v_cmp_lt_u32_e64 %[m], %[c], %[lim]\n\t"
+            "s_nop 1\n\t"
+            "v_cndmask_b32_e64 %[cand], %[bf], %[h], %[m]\n\t"   // (outside the sequence: the running best itself, which is not > itself)
+            "v_cmp_gt_i16_e64 %[m], %[cand], %[bf]\n\t"
+            "s_nop 1\n\t"
+            "v_cndmask_b32_e64 %[col], %[col], %[c], %[m]\n\t"
+            "v_cndmask_b32_e64 %[bf], %[bf], %[cand], %[m]\n\t"
+            "v_add_u16_e32 %[bf], %[rs], %[bf]"
+            : [m] "=&s"(m), [cand] "=&v"(cand), [col] "+v"(col), [bf] "+v"(bf)
+            : [c] "v"(c), [lim] "v"(limit), [h] "v"(h), [rs] "s"(Rs));
+    }
     static __device__ __forceinline__ int half(reg a, int) { return (int)(short)(a & 0xffffu); }
     static __device__ __forceinline__ bool same(reg a, reg b, int) { return (unsigned short)a == (unsigned short)b; }  // v_cmp_eq_u16
     static __device__ __forceinline__ int clampv(long long v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : (int)v); }
@@ -403,7 +424,29 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
     // Shapes with FEW rows per lane (S <= 12: the 32- and 64-lane classes of the longest sequences, whose lone waves are the
     // critical path of a search with a real length tail -- a 35 213-residue target at 2 rows per lane is 35 000 steps of
     // pure latency) do it in every mode: with so few rows the LDS round trip is most of a step.
-    constexpr bool PF_TOP = PLAIN && (MODE == MODE_NW || S <= 12);  // (OV with it: 1.1 % slower since round 3's leaner last-column code)
+#ifndef OPAL_PF_LATE_MASK
+// bit MODE = that mode's tall shapes prefetch late. SW: C2 6 940 -> 7 010 GCUPS, SW + end 6 160 -> 6 280 (same box, interleaved:
+// profiles/r04_ab_prefetch_split.txt); NW / HW / OV (which need SPLIT for it) gain nothing: their row blocks are too short to
+// cover the round trip either way, and they are bound by instruction count and clock, not by LDS latency.
+#define OPAL_PF_LATE_MASK 9
+#endif
+#ifndef OPAL_SPLIT_FILL
+#define OPAL_SPLIT_FILL 1    // NW/HW/OV run their first G-1 steps in a loop of their own (with the round-4 frame: HW +3 %, OV +4 %, NW +3 % with the late prefetch)
+#endif
+    // NW/HW/OV: a lane must not touch its boundary column before its first column (step k), so every step tests c >= 0 and
+    // runs under an execution mask -- needed during the first G-1 steps of a sequence only. SPLIT: those steps get a loop of
+    // their own (the same code with the test), the rest runs unmasked.
+    constexpr bool SPLIT = SKEW && OPAL_SPLIT_FILL != 0;  // (the skewed single-launch kernels: the others have no register left for the second loop's state)
+    constexpr bool PF_LATE_WANTED = WIDTH == 17 && S > 12 && ((OPAL_PF_LATE_MASK >> MODE) & 1) != 0 && (MODE == MODE_SW || SPLIT);  // (width 18 at 40 rows has no register left for it)
+#ifndef OPAL_NW_PF_TOP
+#define OPAL_NW_PF_TOP 0  // (round 3: NW prefetched at the top of the step; with SPLIT the late prefetch measures 3 % faster)
+#endif
+    constexpr bool PF_TOP = PLAIN && !PF_LATE_WANTED && ((MODE == MODE_NW && (OPAL_NW_PF_TOP != 0 || !SPLIT)) || S <= 12);  // (OV with it: 1.1 % slower since round 3's leaner last-column code)
+    // PF_LATE: the same read, issued as late as it can be -- in place of the (absent) block prefetch of the LAST row block,
+    // into the registers that prefetch would have used, behind the address update of the coming step: the four registers are
+    // live across the step's fixed work only (hand-off, boundary, column test), not across the row blocks, and the first row
+    // block of a step no longer waits out an LDS round trip.
+    constexpr bool PF_LATE = PF_LATE_WANTED;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int log2G = cls.log2G;
@@ -514,7 +557,18 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
     const reg Qv = V::splat(Go), Rv = V::splat(Ge);
     // the same as wave-uniform 16-bit patterns for the asm row blocks (SGPR operands)
     const unsigned Qs = (unsigned)Go & 0xffffu, Rs = (unsigned)Ge & 0xffffu, GQs = (unsigned)(Go - Ge) & 0xffffu;
-    const reg SR1v = V::splat((S - 1) * Ge);     // SKEW: frame change between the last register of a lane and register 0 of the next
+    // SKEW: X' = X + (rho + c) * Ge with rho = k * S + j, the row's position among the G * S register rows of the slot (round 4;
+    // before: (j + s), which differs from lane to lane by (S - 1) * Ge and cost two subtractions per step at the hand-off from
+    // lane k-1 to lane k). The code below still writes its frame terms as (j + s) = (j + c + k) and adds kf = k * (S - 1) * Ge where
+    // a value enters or leaves the frame -- outside the column loop only.
+    const reg SR1v = V::splat((S - 1) * Ge);     // SKEW: from the frame of a lane's register 0 to that of its last register
+    const int kf = SKEW ? k * (S - 1) * Ge : 0;
+    // (inside the column loop kf is needed in rare blocks only -- last columns, final cells: made again there instead of kept in a register)
+    auto kf_now = [&]() -> int {
+        int kk = k;
+        asm volatile("" : "+v"(kk));
+        return SKEW ? kk * (S - 1) * Ge : 0;
+    };
     const int r0 = q0 + k * S - padTop;  // query row held in register 0 (negative: virtual rows)
     reg Hp[S], En[S];               // H[r][c-1] and E[r][c] for my rows
 #pragma unroll
@@ -527,8 +581,8 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
             En[j] = V::splat(V::clampv(hb - Go));
         }
         if (SKEW) {  // my first column runs at step k: H(j) is read as the diagonal of step k, E(j) at step k
-            Hp[j] = V::adds(Hp[j], V::splat((j + k - 1) * Ge));
-            En[j] = V::adds(En[j], V::splat((j + k) * Ge));
+            Hp[j] = V::adds(Hp[j], V::splat((j + k - 1) * Ge + kf));
+            En[j] = V::adds(En[j], V::splat((j + k) * Ge + kf));
         }
     }
     // what the lane below reads: H and next-row F of my last row. Before my first column it must be
@@ -536,7 +590,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
     reg outH = 0, outF = 0;
     if ((MODE == MODE_NW || MODE == MODE_HW) && r0 + S - 1 >= 0)
         outH = V::splat(V::clampv(-(long long)Go - (long long)(r0 + S - 1) * Ge));
-    if (SKEW) outH = V::adds(outH, V::splat((S - 1 + k - 1) * Ge));  // as if produced at the end of step k-1
+    if (SKEW) outH = V::adds(outH, V::splat((S - 1 + k - 1) * Ge + kf));  // as if produced at the end of step k-1
     reg diagIn = SKEW ? V::splat(-2 * Ge) : 0;  // H[r0-1][c-1]; H[-1][-1] = 0 in every mode (frame (-1)+(-1) when skewed)
     if (hasPrev && (MODE == MODE_NW || MODE == MODE_HW))  // H[q0-1][-1] for the first lane of a lower chunk
         diagIn = V::splat(V::clampv(-(long long)Go - (long long)(q0 - 1) * Ge));
@@ -612,14 +666,18 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
         }
     };
     int4 pfirst = make_int4(0, 0, 0, 0);  // PF_TOP: first row block of the profile column of the coming step
-    if constexpr (PF_TOP) { advance(0); pfirst = lds_ld16(offv[0]); }
+    if constexpr (PF_TOP || (PF_LATE && !SPLIT)) { advance(0); pfirst = lds_ld16(offv[0]); }
 
     reg bestF = V::splat(-32768);            // SKEW, HW/OV: last-row maximum so far, in the skewed frame of the step at hand
     int slotMax = 0;                         // SW end location: slot-wide running maximum (see the scan filter)
     int topHv = V::clampv(-(long long)Go);  // NW: H[-1][0]
     reg sRv = 0;                             // SKEW: s*Ge as a 16-bit value
-    for (int s = 0; s < nsteps; s++) {
-        if constexpr (!PF_TOP) advance(s);
+    // One column step. MASKED: lanes before their first column sit the step out (NW/HW/OV; SW needs no test: its state is
+    // all zeros until real columns arrive).
+    auto column_step = [&](const int s, auto maskedc) {
+        constexpr bool MASKED = decltype(maskedc)::value;
+        constexpr bool LATE = PF_LATE && !MASKED;
+        if constexpr (!PF_TOP && !LATE) advance(s);
         unsigned offc[NH];  // this step's profile address
 #pragma unroll
         for (int h = 0; h < NH; h++) offc[h] = offv[h];
@@ -642,14 +700,13 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
         }
         reg inH = (reg)shr1((unsigned)outH);
         reg inF = (reg)shr1((unsigned)outF);
-        if (SKEW) {
-            inH = V::subs(inH, SR1v);
-            inF = V::subs(inF, SR1v);
+        if constexpr (SKEW) {
+            // (lane k-1's outputs are in lane k's frame already: rows rho - 1 and rho, same column)
             if (k == 0) {
                 // top boundary in my frame: H[-1][c] + (s-1)*Ge (read as a diagonal one step later) and
                 // F[0][c] + s*Ge = H[-1][c] - Go + s*Ge; NW: H[-1][c] = -Go - s*Ge, HW/OV: 0
                 if (MODE == MODE_NW) { inH = V::splat(-Go - Ge); inF = V::splat(-2 * Go); }
-                else { inH = V::subs(sRv, Rv); inF = V::subs(sRv, Qv); }
+                else { inH = Vec<17>::subs_s(sRv, Rs); inF = Vec<17>::subs_s(sRv, Qs); }
             }
         } else if (MODE == MODE_SW && !MULTI) {
             // top boundary of local alignment: H = 0 and F input = 0 for lane 0 of every slot (two selects, no branch)
@@ -666,7 +723,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
         }
         const int c = s - k;  // my column
 
-        if (MODE == MODE_SW || c >= 0) {
+        if (MODE == MODE_SW || !MASKED || c >= 0) {
             reg diag = diagIn;
             reg f = inF;
             reg h = 0;
@@ -682,7 +739,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
                 constexpr int KIND = MODE == MODE_SW ? ROWS_SW : (SKEW ? ROWS_SKEW : ROWS_GLOBAL);
                 constexpr int NBLK = SPAD / RB;   // LDS reads per column (RB rows each: 4 with 4-byte entries, 8 with 2-byte ones)
                 int4 pc = pcur;
-                if constexpr (!PF_TOP) pc = lds_ld16(offc[0]);
+                if constexpr (!PF_TOP && !LATE) pc = lds_ld16(offc[0]);
                 reg d = V::adds(diag, (reg)pc.x), t = 0;  // (a 16-bit add reads the low half only)
                 // (two row blocks of profile entries in flight instead of one were tried for the 6-instruction kernels in
                 // round 3: NW unchanged, HW 2.8 % slower)
@@ -690,6 +747,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
                     constexpr int rb = decltype(rbc)::value;
                     int4 pn = pc;
                     if constexpr (rb + 1 < NBLK) pn = lds_ld16(offc[0] + (rb + 1) * RB * ES);
+                    else if constexpr (LATE) { advance(s + 1); pn = lds_ld16(offv[0]); }  // every read of this step has been issued
                     reg Pv[RB + 1];  // profile values of this block's rows, then of the next block's first row
                     if constexpr (ES == 4) {
                         Pv[0] = (reg)pc.x; Pv[1] = (reg)pc.y; Pv[2] = (reg)pc.z; Pv[3] = (reg)pc.w;
@@ -710,6 +768,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
                     });
                     pc = pn;
                 });
+                if constexpr (LATE) pfirst = pc;
                 h = Hp[S - 1];
                 if constexpr (SWEND) cm = V::maxs(ch[0], ch[1]);
             } else {
@@ -828,7 +887,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
                     const reg hl = SelectRow<reg, S, 0, S>::get(Hp, jLast);
 #pragma unroll
                     for (int hh = 0; hh < NH; hh++)
-                        if (c == len[hh] - 1) best[hh] = V::half(SKEW ? V::subs(hl, V::splat((jLast + s) * Ge)) : hl, hh);
+                        if (c == len[hh] - 1) best[hh] = V::half(SKEW ? V::subs(hl, V::splat((jLast + s) * Ge + kf_now())) : hl, hh);
                 }
             }
             if ((MODE == MODE_HW || MODE == MODE_OV) && !SKEW && k == kLast && !hasNext) {
@@ -873,10 +932,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
             // last-column maximum below, which includes row Q-1. (Columns before my first one and beyond the sequence fail
             // the one unsigned comparison.)
             const unsigned limit = (unsigned)(MODE == MODE_OV ? len[0] - 1 : len[0]);
-            const bool better = (unsigned)c < limit && (short)outH > (short)bestF;  // strict >: first column wins (opal.cpp:824-834)
-            bestF = better ? outH : bestF;
-            bestCol[0] = better ? c : bestCol[0];
-            bestF = V::adds(bestF, Rv);
+            Vec<17>::track_best(outH, bestF, bestCol[0], c, limit, Rs);
         }
         if constexpr (MODE == MODE_OV && SKEW) {
             // The last column of a sequence (single launch, one sequence per lane): lane k reaches it one step after lane
@@ -893,7 +949,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
                     if (jlo == 0 && jhi == S) {  // all my rows are query rows: the value first, in the skewed frame
                         reg bf = Hp[S - 1];
                         if constexpr (S > 1) OvColumnMax<V, S, S - 2>::run(Hp, Rv, bf);
-                        const unsigned bv = (unsigned)(V::half(V::subs(bf, V::splat(s * Ge)), 0) + 32768);
+                        const unsigned bv = (unsigned)(V::half(V::subs(bf, V::splat(s * Ge + kf_now())), 0) + 32768);
                         if (bv > (inKey >> 16)) {  // (rare) ... then the smallest row holding it
                             reg t = V::adds(bf, SR1v);
                             int bj = 0;
@@ -902,9 +958,10 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
                         }
                     } else {
                         int bv = INT_MIN, bj = -1;
+                        const int kfl = kf_now();
 #pragma unroll
                         for (int j = S - 1; j >= 0; j--) {
-                            const int v = V::half(V::subs(Hp[j], V::splat((j + s) * Ge)), 0);
+                            const int v = V::half(V::subs(Hp[j], V::splat((j + s) * Ge + kfl)), 0);
                             if (j >= jlo && j < jhi && v >= bv) { bv = v; bj = j; }
                             asm volatile("" : "+v"(bv), "+v"(bj));
                         }
@@ -915,7 +972,17 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
             }
         }
         diagIn = inH;
-        if (SKEW) sRv = V::adds(sRv, Rv);
+        if constexpr (SKEW) sRv = Vec<17>::adds_s(sRv, Rs);
+    };
+    if constexpr (SPLIT) {
+        const int nfill = nsteps < G - 1 ? nsteps : G - 1;
+        for (int s = 0; s < nfill; s++) column_step(s, std::true_type{});
+        if (nfill < nsteps) {
+            if constexpr (PF_LATE) { advance(nfill); pfirst = lds_ld16(offv[0]); }
+            for (int s = nfill; s < nsteps; s++) column_step(s, std::false_type{});
+        }
+    } else {
+        for (int s = 0; s < nsteps; s++) column_step(s, std::integral_constant<bool, MODE != MODE_SW>{});
     }
 
     // ---- results
@@ -976,7 +1043,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
     }
     if (MODE != MODE_SW) {
         if constexpr ((MODE == MODE_HW || MODE == MODE_OV) && SKEW) {  // out of the frame of the step after the last one
-            best[0] = bestCol[0] >= 0 ? V::half(V::subs(bestF, V::adds(sRv, SR1v)), 0) : INT_MIN;
+            best[0] = bestCol[0] >= 0 ? V::half(V::subs(bestF, V::adds(V::adds(sRv, SR1v), V::splat(kf_now()))), 0) : INT_MIN;
             prevBest[0] = best[0];  // (OV: the maximum over columns 0 .. L-2, see the loop)
         }
 #pragma unroll

@@ -120,7 +120,8 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
     // even its longest sequence stays inside the 16-bit range
     auto skew_ok = [&](int item) {
         const long long L0 = lenOf(item);
-        return std::min<long long>(c.Q, L0) * c.maxScore + (OPAL_HIP_MAX_ROWS + L0 + 64 + 4) * (long long)c.Ge < 32000;
+        // (frame: row position among the slot's G * S <= Q + 512 register rows + column, see dp_kernel.hpp)
+        return std::min<long long>(c.Q, L0) * c.maxScore + (c.Q + 512 + L0 + 64 + 4) * (long long)c.Ge < 32000;
     };
     const bool maySkew = width == 17 && c.mode != OPAL_MODE_SW && !work && !opts().noSkew;
     // One launch for all classes where a one-launch kernel exists (plain 16-bit, no re-run list): see dp_kernel.hpp.
