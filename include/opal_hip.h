@@ -361,6 +361,14 @@ void opalx_multi_destroy(OpalxMultiDb* mdb);
 int opalx_multi_search_device(OpalxMultiDb* mdb, const unsigned char* query, int query_length, int gap_open, int gap_ext,
                               const int* score_matrix, int alphabet_length, int search_type, int mode,
                               int* d_score, int* d_end_query, int* d_end_target, float* kernel_ms);
+/* The same without the wait, as opalx_search_device_async / opalx_db_wait for the single handle: up to OPALX_ASYNC_DEPTH - 1
+   searches may be queued (each into result buffers of its own); they run one after the other on every shard's stream, the
+   gather of one behind the root's permutation of the one before, with no host round trip between them. opalx_multi_wait
+   waits for the OLDEST one (first in, first out) and reports its kernel time (the longest over the shards). */
+int opalx_multi_search_device_async(OpalxMultiDb* mdb, const unsigned char* query, int query_length, int gap_open, int gap_ext,
+                                    const int* score_matrix, int alphabet_length, int search_type, int mode,
+                                    int* d_score, int* d_end_query, int* d_end_target);
+int opalx_multi_wait(OpalxMultiDb* mdb, float* kernel_ms);
 
 /*
  * Host traceback (no device work): for every result that holds a score and an end location, fill

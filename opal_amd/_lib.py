@@ -64,6 +64,11 @@ def lib():
         L.opalx_multi_search_device.restype = C.c_int
         L.opalx_multi_search_device.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_int, i32p, C.c_int, C.c_int, C.c_int,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+        L.opalx_multi_search_device_async.restype = C.c_int
+        L.opalx_multi_search_device_async.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_int, i32p, C.c_int, C.c_int, C.c_int,
+                                                      C.c_void_p, C.c_void_p, C.c_void_p]
+        L.opalx_multi_wait.restype = C.c_int
+        L.opalx_multi_wait.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.opalx_set_option.restype = C.c_int
         L.opalx_set_option.argtypes = [C.c_char_p, C.c_char_p]
         L.opalx_counters.restype = C.c_int

@@ -152,7 +152,7 @@ class PreparedDb:
         """opalx_search_device_async: enqueue the search and return (results are complete after wait()). Returns rc."""
         q = _u8(query)
         m = np.ascontiguousarray(score_matrix, dtype=np.int32)
-        self._keep = (q, m)  # (read by asynchronous copies until wait())
+        # (the library copies query and matrix into its pinned search header before the call returns: nothing to keep alive)
         return _lib.lib().opalx_search_device_async(self._h, q.ctypes.data_as(C.POINTER(C.c_ubyte)), len(q), int(gap_open), int(gap_ext),
                                                     m.ctypes.data_as(C.POINTER(C.c_int)), int(m.shape[0]), int(search_type), int(mode),
                                                     C.c_void_p(d_score), C.c_void_p(d_end_q or None), C.c_void_p(d_end_t or None))
@@ -227,4 +227,19 @@ class PreparedMultiDb:
         rc = _lib.lib().opalx_multi_search_device(self._h, q.ctypes.data_as(C.POINTER(C.c_ubyte)), len(q), int(gap_open), int(gap_ext),
                                                   m.ctypes.data_as(C.POINTER(C.c_int)), int(m.shape[0]), int(search_type), int(mode),
                                                   C.c_void_p(d_score), C.c_void_p(d_end_q or None), C.c_void_p(d_end_t or None), C.byref(ms))
+        return rc, ms.value
+
+    def search_device_async(self, query, gap_open, gap_ext, score_matrix, search_type, mode, d_score, d_end_q=0, d_end_t=0):
+        """opalx_multi_search_device_async: enqueue the search on every shard and the gather behind it (results are complete
+        after wait()). Up to three may be queued, each into result buffers of its own. Returns rc."""
+        q = _u8(query)
+        m = np.ascontiguousarray(score_matrix, dtype=np.int32)
+        return _lib.lib().opalx_multi_search_device_async(self._h, q.ctypes.data_as(C.POINTER(C.c_ubyte)), len(q), int(gap_open), int(gap_ext),
+                                                          m.ctypes.data_as(C.POINTER(C.c_int)), int(m.shape[0]), int(search_type), int(mode),
+                                                          C.c_void_p(d_score), C.c_void_p(d_end_q or None), C.c_void_p(d_end_t or None))
+
+    def wait(self):
+        """opalx_multi_wait: the OLDEST queued search (first in, first out). Returns (rc, kernel_ms = the longest over the shards)."""
+        ms = C.c_float(0)
+        rc = _lib.lib().opalx_multi_wait(self._h, C.byref(ms))
         return rc, ms.value

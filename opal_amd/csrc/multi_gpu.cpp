@@ -29,6 +29,80 @@ std::vector<int> call_devices() {
     return out;
 }
 
+// ------------------------------------------------------------------------------------ persistent per-slot workers
+namespace {
+struct SlotWorker {
+    std::mutex m;
+    std::condition_variable cv;
+    const std::function<void(size_t)>* fn = nullptr;  // the job at hand (nullptr: none)
+    std::atomic<int> posted{0};                        // (polled for a while after a job before the worker blocks)
+    size_t slot = 0;
+    std::atomic<int>* left = nullptr;
+    std::mutex* doneM = nullptr;
+    std::condition_variable* doneCv = nullptr;
+    void loop() {
+        for (;;) {
+            const std::function<void(size_t)>* job = nullptr;
+            // a caller that sends search after search finds the worker still polling: no wake-up latency between two searches
+            const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
+            while (!posted.load(std::memory_order_acquire) && std::chrono::steady_clock::now() < until) __builtin_ia32_pause();
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return fn != nullptr; });
+                job = fn;
+                fn = nullptr;
+                posted.store(0, std::memory_order_relaxed);
+            }
+            (*job)(slot);
+            if (left->fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                std::lock_guard<std::mutex> lk(*doneM);
+                doneCv->notify_all();
+            }
+        }
+    }
+};
+struct SlotWorkers {
+    std::mutex busy;                                  // one job at a time on the shared workers
+    std::vector<std::unique_ptr<SlotWorker>> w;       // never destroyed (like the host pool: see opalx_release_cached)
+    std::mutex doneM;
+    std::condition_variable doneCv;
+    static SlotWorkers& get() { static SlotWorkers* s = new SlotWorkers; return *s; }
+};
+}  // namespace
+
+void run_on_device_workers(size_t slots, const std::function<void(size_t)>& fn) {
+    if (slots == 0) return;
+    if (slots == 1) { fn(0); return; }
+    SlotWorkers& sw = SlotWorkers::get();
+    std::unique_lock<std::mutex> own(sw.busy, std::try_to_lock);
+    if (!own.owns_lock()) {  // another host thread is using the workers: threads of this call's own
+        std::vector<std::thread> threads;
+        for (size_t k = 0; k < slots; k++) threads.emplace_back([&fn, k] { fn(k); });
+        for (auto& th : threads) th.join();
+        return;
+    }
+    while (sw.w.size() < slots) {
+        sw.w.emplace_back(new SlotWorker);
+        SlotWorker* me = sw.w.back().get();
+        me->slot = sw.w.size() - 1;
+        me->doneM = &sw.doneM; me->doneCv = &sw.doneCv;
+        std::thread([me] { me->loop(); }).detach();
+    }
+    std::atomic<int> left{(int)slots};
+    for (size_t k = 0; k < slots; k++) {
+        SlotWorker* me = sw.w[k].get();
+        {
+            std::lock_guard<std::mutex> lk(me->m);
+            me->left = &left;
+            me->fn = &fn;
+            me->posted.store(1, std::memory_order_release);
+        }
+        me->cv.notify_one();
+    }
+    std::unique_lock<std::mutex> lk(sw.doneM);
+    sw.doneCv.wait(lk, [&] { return left.load(std::memory_order_acquire) == 0; });
+}
+
 /*
  * Deal sequences to `parts` shards: indices sorted by length (descending), cut into groups of
  * 64 consecutive ones (sequences of one wave stay together), every group to the shard with the fewest residues
@@ -77,6 +151,10 @@ struct OpalxMultiDb {
     std::vector<void*> done;                 // per shard: recorded behind its peer copy
     void* rootStream = nullptr;
     int total = 0;
+    // searches queued by opalx_multi_search_device_async and not yet waited for: [tail, head), slot = index % OPALX_ASYNC_DEPTH
+    unsigned head = 0, tail = 0;
+    void* rootDone[OPALX_ASYNC_DEPTH] = {};  // recorded on the root stream behind a search's permutation
+    int queuedRc[OPALX_ASYNC_DEPTH] = {};
 };
 
 using namespace opal_host;
@@ -93,6 +171,8 @@ extern "C" void opalx_multi_destroy(OpalxMultiDb* m) {
     if (!m->devices.empty()) {
         opal_hip_set_device(m->devices[0]);
         m->gathered.release(); m->perm.release();
+        if (m->rootStream) opal_hip_stream_sync(m->rootStream);
+        for (void*& ev : m->rootDone) { opal_hip_event_destroy(ev); ev = nullptr; }
         opal_hip_stream_destroy(m->rootStream);
     }
     if (cur >= 0) opal_hip_set_device(cur);
@@ -146,61 +226,114 @@ extern "C" OpalxMultiDb* opalx_multi_create_flat(const unsigned char* residues, 
     return m;
 }
 
-extern "C" int opalx_multi_search_device(OpalxMultiDb* m, const unsigned char* query, int query_length, int gap_open, int gap_ext,
-                                         const int* score_matrix, int alphabet_length, int search_type, int mode,
-                                         int* d_score, int* d_end_query, int* d_end_target, float* kernel_ms) {
+/*
+ * Enqueue one search on every shard and the gather behind it; nothing is waited for. Every shard's search goes through its
+ * handle's own queue (opalx_search_device_async: header slot, timing events), its block then travels to the root GPU by peer
+ * DMA on the shard's stream -- behind the root's permutation of the PREVIOUS queued search, which is still reading the gathered
+ * block -- and the root stream permutes the three vectors into database order and records the search's `rootDone` event.
+ */
+extern "C" int opalx_multi_search_device_async(OpalxMultiDb* m, const unsigned char* query, int query_length, int gap_open, int gap_ext,
+                                               const int* score_matrix, int alphabet_length, int search_type, int mode,
+                                               int* d_score, int* d_end_query, int* d_end_target) {
     if (!m || !d_score) return OPAL_ERR_NO_SIMD_SUPPORT;
     const int wantEnd = search_type != OPAL_SEARCH_SCORE;
     if (wantEnd && (!d_end_query || !d_end_target)) return OPAL_ERR_NO_SIMD_SUPPORT;
     if (mode != OPAL_MODE_NW && mode != OPAL_MODE_HW && mode != OPAL_MODE_OV && mode != OPAL_MODE_SW) return OPAL_ERR_INVALID_MODE;
+    if (m->head - m->tail >= OPALX_ASYNC_DEPTH - 1) return OPAL_ERR_NO_SIMD_SUPPORT;  // the queue of this handle is full
     const size_t K = m->shard.size();
     const int nres = wantEnd ? 3 : 1;
     const size_t total = (size_t)m->total;
+    const int slot = (int)(m->head % OPALX_ASYNC_DEPTH);
+    void* prevDone = m->head > m->tail ? m->rootDone[(m->head - 1) % OPALX_ASYNC_DEPTH] : nullptr;
     std::vector<int> rcs(K, 0);
-    std::vector<float> kms(K, 0.f);
-    std::vector<std::thread> threads;
     const int cur = opal_hip_get_device();
-    for (size_t k = 0; k < K; k++) {
-        threads.emplace_back([&, k] {
-            const int n = m->count[k];
-            if (!n) return;
-            // device_ok() first: its once-per-thread OPAL_HIP_DEVICE selection must not override the shard's GPU
-            if (!device_ok() || opal_hip_set_device(m->devices[k])) { rcs[k] = OPAL_ERR_NO_SIMD_SUPPORT; return; }
-            OpalxDb* db = m->shard[k];
-            int* r = m->res[k].p;
-            rcs[k] = search_core(db, query, query_length, gap_open, gap_ext, score_matrix, alphabet_length, search_type, mode, r,
-                                 wantEnd ? r + n : nullptr, wantEnd ? r + 2 * (size_t)n : nullptr, kernel_ms ? &kms[k] : nullptr, /*finalSync=*/false);
-            if (rcs[k] == OPAL_ERR_NO_SIMD_SUPPORT || rcs[k] == OPAL_ERR_INVALID_MODE) return;
-            // the path's only exchange: this shard's block to the root GPU (peer DMA over xGMI), vector by vector into its
-            // place in the gathered block, on the shard's own stream behind its kernels
-            void* st = db->main();
-            int e = 0;
-            for (int v = 0; v < nres; v++)
-                e |= opal_hip_memcpy_peer(m->gathered.p + (size_t)v * total + (size_t)m->first[k], m->devices[0], r + (size_t)v * n, m->devices[k],
-                                          (size_t)n * sizeof(int), st);
-            e |= opal_hip_event_record(m->done[k], st);
-            if (e) rcs[k] = OPAL_ERR_NO_SIMD_SUPPORT;
-        });
-    }
-    for (auto& th : threads) th.join();
+    run_on_device_workers(K, [&](size_t k) {
+        const int n = m->count[k];
+        if (!n) return;
+        // device_ok() first: its once-per-thread OPAL_HIP_DEVICE selection must not override the shard's GPU
+        if (!device_ok() || opal_hip_set_device(m->devices[k])) { rcs[k] = OPAL_ERR_NO_SIMD_SUPPORT; return; }
+        OpalxDb* db = m->shard[k];
+        int* r = m->res[k].p;
+        rcs[k] = opalx_search_device_async(db, query, query_length, gap_open, gap_ext, score_matrix, alphabet_length, search_type, mode, r,
+                                           wantEnd ? r + n : nullptr, wantEnd ? r + 2 * (size_t)n : nullptr);
+        if (rcs[k] == OPAL_ERR_NO_SIMD_SUPPORT || rcs[k] == OPAL_ERR_INVALID_MODE) return;
+        // the path's only exchange: this shard's block to the root GPU (peer DMA over xGMI), vector by vector into its
+        // place in the gathered block, on the shard's own stream behind its kernels
+        void* st = db->main();
+        int e = prevDone ? opal_hip_stream_wait_event(st, prevDone) : 0;
+        for (int v = 0; v < nres; v++)
+            e |= opal_hip_memcpy_peer(m->gathered.p + (size_t)v * total + (size_t)m->first[k], m->devices[0], r + (size_t)v * n, m->devices[k],
+                                      (size_t)n * sizeof(int), st);
+        e |= opal_hip_event_record(m->done[k], st);
+        if (e) rcs[k] = OPAL_ERR_NO_SIMD_SUPPORT;
+    });
     int rc = 0;
     for (size_t k = 0; k < K; k++) {
         if (rcs[k] == OPAL_ERR_NO_SIMD_SUPPORT || rcs[k] == OPAL_ERR_INVALID_MODE) rc = rcs[k];
         else if (rcs[k] && !rc) rc = rcs[k];
     }
-    if (kernel_ms) { *kernel_ms = 0.f; for (size_t k = 0; k < K; k++) *kernel_ms = std::max(*kernel_ms, kms[k]); }
     int e = opal_hip_set_device(m->devices[0]);
     if (!e && rc != OPAL_ERR_NO_SIMD_SUPPORT && rc != OPAL_ERR_INVALID_MODE) {
-        // root: wait for every shard's copy, then the three vectors into database order
+        // root: behind every shard's copy, the three vectors into database order
         for (size_t k = 0; k < K; k++)
             if (m->count[k]) e |= opal_hip_stream_wait_event(m->rootStream, m->done[k]);
         int* outs[3] = {d_score, d_end_query, d_end_target};
         for (int v = 0; v < nres; v++) e |= opal_hip_permute(m->gathered.p + (size_t)v * total, m->perm.p, m->total, outs[v], m->rootStream);
-        e |= opal_hip_stream_sync(m->rootStream);
+        if (!m->rootDone[slot]) m->rootDone[slot] = opal_hip_event_create_untimed();
+        e |= !m->rootDone[slot] || opal_hip_event_record(m->rootDone[slot], m->rootStream);
     }
-    // (an error on one shard: its stream may still hold work that reads the handle's buffers)
-    if (e || rc == OPAL_ERR_NO_SIMD_SUPPORT)
-        for (size_t k = 0; k < K; k++) { opal_hip_set_device(m->devices[k]); m->shard[k]->quiesce(); }
+    if (e || rc == OPAL_ERR_NO_SIMD_SUPPORT || rc == OPAL_ERR_INVALID_MODE) {
+        // (an error on one shard: nothing of this handle stays in flight, the queue is emptied)
+        for (size_t k = 0; k < K; k++) {
+            opal_hip_set_device(m->devices[k]);
+            m->shard[k]->quiesce();
+            float ms;
+            while (m->shard[k]->asyncTail != m->shard[k]->asyncHead) opalx_db_wait(m->shard[k], &ms);
+        }
+        opal_hip_set_device(m->devices[0]);
+        opal_hip_stream_sync(m->rootStream);
+        m->tail = m->head;
+        if (cur >= 0) opal_hip_set_device(cur);
+        return e ? OPAL_ERR_NO_SIMD_SUPPORT : rc;
+    }
+    m->queuedRc[slot] = rc;
+    m->head++;
     if (cur >= 0) opal_hip_set_device(cur);
-    return e ? OPAL_ERR_NO_SIMD_SUPPORT : rc;
+    return rc;
+}
+
+/* Wait for the OLDEST queued search of the handle (first in, first out); `kernel_ms`: the longest DP time over its shards. */
+extern "C" int opalx_multi_wait(OpalxMultiDb* m, float* kernel_ms) {
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (!m) return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (m->tail == m->head) return 0;
+    const int slot = (int)(m->tail % OPALX_ASYNC_DEPTH);
+    m->tail++;
+    const int cur = opal_hip_get_device();
+    int e = 0;
+    for (size_t k = 0; k < m->shard.size(); k++) {
+        if (!m->count[k]) continue;
+        float ms = 0.f;
+        e |= opal_hip_set_device(m->devices[k]);
+        if (opalx_db_wait(m->shard[k], &ms)) e = 1;
+        if (kernel_ms && ms > *kernel_ms) *kernel_ms = ms;
+    }
+    e |= opal_hip_set_device(m->devices[0]);
+    if (m->rootDone[slot]) e |= opal_hip_event_sync(m->rootDone[slot]);
+    if (cur >= 0) opal_hip_set_device(cur);
+    return e ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
+}
+
+extern "C" int opalx_multi_search_device(OpalxMultiDb* m, const unsigned char* query, int query_length, int gap_open, int gap_ext,
+                                         const int* score_matrix, int alphabet_length, int search_type, int mode,
+                                         int* d_score, int* d_end_query, int* d_end_target, float* kernel_ms) {
+    if (kernel_ms) *kernel_ms = 0.f;
+    if (!m) return OPAL_ERR_NO_SIMD_SUPPORT;
+    // (searches still queued on the handle come first: this call returns with ITS results complete)
+    while (m->tail != m->head)
+        if (opalx_multi_wait(m, nullptr)) return OPAL_ERR_NO_SIMD_SUPPORT;
+    const int rc = opalx_multi_search_device_async(m, query, query_length, gap_open, gap_ext, score_matrix, alphabet_length, search_type, mode,
+                                                   d_score, d_end_query, d_end_target);
+    if (rc == OPAL_ERR_NO_SIMD_SUPPORT || rc == OPAL_ERR_INVALID_MODE || m->tail == m->head) return rc;
+    return opalx_multi_wait(m, kernel_ms) ? OPAL_ERR_NO_SIMD_SUPPORT : rc;
 }

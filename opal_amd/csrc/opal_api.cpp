@@ -136,7 +136,19 @@ extern "C" int opalx_search_device_async(OpalxDb* db, const unsigned char* query
                                d_score, d_end_query, d_end_target, nullptr, /*finalSync=*/false);
     db->asyncTimed = false;
     if (db->asyncEvents) db->asyncHead++;  // (its events were recorded: opalx_db_wait will wait for them)
-    else { db->quiesce(); db->asyncTail = db->asyncHead; }  // (failed before its end: nothing of this handle stays in flight)
+    else if (rc == 0) {
+        // a search that launched nothing (empty query or database): it still owns its place in the queue -- the searches
+        // queued before it keep theirs, and its own opalx_db_wait reports 0 ms
+        const int slot = (int)(db->asyncHead % OPALX_ASYNC_DEPTH);
+        void* st = db->main();
+        for (int i = 0; i < 2; i++)
+            if (!db->asyncEv[2 * slot + i]) db->asyncEv[2 * slot + i] = opal_hip_event_create();
+        if (st && db->asyncEv[2 * slot] && db->asyncEv[2 * slot + 1] && !opal_hip_event_record(db->asyncEv[2 * slot], st) &&
+            !opal_hip_event_record(db->asyncEv[2 * slot + 1], st))
+            db->asyncHead++;
+    } else {
+        db->quiesce();  // (an error: nothing of THIS call stays in flight; the earlier searches have completed, their entries stay)
+    }
     db->asyncEvents = false;
     return rc;
 }
@@ -279,10 +291,10 @@ static int search_into_results(unsigned char query[], int Q, unsigned char* db[]
             std::vector<std::vector<int>> shard = deal_groups(lens.data(), n, (int)devices.size());
             std::vector<int> rcs(devices.size(), 0);
             std::vector<std::vector<int>> out(devices.size());
-            std::vector<std::thread> threads;
             const int callerDevice = opal_hip_get_device();
-            for (size_t k = 0; k < devices.size(); k++) {
-                threads.emplace_back([&, k] {
+            {
+                // (persistent workers, one per listed device slot: no thread creation per call)
+                run_on_device_workers(devices.size(), [&](size_t k) {
                     std::vector<int>& pos = shard[k];
                     const int m = (int)pos.size();
                     if (!m) return;
@@ -297,7 +309,6 @@ static int search_into_results(unsigned char query[], int Q, unsigned char* db[]
                                        starts ? s + 4 * (size_t)m : nullptr, traced ? &traces[k] : nullptr);
                 });
             }
-            for (auto& th : threads) th.join();
             if (callerDevice >= 0) opal_hip_set_device(callerDevice);
             for (size_t k = 0; k < devices.size(); k++) {
                 if (rcs[k] == OPAL_ERR_NO_SIMD_SUPPORT || rcs[k] == OPAL_ERR_INVALID_MODE) return rcs[k];

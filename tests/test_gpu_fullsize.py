@@ -630,6 +630,26 @@ def test_multi_gpu_handle_device_side_gather(c2):
                 np.testing.assert_array_equal(got[2], et0, err_msg=f"{mode} endT")
             else:
                 assert (got[1:] == -12345).all()
+    # three searches QUEUED on the multi-GPU handle (different queries and modes, result buffers of their own), waited for
+    # first in, first out; a fourth is refused until one has been waited for
+    from opal_amd import synth
+    jobs = [(synth.query(250, seed=31), "SW", 0), (q, "HW", 1), (synth.query(180, seed=32), "NW", 1)]
+    outs = [torch.full((3 * n,), -12345, dtype=torch.int32, device="cuda") for _ in jobs]
+    torch.cuda.synchronize()
+    for (qq, mode, st), o in zip(jobs, outs):
+        assert multi.search_device_async(qq, 3, 1, m, st, oracle_lib.MODES[mode], o[:n].data_ptr(), o[n:2 * n].data_ptr() if st else 0,
+                                         o[2 * n:].data_ptr() if st else 0) == 0
+    assert multi.search_device_async(q, 3, 1, m, 0, oracle_lib.MODE_SW, outs[0].data_ptr()) != 0, "a fourth queued search must be refused"
+    for (qq, mode, st), o in zip(jobs, outs):
+        rc, kms = multi.wait()
+        assert rc == 0 and kms > 0
+        rc0, s0, eq0, et0 = one.search(qq, 3, 1, m, st, oracle_lib.MODES[mode])
+        got = o.cpu().numpy().reshape(3, n)
+        np.testing.assert_array_equal(got[0], s0, err_msg=f"queued {mode} score")
+        if st:
+            np.testing.assert_array_equal(got[1], eq0)
+            np.testing.assert_array_equal(got[2], et0)
+    assert multi.wait() == (0, 0.0)  # nothing queued any more
     multi.close()
 
 
@@ -707,3 +727,15 @@ def test_queued_async_searches_first_in_first_out():
     assert pdb.search_device(big, 11, 1, m, 0, 3, c.data_ptr())[0] == 0
     np.testing.assert_array_equal(a.cpu().numpy(), want[0][:n])
     np.testing.assert_array_equal(b.cpu().numpy(), c.cpu().numpy())
+    # a search that launches nothing (empty query) BETWEEN two real ones keeps its own place in the queue: the first wait is
+    # the first search's, the second reports 0 ms, the third is the last search's
+    a.zero_(); b.fill_(7); c.zero_()
+    torch.cuda.synchronize()
+    assert pdb.search_device_async(jobs[0][0], 11, 1, m, 0, 3, a.data_ptr()) == 0
+    assert pdb.search_device_async(np.zeros(0, np.uint8), 11, 1, m, 0, 3, b.data_ptr()) == 0
+    assert pdb.search_device_async(jobs[1][0], 11, 1, m, 0, 0, c.data_ptr()) == 0
+    t = [pdb.wait() for _ in range(3)]
+    assert [x[0] for x in t] == [0, 0, 0] and t[0][1] > 0 and t[1][1] < 0.05 and t[2][1] > 0, t
+    np.testing.assert_array_equal(a.cpu().numpy(), want[0][:n])
+    assert (b.cpu().numpy() == 0).all()     # SW against an empty query: score 0 everywhere
+    np.testing.assert_array_equal(c.cpu().numpy(), want[1][:n])
