@@ -208,6 +208,16 @@ template <> struct Vec<17> {
             : [m] "=&s"(m), [cand] "=&v"(cand), [col] "+v"(col), [bf] "+v"(bf)
             : [c] "v"(c), [lim] "v"(limit), [h] "v"(h), [rs] "s"(Rs));
     }
+    // ... the same without a column limit (streaming kernels: columns beyond the sequence come after its result was written)
+    static __device__ __forceinline__ void track_best_any(reg h, reg& bf, int& col, int c) {
+        unsigned long long m;
+        asm("v_cmp_gt_i16_e64 %[m], %[h], %[bf]\n\t"
+            "s_nop 1\n\t"
+            "v_cndmask_b32_e64 %[col], %[col], %[c], %[m]\n\t"
+            "v_cndmask_b32_e64 %[bf], %[bf], %[h], %[m]"
+            : [m] "=&s"(m), [col] "+v"(col), [bf] "+v"(bf)
+            : [c] "v"(c), [h] "v"(h));
+    }
     static __device__ __forceinline__ int half(reg a, int) { return (int)(short)(a & 0xffffu); }
     static __device__ __forceinline__ bool same(reg a, reg b, int) { return (unsigned short)a == (unsigned short)b; }  // v_cmp_eq_u16
     static __device__ __forceinline__ int clampv(long long v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : (int)v); }

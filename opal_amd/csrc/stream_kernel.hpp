@@ -554,6 +554,10 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
             const int e = idx - k * INIT;
             const int r0k = k * S - padTop;
             int v = 0;
+            // (frame: X' = X + (j + local step) * Ge. The class kernels moved to the row position k * S + j in round 4 and save the two
+            // subtractions at the lane hand-off; here that costs more than it saves: with a 2000-aa query the frame would grow by
+            // 2000 * Ge, every sequence beyond 1 870 instead of 1 993 residues would leave the 16-bit range and join the side
+            // workgroups, which displace streaming ones -- C5 NW 7 900 -> 7 700 GCUPS, profiles/r04_ab_glstream.txt)
             if (e < SP4) {  // H[r][-1] in the frame of my step before my first column
                 const int j = e;
                 v = V::clampv(hbound(r0k + j)) + (j + k - 1) * Ge;
@@ -584,7 +588,9 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
     const reg Qv = V::splat(Go), Rv = V::splat(Ge);
     const unsigned GQs = (unsigned)(Go - Ge) & 0xffffu;
     const reg SR1v = V::splat((S - 1) * Ge);
+    const unsigned SR1s = (unsigned)((S - 1) * Ge) & 0xffffu;
     reg sRv = 0;  // (my column + k) * Ge: the local step of my current sequence
+    const unsigned Qs = (unsigned)Go & 0xffffu, Rs = (unsigned)Ge & 0xffffu;  // (wave-uniform operands straight from SGPRs)
     const unsigned ldsBase = (unsigned)(uintptr_t)(opal_lds_u8*)lds;
     const unsigned padOff = ldsBase + (unsigned)(PAD * stride);
     unsigned offv = padOff + (unsigned)(k * LANE_BYTES);
@@ -669,15 +675,15 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
         const int c = x - myStart;  // my column
 
         // ---- inputs of this column: from the lane above (frame change of S-1 registers), or the top boundary
-        reg inH = V::subs((reg)shr1((unsigned)outH), SR1v);
-        reg inF = V::subs((reg)shr1((unsigned)outF), SR1v);
+        reg inH = V::subs_s((reg)shr1((unsigned)outH), SR1s);
+        reg inF = V::subs_s((reg)shr1((unsigned)outF), SR1s);
         if (k == 0) {
-            // H[-1][c] + (s-1)*Ge and F[0][c] + s*Ge = H[-1][c] - Go + s*Ge; NW: H[-1][c] = -Go - c*Ge, HW/OV: 0
+            // H[-1][c] + (c-1)*Ge and F[0][c] + c*Ge = H[-1][c] - Go + c*Ge; NW: H[-1][c] = -Go - c*Ge, HW/OV: 0
             if (hasPrev) {  // ... a lower chunk: what the chunk above left for this column, into my frame (k = 0: sRv = c*Ge)
-                inH = V::adds((reg)(bndq & 0xffffu), V::subs(sRv, Rv));
+                inH = V::adds((reg)(bndq & 0xffffu), V::subs_s(sRv, Rs));
                 inF = V::adds((reg)(bndq >> 16), sRv);
             } else if (MODE == MODE_NW) { inH = V::splat(-Go - Ge); inF = V::splat(-2 * Go); }
-            else { inH = V::subs(sRv, Rv); inF = V::subs(sRv, Qv); }
+            else { inH = V::subs_s(sRv, Rs); inF = V::subs_s(sRv, Qs); }
         }
         if constexpr (CHUNK) bndq = shl1(bndq);
         {
@@ -777,9 +783,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
             // step: the running best moves into the frame of the new step with one addition (only the last lane's value is
             // ever used; columns beyond the sequence come after its result has been written).
             const reg prevF = bestF;                      // OV: the maximum over columns 0 .. c-1, in this step's frame
-            const bool better = (short)outH > (short)bestF;  // strict >: first column wins (opal.cpp:824-834)
-            bestF = better ? outH : bestF;
-            bestCol = better ? c : bestCol;
+            V::track_best_any(outH, bestF, bestCol, c);  // strict >: first column wins (opal.cpp:824-834)
             if (k == kLast && lastc) {
                 const reg frame = V::adds(sRv, SR1v);
                 int sc = V::half(V::subs(bestF, frame), 0), eq = p.Q - 1, et = bestCol;
@@ -802,9 +806,9 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
                     if (p.outEndQ) { p.outEndQ[seq] = eq; p.outEndT[seq] = et; }
                 }
             }
-            bestF = V::adds(bestF, Rv);  // into the frame of the next step
+            bestF = V::adds_s(bestF, Rs);  // into the frame of the next step
         }
-        sRv = V::adds(sRv, Rv);
+        sRv = V::adds_s(sRv, Rs);
     }
     clk_end(clkSlot);
 }
