@@ -246,8 +246,19 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     unsigned bndq = 0;  // CHUNK: lane queue of the boundary words above the columns of this batch (lane 0 consumes)
     unsigned outq = 0;  // CHUNK: lane queue of the last lane's outputs, oldest towards lane 0
 
-    for (int s = 0;; s++) {
-        if ((s & (G - 1)) == 0) {  // wave-uniform: refill the queue with columns s .. s+G-1, fetch those of the next batch
+#ifndef OPAL_STREAM_PF_LATE
+#define OPAL_STREAM_PF_LATE 1
+#endif
+    // LATE (single-launch streams): the profile address of the NEXT step, its gap block and its first row block are made and
+    // read inside the last row block of the current step -- behind the batch refill when the next step starts a batch --, so
+    // a step no longer begins by waiting out an LDS round trip (dp_kernel.hpp, PF_LATE: the registers that carry the three
+    // reads are live across the step's tail only).
+    constexpr bool LATE = !CHUNK && !(SIDE && SWEND) && S <= (SWEND ? 34 : 38) && OPAL_STREAM_PF_LATE != 0;  // (the tallest shapes are two registers short)
+    bool finished = false;
+    int4 infoNext = make_int4(0, 0, 0, 0), pfirst = make_int4(0, 0, 0, 0);
+    // start of a batch of G steps (wave-uniform): refill the queue with columns s .. s+G-1, fetch those of the next batch
+    auto refill = [&](const int s) {
+        {
             const unsigned letter = st.tokNext;
             const unsigned above = st.bndNext;
             if constexpr (CHUNK) {
@@ -272,7 +283,24 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
             bndq = above;
             // every slot has run dry and its last separator has left the last lane (CHUNK: the store above covered the positions
             // up to s-G-1, i.e. everything before lastEnd)
-            if (__ballot(!(st.done && s >= st.lastEnd + G)) == 0ull) break;
+            if (__ballot(!(st.done && s >= st.lastEnd + G)) == 0ull) finished = true;
+        }
+    };
+    auto next_address = [&]() {  // offv <- the profile address of the step that follows
+        const unsigned shifted = shr1(offv) + (unsigned)LANE_BYTES;
+        offv = (k == 0) ? tokq : shifted;
+        tokq = shl1(tokq);
+    };
+    if constexpr (LATE) {
+        refill(0);
+        next_address();
+        infoNext = lds_ld16(offv + infoOff);
+        pfirst = lds_ld16(offv);
+    }
+
+    for (int s = 0; !finished; s++) {
+        if constexpr (!LATE) {
+            if ((s & (G - 1)) == 0) { refill(s); if (finished) break; }
         }
         if constexpr (CHUNK) {  // the last lane's outputs of the step behind us join the queue
             const unsigned mine = ((unsigned)outH & 0xffffu) | ((unsigned)outF << 16);
@@ -289,12 +317,8 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
             inH = (k == 0) ? (reg)0 : inH;  // top boundary of local alignment
             inF = (k == 0) ? (reg)0 : inF;
         }
-        {
-            const unsigned shifted = shr1(offv) + (unsigned)LANE_BYTES;
-            offv = (k == 0) ? tokq : shifted;
-            tokq = shl1(tokq);
-        }
-        const int4 info = lds_ld16(offv + infoOff);
+        if constexpr (!LATE) next_address();
+        const int4 info = LATE ? infoNext : lds_ld16(offv + infoOff);
         const reg Qv = (reg)info.x, Rv = (reg)info.y;
 
         reg f = inF;
@@ -305,12 +329,18 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
         reg cq[NQ] = {0, 0};
         {
             constexpr int NBLK = SPAD / RB;
-            int4 pc = lds_ld16(offv);
+            int4 pc = LATE ? pfirst : lds_ld16(offv);
             reg d = V::adds(diagIn, (reg)pc.x), t = 0;
             static_for<NBLK>([&](auto rbc) {
                 constexpr int rb = decltype(rbc)::value;
                 int4 pn = pc;
                 if constexpr (rb + 1 < NBLK) pn = lds_ld16(offv + (rb + 1) * RB * ES);
+                else if constexpr (LATE) {  // every read of this step has been issued: the next step's address and reads
+                    if (((s + 1) & (G - 1)) == 0) refill(s + 1);
+                    next_address();
+                    infoNext = lds_ld16(offv + infoOff);
+                    pn = lds_ld16(offv);
+                }
                 reg Pv[RB + 1];
                 if constexpr (ES == 4) {
                     Pv[0] = (reg)pc.x; Pv[1] = (reg)pc.y; Pv[2] = (reg)pc.z; Pv[3] = (reg)pc.w;
@@ -329,6 +359,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
                 });
                 pc = pn;
             });
+            if constexpr (LATE) pfirst = pc;
         }
         outH = Hp[S - 1];
         outF = f;

@@ -34,15 +34,15 @@ for c in $CFGS; do
     sprot390) ARGS="--workload sprot --query-fasta $GRAFT_REPO_ROOT/tests/golden/data/query_Q3ZAI3.fasta" ;;
   esac
   D=$OUT/$c; mkdir -p $D
-  python3 $B $ARGS $COMMON > $D/bench.json 2> $D/bench.err
-  rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python3 $B $ARGS $COMMON > $D/trace.log 2>&1
+  timeout 600 python3 $B $ARGS $COMMON > $D/bench.json 2> $D/bench.err
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $D/trace -- python3 $B $ARGS $COMMON > $D/trace.log 2>&1
   if [ -z "$QUICK" ]; then :; fi
-  rocprofv3 --pmc $SQ1 --output-format csv -d $D/sq1 -- python3 $B $ARGS $COMMON > $D/sq1.log 2>&1
-  rocprofv3 --pmc $SQ2 --output-format csv -d $D/sq2 -- python3 $B $ARGS $COMMON > $D/sq2.log 2>&1
+  timeout 600 rocprofv3 --pmc $SQ1 --output-format csv -d $D/sq1 -- python3 $B $ARGS $COMMON > $D/sq1.log 2>&1
+  timeout 600 rocprofv3 --pmc $SQ2 --output-format csv -d $D/sq2 -- python3 $B $ARGS $COMMON > $D/sq2.log 2>&1
   if [ -z "$QUICK" ]; then
-  rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $D/grbm -- python3 $B $ARGS $COMMON > $D/grbm.log 2>&1
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/fetch -- python3 $B $ARGS $COMMON > $D/fetch.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/write -- python3 $B $ARGS $COMMON > $D/write.log 2>&1
+  timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $D/grbm -- python3 $B $ARGS $COMMON > $D/grbm.log 2>&1
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/fetch -- python3 $B $ARGS $COMMON > $D/fetch.log 2>&1
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/write -- python3 $B $ARGS $COMMON > $D/write.log 2>&1
   fi
   python3 $GRAFT_REPO_ROOT/scripts/summarize_prof.py $D $OUT/r04_$c.json $c > $D/summary.log 2>&1
   # keep the merged output small: the raw per-dispatch CSVs can be tens of MB
