@@ -140,8 +140,8 @@ int opal_hip_launch_stream(const OpalHipLaunch* args, int* next_counter);
 /* Role-swapped SW score search (swap_kernel.hpp) for the few longest targets of a search with a short query: the TARGET
    on the rows of a wave (row chunks of 64 lanes x rows_per_lane residues, top to bottom), the query on the columns; one
    workgroup per item of [first_item, +num_items). Read from `args`: query / matrix / gaps, the packed database, first_item,
-   num_items, rows_per_lane (from opal_hip_swap_rows), out_score, the overflow list, sat_limit / neg_pad, stream,
-   clock_probe. opal_hip_swap_rows: the default rows per lane (8 / 16 / 24 / 40 exist) for this query length and
+   num_items, rows_per_lane (from opal_hip_swap_rows), want_end (end cells: 8 or 16 rows per lane only), out_score /
+   out_end_query / out_end_target, the overflow list, sat_limit / neg_pad, stream, clock_probe. opal_hip_swap_rows: the default rows per lane (8 / 16 / 24 / 40 exist) for this query length and
    alphabet -- the largest shape within 64 KiB of LDS, so that the launch shares its CUs (0: none -- query beyond
    OPAL_HIP_SWAP_MAX_QUERY or alphabet too large). */
 #define OPAL_HIP_SWAP_MAX_QUERY 1024

@@ -1,12 +1,13 @@
 // Role-swapped SW score kernels (swap_kernel.hpp): the target on the rows, 64 lanes x 8 / 16 / 24 / 40 residues per row chunk.
 #include "swap_kernel.hpp"
 
-SwapFn opal_swap_kernel(int rows) {
+SwapFn opal_swap_kernel(int rows, int want_end) {
+    if (want_end) return rows == 8 ? (SwapFn)opal_swap_sw<8, true> : rows == 16 ? (SwapFn)opal_swap_sw<16, true> : nullptr;
     switch (rows) {
-    case 8: return opal_swap_sw<8>;
-    case 16: return opal_swap_sw<16>;
-    case 24: return opal_swap_sw<24>;
-    case 40: return opal_swap_sw<40>;
+    case 8: return opal_swap_sw<8, false>;
+    case 16: return opal_swap_sw<16, false>;
+    case 24: return opal_swap_sw<24, false>;
+    case 40: return opal_swap_sw<40, false>;
     }
     return nullptr;
 }

@@ -569,13 +569,15 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                 // the class kernels run with the roles swapped (swap_kernel.hpp) on a high-priority stream of their own,
                 // submitted first; everything else as usual beside them.
                 int swapRows = 0;
-                const int swapN = (narrow == 17 && !wantEnd && !chunkedQuery) ? plan_swap(Q, A, seqLenOf, 0, nNarrow, db->residues, &swapRows) : 0;
+                int swapN = (narrow == 17 && !chunkedQuery) ? plan_swap(Q, A, seqLenOf, 0, nNarrow, db->residues, &swapRows) : 0;
+                if (wantEnd && swapRows > 16) swapRows = 16;  // (end cells: the 8- and 16-row shapes)
+                if (wantEnd && swapN > 0 && opal_hip_swap_lds_bytes(swapRows, Q, A) > 160 * 1024) swapN = 0;
                 void* joinSwap = nullptr;
                 if (swapN > 0) {
                     void* fork = db->event(11);
                     void* side = db->swap();
                     OpalHipLaunch a;
-                    fill_launch(a, c, 18, 0, 0, nullptr, db->ovfCount.p);
+                    fill_launch(a, c, 18, wantEnd, 0, nullptr, db->ovfCount.p);
                     a.rows_per_lane = swapRows; a.first_item = 0; a.num_items = swapN; a.stream = side;
                     if (!fork || !side || opal_hip_event_record(fork, st) || opal_hip_stream_wait_event(side, fork) || !gate_items(db, side, 0, swapN) ||
                         opal_hip_launch_swap(&a) || !(joinSwap = db->event(12)) || opal_hip_event_record(joinSwap, side)) {

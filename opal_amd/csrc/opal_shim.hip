@@ -588,9 +588,9 @@ extern "C" size_t opal_hip_swap_lds_bytes(int rows_per_lane, int query_length, i
     return opal_swap_lds(rows_per_lane, query_length, alphabet_length);
 }
 extern "C" int opal_hip_launch_swap(const OpalHipLaunch* a) {
-    SwapFn fn = opal_swap_kernel(a->rows_per_lane);
+    SwapFn fn = opal_swap_kernel(a->rows_per_lane, a->want_end);
     const size_t lds = opal_swap_lds(a->rows_per_lane, a->query_length, a->alphabet_length);
-    if (!fn || a->mode != MODE_SW || a->want_end || a->work || a->query_length < 1 || a->query_length > OPAL_HIP_SWAP_MAX_QUERY || lds > 160 * 1024) {
+    if (!fn || a->mode != MODE_SW || (a->want_end && (!a->out_end_query || !a->out_end_target)) || a->work || a->query_length < 1 || a->query_length > OPAL_HIP_SWAP_MAX_QUERY || lds > 160 * 1024) {
         snprintf(g_err, sizeof g_err, "unlaunchable swapped shape: rows=%d Q=%d A=%d", a->rows_per_lane, a->query_length, a->alphabet_length);
         fprintf(stderr, "[opal-hip] %s\n", g_err);
         return 2;
@@ -602,7 +602,8 @@ extern "C" int opal_hip_launch_swap(const OpalHipLaunch* a) {
     p.Go = a->gap_open; p.Ge = a->gap_ext;
     p.res = a->residues; p.seqOff = a->seq_offset; p.pairLen = a->pair_len; p.pairSeq = a->pair_seq;
     p.firstItem = a->first_item; p.numItems = a->num_items;
-    p.outScore = a->out_score; p.ovfCount = a->overflow_count; p.ovfItems = a->overflow_items;
+    p.outScore = a->out_score; p.outEndQ = a->out_end_query; p.outEndT = a->out_end_target;
+    p.ovfCount = a->overflow_count; p.ovfItems = a->overflow_items;
     p.satLimit = a->sat_limit; p.negPad = a->neg_pad;
     p.clk = a->clock_probe;
     if (lds > 64 * 1024 && raise_lds_limit((const void*)fn)) return 1;

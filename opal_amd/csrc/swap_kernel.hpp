@@ -22,7 +22,7 @@
 //     step ahead, instead of through a lane queue.
 // One workgroup per target (the profile of a 2560-row chunk fills most of a CU's LDS); the host sends only the handful of
 // targets here whose lone-wave time on the class kernels would exceed the search (planner.cpp: swap_prefix).
-// Scores only (end cells: the class kernels); scores at the 16-bit limit go to the 32-bit re-run list like everywhere else.
+// Scores, and end cells at 8 / 16 rows per lane; scores at the 16-bit limit go to the 32-bit re-run list like everywhere else.
 #pragma once
 #include "dp_kernel.hpp"
 
@@ -36,6 +36,8 @@ struct SwapParams {
     const int* pairSeq;
     int firstItem, numItems;  // items [firstItem, +numItems): one workgroup each
     int* outScore;
+    int* outEndQ;   // END kernels: where the score is first reached (opal.h:44-45): smallest TARGET index, then smallest query index
+    int* outEndT;
     int* ovfCount;
     int* ovfItems;
     int satLimit, negPad;
@@ -55,7 +57,15 @@ __host__ __device__ inline size_t opal_swap_lds_bytes(int Q, int A) {
     return (size_t)(A + 1) * (size_t)opal_swap_stride<S>() + 4 * (size_t)(Q + 128) + 4 * (size_t)(Q + 66) + (((size_t)A * A * 2 + 15) & ~(size_t)15) + 48;
 }
 
-template <int S>
+// END: also the end cell. In the swapped frame the target index is the ROW and the query index the column, so the cell
+// wanted is the one with the smallest row, then the smallest column, among those that hold the score (opal.h:44-45,
+// opal.cpp:385-401 pick the smallest target index first). Every lane keeps the best cell of its own rows: a column whose
+// maximum over the lane's rows improves the lane's running maximum replaces it (smallest row of that column), a column
+// that TIES with it replaces it only if it holds the value in a smaller row (it comes later, so its column is larger);
+// both only inside the query (pad columns can repeat a value, never create one) and only if the value reaches what the
+// whole wave had a few steps ago. The lanes hold ascending rows and the chunks run top to bottom, so the final choice is
+// the highest score, then the smallest global row.
+template <int S, bool END = false>
 __global__ void __launch_bounds__(SWAP_WAVES * 64, 1) opal_swap_sw(const SwapParams p) {
     using V = Vec<18>;
     using reg = typename V::reg;
@@ -100,6 +110,8 @@ __global__ void __launch_bounds__(SWAP_WAVES * 64, 1) opal_swap_sw(const SwapPar
     const int k = lane;
     const unsigned Qs = (unsigned)p.Go & 0xffffu, Rs = (unsigned)p.Ge & 0xffffu;
     reg mx = 0;
+    int bestRow = INT_MAX, bestCol = -1;  // END: my best cell (global target row, query column)
+    int waveMax = 0;                      // END: what the whole wave had reached a few steps ago (scan filter)
     const int chunkRows = 64 * S;
     const int nchunks = (L + chunkRows - 1) / chunkRows;
     const unsigned qoffLane = (unsigned)(uintptr_t)(opal_lds_u8*)reinterpret_cast<unsigned char*>(qoff) + 4u * (unsigned)(63 - k);
@@ -153,6 +165,7 @@ __global__ void __launch_bounds__(SWAP_WAVES * 64, 1) opal_swap_sw(const SwapPar
             inH = (k == 0) ? (reg)(bndCur & 0xffffu) : inH;
             inF = (k == 0) ? (reg)(bndCur >> 16) : inF;
             reg f = inF;
+            reg cm = 0;  // END: this column's maximum over my rows
             int4 pc = pcur;
             reg d = V::adds(diagIn, (reg)pc.x), t = 0;
             static_for<NBLK>([&](auto rbc) {
@@ -169,13 +182,27 @@ __global__ void __launch_bounds__(SWAP_WAVES * 64, 1) opal_swap_sw(const SwapPar
                         constexpr int n = (S - j0) < 4 ? (S - j0) : 4;
                         constexpr bool last = j0 + n == S;
                         const reg* Pn = &Pv[j0 - rb * RB + 1];
-                        V::template rows<ROWS_SW, n, last>(&Hp[j0], &En[j0], Pn, f, mx, d, t, Qs, Rs);
+                        V::template rows<ROWS_SW, n, last>(&Hp[j0], &En[j0], Pn, f, END ? cm : mx, d, t, Qs, Rs);
                     }
                 });
                 pc = pn;
             });
             outH = Hp[S - 1];
             outF = f;
+            if constexpr (END) {
+                if ((s & 7) == 0) waveMax = wave_max_i32(V::half(mx, 0));
+                const int cv = V::half(cm, 0), mv = V::half(mx, 0);
+                const int c = s - k;
+                if (cv >= mv && cv > 0 && cv >= waveMax && (unsigned)c < (unsigned)Q) {
+                    int r = 0;
+#pragma unroll
+                    for (int j = S - 1; j >= 0; j--)
+                        if (V::same(Hp[j], cm, 0)) r = j;  // smallest row of the column holding it
+                    const int row = t0 + k * S + r;
+                    if (cv > mv || row < bestRow) { bestRow = row; bestCol = c; }
+                }
+                mx = V::maxs(mx, cm);
+            }
             // the bottom row of a full chunk: lane 63 finishes column s - 63
             if (hasNext && k == 63 && s >= 63) {
                 const unsigned w = ((unsigned)outH & 0xffffu) | ((unsigned)outF << 16);
@@ -189,18 +216,32 @@ __global__ void __launch_bounds__(SWAP_WAVES * 64, 1) opal_swap_sw(const SwapPar
 
     // ---- result: the maximum over the lanes of wave 0 (every chunk accumulated into mx)
     if (wave == 0) {
-        const int sc = wave_max_i32(V::half(mx, 0));
+        int sc = V::half(mx, 0), row = bestRow, col = bestCol;
+        if constexpr (END) {  // highest score, then smallest target index (= row)
+#pragma unroll
+            for (int dd = 32; dd >= 1; dd >>= 1) {
+                const int osc = __shfl_xor(sc, dd, 64), orow = __shfl_xor(row, dd, 64), ocol = __shfl_xor(col, dd, 64);
+                if (osc > sc || (osc == sc && orow < row)) { sc = osc; row = orow; col = ocol; }
+            }
+        } else {
+            sc = wave_max_i32(sc);
+        }
         if (lane == 0 && seq >= 0) {
             if (sc >= p.satLimit) {  // (opal.cpp:364-370): hand over to width 32
                 const int at = atomicAdd(p.ovfCount, 1);
                 p.ovfItems[at] = item;
             } else {
                 p.outScore[seq] = sc;
+                if constexpr (END) {
+                    const bool none = sc <= 0 || col < 0;  // score 0: no cell (test.cpp:242-243)
+                    p.outEndQ[seq] = none ? -1 : col;
+                    p.outEndT[seq] = none ? -1 : row;
+                }
             }
         }
     }
     clk_end(clkSlot);
 }
 
-SwapFn opal_swap_kernel(int rows);         // inst_swap.hip: rows per lane 8 / 16 / 24 / 40 (nullptr: not instantiated)
+SwapFn opal_swap_kernel(int rows, int want_end);  // inst_swap.hip: rows per lane 8 / 16 / 24 / 40, with end cells 8 / 16 (nullptr: not instantiated)
 size_t opal_swap_lds(int rows, int Q, int A);  // LDS bytes of that shape

@@ -26,13 +26,16 @@ pdb = PreparedDb(None, offs, device_ptr=d_res.data_ptr())
 out = torch.zeros(n, dtype=torch.int32, device=dev)
 torch.cuda.synchronize()
 reps = int(os.environ.get("REPS", "7"))
+ST = int(os.environ.get("ST", "0"))  # 1: with end locations
+e1 = torch.zeros(n, dtype=torch.int32, device=dev); e2 = torch.zeros(n, dtype=torch.int32, device=dev)
+torch.cuda.synchronize()
 for name in names:
     q = read_fasta(os.path.join(ROOT, "tests", "golden", "data", f"query_{name}.fasta"), alphabet)[0]
     ks = []
     for _ in range(reps):
-        rc, k = pdb.search_device(q, 3, 1, matrix, 0, MODES["SW"], out.data_ptr())
+        rc, k = pdb.search_device(q, 3, 1, matrix, ST, MODES["SW"], out.data_ptr(), e1.data_ptr() if ST else 0, e2.data_ptr() if ST else 0)
         assert rc == 0
         ks.append(k)
     cells = len(q) * float(offs[-1])
     med = float(np.median(ks))
-    print(f"{name} Q={len(q)}: kernel ms median {med:.3f} min {min(ks):.3f} -> {cells / med / 1e6:.0f} GCUPS, frac of 9-instr bound {cells / med / 1e6 / 8738:.3f}; checksum {int(out.sum().item())}", flush=True)
+    print(f"{name} Q={len(q)}: kernel ms median {med:.3f} min {min(ks):.3f} -> {cells / med / 1e6:.0f} GCUPS, frac of 9-instr bound {cells / med / 1e6 / 8738:.3f}; checksum {int(out.sum().item())}" + (f" end checksum {int(e1.sum().item())} {int(e2.sum().item())}" if ST else ""), flush=True)

@@ -74,6 +74,17 @@ def test_swapped_kernel_vs_oracle(qlen, rows, ours, oracle, opal_opt):
         assert got[0] == want[0] == 0
         np.testing.assert_array_equal(got[1], want[1], err_msg=f"swapped q{qlen} rows={rows} gaps {go}/{ge}")
         assert (got[2] == -1).all() and (got[3] == -1).all()
+        # ... and with end cells (the 8- and 16-row shapes; taller requests fall back to 16 rows): the smallest target index
+        # holding the score, then the smallest query index -- rows first, then columns, in the swapped frame
+        before = _swapped(ours)
+        got = ours.search(q, db, go, ge, m, 1, MODES["SW"])[:4]
+        assert _swapped(ours) - before == 20, "the swapped kernel did not run for the search with end cells"
+        want = oracle.search(q, db, go, ge, m, 1, MODES["SW"])
+        assert got[0] == want[0] == 0
+        np.testing.assert_array_equal(got[1], want[1], err_msg=f"swapped + end q{qlen} rows={rows} gaps {go}/{ge}: score")
+        live = want[1] != 0
+        np.testing.assert_array_equal(got[3][live], want[3][live], err_msg=f"swapped + end q{qlen} rows={rows} gaps {go}/{ge}: endT")
+        np.testing.assert_array_equal(got[2][live], want[2][live], err_msg=f"swapped + end q{qlen} rows={rows} gaps {go}/{ge}: endQ")
 
 
 def test_swapped_kernel_saturated_scores_rerun(ours, oracle, opal_opt):
@@ -92,7 +103,7 @@ def test_swapped_kernel_saturated_scores_rerun(ours, oracle, opal_opt):
 
 def test_swapped_kernel_is_what_a_long_tail_runs_on(ours, oracle, opal_opt):
     """Without forcing: a short query against a database with a few very long targets sends exactly those to the swapped
-    kernel (planner.cpp plan_swap); with end locations, a longer query or no tail it stays away."""
+    kernel (planner.cpp plan_swap), with and without end locations; with a longer query or no tail it stays away."""
     from opal_amd import synth
     from opal_amd.score_matrix import blosum50
     res, offs, lens = synth.database(20000, seed=42)
@@ -102,7 +113,7 @@ def test_swapped_kernel_is_what_a_long_tail_runs_on(ours, oracle, opal_opt):
     q = synth.query(110, seed=7)
     opal_opt.unset("OPAL_HIP_SWAP")
     short = [s[:1000] for s in db]  # (no tail at all: nothing outlasts the search on the chain by enough to move)
-    for st, seqs, expect in ((0, db + tail, True), (1, db + tail, False), (0, short, False)):
+    for st, seqs, expect in ((0, db + tail, True), (1, db + tail, True), (0, short, False)):
         before = _swapped(ours)
         got = ours.search(q, seqs, 3, 1, m, st, MODES["SW"])[:4]
         n = _swapped(ours) - before
