@@ -155,7 +155,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
     // Can the classes run as one grid? (bulk on G0 lanes, the others on 2*G0 and 4*G0, all on the same arithmetic)
     const LaunchClass& bulk = classes.back();
     const int skewBulk = maySkew && skew_ok(bulk.first);
-    bool oneGrid = uberEligible && classes.size() <= 3 && bulk.wpb == 4 && bulk.ldsPad == 0 &&
+    bool oneGrid = uberEligible && classes.size() <= 3 && bulk.wpb == 4 && (bulk.ldsPad == 0 || opts().uberLdsPad) &&
                    opal_hip_uber_supported(c.mode, swEndPass, skewBulk, bulk.rows);
     for (size_t ki = 0; oneGrid && ki + 1 < classes.size(); ki++) {
         const LaunchClass& k = classes[ki];
@@ -169,6 +169,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
         fill_launch(u.base, cx, width, swEndPass, detectWrap, nullptr, ovfCounter);
         u.base.stream = stream;
         u.base.lanes_per_seq = bulk.G; u.base.rows_per_lane = bulk.rows; u.base.waves_per_block = 4; u.base.skew = skewBulk;
+        u.base.lds_bytes_min = bulk.ldsPad;  // (an LDS request padded so that every SIMD holds an even number of waves)
         for (const LaunchClass& k : classes) {
             const int a = std::max(k.first, i0), b = std::min(k.first + k.count, i1);
             const int n = std::max(0, b - a);

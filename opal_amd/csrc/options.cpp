@@ -97,6 +97,7 @@ const std::vector<Desc>& table() {
         flag("OPAL_HIP_NO_SKEW", &Options::noSkew),
         flag("OPAL_HIP_NO_UBER", &Options::noUber),
         flag("OPAL_HIP_UBER_ONLY", &Options::uberOnly),
+        flag("OPAL_HIP_UBER_LDS_PAD", &Options::uberLdsPad),
         flag("OPAL_HIP_NO_SLICES", &Options::noSlices),
         {"OPAL_HIP_SLICES", [](Options& o, const char* v) {
              std::vector<int> out;

@@ -50,6 +50,7 @@ struct Options {
     bool noSkew = false;              // OPAL_HIP_NO_SKEW: NW/HW/OV on the unskewed kernels
     bool noUber = false;              // OPAL_HIP_NO_UBER: length classes as separate launches
     bool uberOnly = false;            // OPAL_HIP_UBER_ONLY: keep the one-launch chain whatever the tail
+    bool uberLdsPad = true;           // OPAL_HIP_UBER_LDS_PAD=0: length classes as separate launches when the bulk wants a padded LDS request (round 3)
     bool noSlices = false;            // OPAL_HIP_NO_SLICES: no sliced launches while the database arrives
     std::vector<int> slices;          // OPAL_HIP_SLICES "a,b,..": upload chunks per slice
     int sliceStreams = 1;             // OPAL_HIP_SLICE_STREAMS: serial (0) / alternate (1, default) / separate (2)
