@@ -783,6 +783,52 @@ def test_randomized_differential_streaming(seed, ours, oracle, opal_opt):
         assert (got[2] == want[2]).all() and (got[3] == want[3]).all(), what
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OPAL_TEST_SEEDS", "10"))))  # (OPAL_TEST_SEEDS=400: a one-off stress run)
+def test_randomized_differential_round4_paths(seed, ours, oracle, opal_opt):
+    """Randomized shapes aimed at what round 4 changed in the class kernels and at the role-swapped kernel: matrices scaled
+    so that scores and the skew frame of the global modes (row position + column, times the gap extension) come close to the
+    16-bit limit -- the host's safety bound decides kernel by kernel between the skewed 16-bit, the plain 16-bit and the
+    32-bit path, and a wrong decision is a silently wrong score --, gap extensions up to 25, sequences shorter than the lane
+    pipeline (the fill steps run in a loop of their own), every lanes-per-sequence value, and for SW a forced number of
+    longest targets on the swapped kernel (8 or 16 rows per lane, scores and end cells)."""
+    rng = np.random.RandomState(9100 + seed)
+    for _ in range(6):
+        A = int(rng.choice([4, 20, 24]))
+        scale = int(rng.choice([1, 1, 3, 7, 13, 40]))
+        m = (rng.randint(-5, 12, size=(A, A)) * scale).astype(np.int32)
+        m = ((m + m.T) // 2).astype(np.int32)
+        np.fill_diagonal(m, rng.randint(4, 14) * scale)
+        go = int(rng.choice([0, 1, 3, 11, 40])) * (scale if rng.rand() < 0.5 else 1)
+        ge = int(rng.choice([0, 1, 1, 2, 5, 25]))
+        qlen = int(rng.choice([1, 3, 30, 64, 110, 200, 300, 333, 420, 640]))
+        n = int(rng.randint(5, 160))
+        lens = np.maximum(1, (rng.lognormal(5.0, 1.1, size=n)).astype(int)); lens = np.minimum(lens, 2500)
+        lens[rng.randint(0, n)] = int(rng.choice([1, 2, 5, 7]))            # shorter than any lane pipeline
+        if rng.rand() < 0.6:
+            for _k in range(int(rng.randint(1, 4))):
+                lens[rng.randint(0, n)] = int(rng.choice([511, 512, 513, 1024, 1025, 3000, 6000, 9000]))  # swapped-kernel chunk sizes
+        q = rng.randint(0, A, size=qlen).astype(np.uint8)
+        db = [rng.randint(0, A, size=int(L)).astype(np.uint8) for L in lens]
+        for i in range(0, n, 4):  # near copies of the query: high scores
+            L = len(db[i]); k = min(L, qlen); at = int(rng.randint(0, L - k + 1))
+            db[i][at:at + k] = np.where(rng.rand(k) < 0.85, q[:k], db[i][at:at + k])
+        mode = str(rng.choice(["SW", "SW", "NW", "HW", "OV"])); st = int(rng.randint(0, 2))
+        lanes = str(rng.choice(["", "", "", "2", "8", "16", "64"]))
+        for name in ("OPAL_HIP_LANES_PER_SEQ", "OPAL_HIP_SWAP", "OPAL_HIP_SWAP_ROWS"):
+            opal_opt.unset(name)
+        swap = ""
+        if mode == "SW" and qlen <= 420 and rng.rand() < 0.7:
+            swap = str(int(rng.choice([1, 4, 25])))
+            opal_opt.set("OPAL_HIP_SWAP", swap)
+            opal_opt.set("OPAL_HIP_SWAP_ROWS", str(int(rng.choice([8, 16]))))
+        elif lanes and qlen <= 40 * int(lanes):
+            opal_opt.set("OPAL_HIP_LANES_PER_SEQ", lanes)
+        got = ours.search(q, db, go, ge, m, st, MODES[mode], int(rng.randint(0, 2)))[:4]
+        want = oracle.search(q, db, go, ge, m, st, MODES[mode])
+        what = f"round-4 seed {seed}: A={A} x{scale} Q={qlen} n={n} gaps {go}/{ge} {mode} st={st} lanes={lanes or 'auto'} swap={swap or 'auto'}"
+        _check(got, want, mode, what)
+
+
 @pytest.mark.parametrize("mode", ["SW", "OV"])
 def test_alignment_search_sharded_over_devices(mode, ours, opal_opt):
     """OPAL_SEARCH_ALIGNMENT with the call sharded over several devices ("0,0": two contexts on this box's one GPU): the
