@@ -722,9 +722,13 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
         // high-priority side stream. The two ranges share nothing but the buffers they index by their own sequences.
         void* join32 = nullptr;
         SearchCtx c32 = c;
-        if (chunkedQuery && P > q32 && (2 * p32 > nBad || (gplan.G && gplan.passes > 1 && q32 > p32)) && !opts().noSidePrefix) {
+        // (round 4: any query. On a database with a real length tail -- Swiss-Prot shape, 110-aa query -- the ten targets beyond
+        // 32 000 residues need 8 ms on the 32-bit kernels, and everything else waited behind them on the main stream: 14 ms for a
+        // search whose bulk takes 2.8. Unchunked queries use the stream of the swapped launches, which the global modes never
+        // need: the side streams 0..2 belong to the long classes of the 16-bit range.)
+        if (P > q32 && (2 * p32 > nBad || (chunkedQuery && gplan.G && gplan.passes > 1 && q32 > p32)) && !opts().noSidePrefix) {
             void* fork = db->event(8);
-            void* side = db->stream(0);
+            void* side = chunkedQuery ? db->stream(0) : db->swap();
             if (fork && side && !opal_hip_event_record(fork, st) && !opal_hip_stream_wait_event(side, fork)) { c32.stream = side; join32 = db->event(9); }
         }
         if (2 * p32 > nBad && launch_range(c32, 32, 0, 0, nullptr, nBad, 2 * p32 - nBad, seqLenOf, db->ovfCount.p + 1)) {

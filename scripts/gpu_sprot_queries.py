@@ -27,15 +27,16 @@ out = torch.zeros(n, dtype=torch.int32, device=dev)
 torch.cuda.synchronize()
 reps = int(os.environ.get("REPS", "7"))
 ST = int(os.environ.get("ST", "0"))  # 1: with end locations
+MODE = os.environ.get("MODE", "SW")
 e1 = torch.zeros(n, dtype=torch.int32, device=dev); e2 = torch.zeros(n, dtype=torch.int32, device=dev)
 torch.cuda.synchronize()
 for name in names:
     q = read_fasta(os.path.join(ROOT, "tests", "golden", "data", f"query_{name}.fasta"), alphabet)[0]
     ks = []
     for _ in range(reps):
-        rc, k = pdb.search_device(q, 3, 1, matrix, ST, MODES["SW"], out.data_ptr(), e1.data_ptr() if ST else 0, e2.data_ptr() if ST else 0)
+        rc, k = pdb.search_device(q, 3, 1, matrix, ST, MODES[MODE], out.data_ptr(), e1.data_ptr() if ST else 0, e2.data_ptr() if ST else 0)
         assert rc == 0
         ks.append(k)
     cells = len(q) * float(offs[-1])
     med = float(np.median(ks))
-    print(f"{name} Q={len(q)}: kernel ms median {med:.3f} min {min(ks):.3f} -> {cells / med / 1e6:.0f} GCUPS, frac of 9-instr bound {cells / med / 1e6 / 8738:.3f}; checksum {int(out.sum().item())}" + (f" end checksum {int(e1.sum().item())} {int(e2.sum().item())}" if ST else ""), flush=True)
+    print(f"{MODE} {name} Q={len(q)}: kernel ms median {med:.3f} min {min(ks):.3f} -> {cells / med / 1e6:.0f} GCUPS, frac of the {9 if MODE == 'SW' else 6}-instr bound {cells / med / 1e6 / (8738 if MODE == 'SW' else 13107):.3f}; checksum {int(out.sum().item())}" + (f" end checksum {int(e1.sum().item())} {int(e2.sum().item())}" if ST else ""), flush=True)
