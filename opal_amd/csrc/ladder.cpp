@@ -570,7 +570,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                 // the class kernels run with the roles swapped (swap_kernel.hpp) on a high-priority stream of their own,
                 // submitted first; everything else as usual beside them.
                 int swapRows = 0;
-                int swapN = (narrow == 17 && !chunkedQuery) ? plan_swap(Q, A, seqLenOf, 0, nNarrow, db->residues, &swapRows) : 0;
+                int swapN = (narrow == 17 && !chunkedQuery) ? plan_swap(Q, A, mode, seqLenOf, 0, nNarrow, db->residues, &swapRows) : 0;
                 if (wantEnd && swapRows > 16) swapRows = 16;  // (end cells: the 8- and 16-row shapes)
                 if (wantEnd && swapN > 0 && opal_hip_swap_lds_bytes(swapRows, Q, A) > 160 * 1024) swapN = 0;
                 void* joinSwap = nullptr;
@@ -717,6 +717,39 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
             nBad++;
         }
         if (nBad > 0) rc = OPAL_ERR_OVERFLOW;
+        // The longest targets with the roles swapped (swap_kernel.hpp, opal_swap_gl: int32, the target on the rows of a wave): every
+        // sequence the a-priori bounds send to the 32-bit rung -- a 35 213-residue target is 35 276 dependent steps of int32 rows
+        // there, 8 ms against a 110-aa query on a search whose bulk takes 3 -- and the 16-bit ones behind them that would outlast
+        // the search alone on the widest class. Items [nBad, nBad + swapG) on a high-priority stream of their own, submitted first;
+        // the 32-bit rung then has nothing left, the 16-bit range starts behind them.
+        int swapG = 0;
+        void* joinSwapG = nullptr;
+        if (!chunkedQuery && !gplan.G && narrow != 16 && P > 0) {
+            int rowsG = 0;
+            const int planned = plan_swap(Q, A, mode, seqLenOf, nBad, 2 * P - nBad, db->residues, &rowsG);
+            const int need32 = 2 * p32 - nBad;
+            const int want = std::max(planned, (rowsG && opts().swap != 0) ? need32 : 0);
+            if (rowsG && want > 0 && want <= 240 && want >= need32) swapG = std::min(want, 2 * P - nBad);
+            while (swapG > 0 && db->pairSeq[(size_t)nBad + swapG - 1] < 0) swapG--;  // (the absent last item of an odd count)
+            if (swapG > 0 && swapG < need32) swapG = 0;
+            if (swapG > 0) {
+                void* fork = db->event(11);
+                void* side = db->swap();
+                OpalHipLaunch a;
+                fill_launch(a, c, 32, 0, 0, nullptr, db->ovfCount.p + 1);
+                a.rows_per_lane = rowsG; a.first_item = nBad; a.num_items = swapG; a.stream = side;
+                if (debug_on()) fprintf(stderr, "[opal] swapped launch mode=%d: items [%d,+%d) (%d of them beyond the 16-bit bounds), %d rows per lane\n", mode, nBad, swapG, need32, rowsG);
+                if (!fork || !side || opal_hip_event_record(fork, st) || opal_hip_stream_wait_event(side, fork) || !gate_items(db, side, nBad, swapG) ||
+                    opal_hip_launch_swap(&a) || !(joinSwapG = db->event(12)) || opal_hip_event_record(joinSwapG, side)) {
+                    db->quiesce();
+                    return OPAL_ERR_NO_SIMD_SUPPORT;
+                }
+                count(CNT_SWAPPED, swapG);
+            }
+        }
+        // (what the swapped launch took is gone from both rungs: the 32-bit range is empty, the 16-bit one starts behind it)
+        const int first16 = swapG > 0 ? nBad + swapG : 2 * p32;
+        if (swapG > 0) { p32 = 0; q32 = 0; nBad = 0; }
         // A query beyond one wave runs in row chunks, one launch after the other; its 32-bit prefix (a few long sequences: every
         // chunk is one long lone-wave tail, 2 x 2.4 ms of a 26 ms 3000-aa NW search) runs BESIDE the 16-bit chunks on a
         // high-priority side stream. The two ranges share nothing but the buffers they index by their own sequences.
@@ -753,10 +786,11 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
         if (P > q32) {
             const int e = gplan.G ? launch_global_stream()
                         : narrow == 16 ? launch_range(c, 16, 0, 0, nullptr, p32, P - p32, pairLenOf, db->ovfCount.p)
-                                       : launch_range(c, narrow, 0, 0, nullptr, 2 * p32, 2 * (P - p32), seqLenOf, db->ovfCount.p);
+                                       : launch_range(c, narrow, 0, 0, nullptr, first16, 2 * P - first16, seqLenOf, db->ovfCount.p);
             if (e) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
         }
-        if ((c32.stream && opal_hip_stream_wait_event(st, join32)) || (join16 && opal_hip_stream_wait_event(st, join16))) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
+        if ((c32.stream && opal_hip_stream_wait_event(st, join32)) || (join16 && opal_hip_stream_wait_event(st, join16)) ||
+            (joinSwapG && opal_hip_stream_wait_event(st, joinSwapG))) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
     }
     if (evStop) { opal_hip_event_record(evStop, st); db->asyncEvents = db->asyncTimed; }
     // (a caller that copies the results back on the same stream and waits for that copy needs no wait of its own here)

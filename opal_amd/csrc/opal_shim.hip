@@ -587,10 +587,20 @@ extern "C" int opal_hip_swap_rows(int query_length, int alphabet_length) {
 extern "C" size_t opal_hip_swap_lds_bytes(int rows_per_lane, int query_length, int alphabet_length) {
     return opal_swap_lds(rows_per_lane, query_length, alphabet_length);
 }
+extern "C" int opal_hip_swap_gl_rows(int query_length, int alphabet_length) {
+    if (query_length < 1 || query_length > OPAL_HIP_SWAP_MAX_QUERY || alphabet_length < 1) return 0;
+    if (opal_swap_gl_lds(8, query_length, alphabet_length) <= 160 * 1024) return 8;  // (64 x 8 rows of 4-byte entries: 54 KB for a protein alphabet)
+    return 0;
+}
+extern "C" size_t opal_hip_swap_gl_lds_bytes(int rows_per_lane, int query_length, int alphabet_length) {
+    return opal_swap_gl_lds(rows_per_lane, query_length, alphabet_length);
+}
 extern "C" int opal_hip_launch_swap(const OpalHipLaunch* a) {
-    SwapFn fn = opal_swap_kernel(a->rows_per_lane, a->want_end);
-    const size_t lds = opal_swap_lds(a->rows_per_lane, a->query_length, a->alphabet_length);
-    if (!fn || a->mode != MODE_SW || (a->want_end && (!a->out_end_query || !a->out_end_target)) || a->work || a->query_length < 1 || a->query_length > OPAL_HIP_SWAP_MAX_QUERY || lds > 160 * 1024) {
+    const bool gl = a->mode != MODE_SW;
+    SwapFn fn = gl ? opal_swap_gl_kernel(a->mode, a->rows_per_lane) : opal_swap_kernel(a->rows_per_lane, a->want_end);
+    const size_t lds = gl ? opal_swap_gl_lds(a->rows_per_lane, a->query_length, a->alphabet_length)
+                          : opal_swap_lds(a->rows_per_lane, a->query_length, a->alphabet_length);
+    if (!fn || a->mode < 0 || a->mode > 3 || (a->want_end && (!a->out_end_query || !a->out_end_target)) || a->work || a->query_length < 1 || a->query_length > OPAL_HIP_SWAP_MAX_QUERY || lds > 160 * 1024) {
         snprintf(g_err, sizeof g_err, "unlaunchable swapped shape: rows=%d Q=%d A=%d", a->rows_per_lane, a->query_length, a->alphabet_length);
         fprintf(stderr, "[opal-hip] %s\n", g_err);
         return 2;

@@ -234,12 +234,16 @@ std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass, int sk
  * (Q + 63) steps per chunk of 64 x rows residues -- provided it is the faster place for the longest of them and there are
  * no more of them than CUs (one workgroup fills most of a CU's LDS: the kernel is for a handful of outliers, not a class).
  */
-int plan_swap(int Q, int A, LenView lenOf, int first, int count, long long residues, int* rowsOut) {
+int plan_swap(int Q, int A, int mode, LenView lenOf, int first, int count, long long residues, int* rowsOut) {
     *rowsOut = 0;
     const int forced = opts().swap;  // 0: never; N > 0 (test hook): the N longest items whatever the model says
     if (forced == 0) return 0;
-    int rows = opal_hip_swap_rows(Q, A);
-    if (opts().swapRows && opal_hip_swap_lds_bytes(opts().swapRows, Q, A) <= 160 * 1024) rows = opts().swapRows;  // test / tuning hook
+    const bool gl = mode != OPAL_MODE_SW;  // NW / HW / OV: the int32 swapped kernels (swap_kernel.hpp, opal_swap_gl)
+    int rows = gl ? opal_hip_swap_gl_rows(Q, A) : opal_hip_swap_rows(Q, A);
+    if (opts().swapRows) {  // test / tuning hook
+        const size_t need = gl ? opal_hip_swap_gl_lds_bytes(opts().swapRows, Q, A) : opal_hip_swap_lds_bytes(opts().swapRows, Q, A);
+        if (need <= 160 * 1024) rows = opts().swapRows;
+    }
     if (!rows || count <= 0) return 0;
     *rowsOut = rows;
     if (forced > 0) return std::min(forced, count);
@@ -248,10 +252,12 @@ int plan_swap(int Q, int A, LenView lenOf, int first, int count, long long resid
     const int S0 = (Q + G0 - 1) / G0;
     const int Gw = std::min(64, 4 * G0);
     const int Sw = (Q + Gw - 1) / Gw;
-    const double totalClocks = (double)residues / (64 / G0) * step_clocks(17, S0) / 1024.0;
+    // (global modes: 6-instruction rows in the bulk; the long targets mostly on the unskewed 8-instruction rows; the swapped
+    // int32 kernel at 9 per row)
+    const double totalClocks = (double)residues / (64 / G0) * (gl ? 2.15 * 6.5 * S0 + 90.0 : step_clocks(17, S0)) / 1024.0;
     const double budget = std::max(totalClocks * (opts().tailFraction > 0 ? opts().tailFraction : 0.7), 20000.0);
-    auto classClocks = [&](int len) { return (len + Gw - 1) * lone_step_clocks(17, Sw); };
-    auto swapClocks = [&](int len) { return (double)((len + 64 * rows - 1) / (64 * rows)) * (Q + 63) * lone_step_clocks(18, rows); };
+    auto classClocks = [&](int len) { return (len + Gw - 1) * (gl ? 4.8 * (8.0 * Sw + 28.0) : lone_step_clocks(17, Sw)); };
+    auto swapClocks = [&](int len) { return (double)((len + 64 * rows - 1) / (64 * rows)) * (Q + 63) * (gl ? 4.8 * (9.0 * rows + 20.0) : lone_step_clocks(18, rows)); };
     const int longest = lenOf(first);
     // (a clear win only: at 64 lanes on the chain the two are within 10 % of each other -- 390-aa query, 35 213 residues)
     if (classClocks(longest) <= budget || swapClocks(longest) >= 0.7 * classClocks(longest)) return 0;

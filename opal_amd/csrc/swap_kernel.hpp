@@ -245,3 +245,223 @@ __global__ void __launch_bounds__(SWAP_WAVES * 64, 1) opal_swap_sw(const SwapPar
 
 SwapFn opal_swap_kernel(int rows, int want_end);  // inst_swap.hip: rows per lane 8 / 16 / 24 / 40, with end cells 8 / 16 (nullptr: not instantiated)
 size_t opal_swap_lds(int rows, int Q, int A);  // LDS bytes of that shape
+
+// ------------------------------------------------------------------ NW / HW / OV with the roles swapped (int32)
+// The same idea for the global modes (reference src/opal.cpp:594-977 searchDatabase_; boundary conditions :671-689, core
+// :748-771, results :844-904): the longest targets of a search -- the ones whose a-priori bounds push them onto the 32-bit
+// kernels (a 35 213-residue target: 35 276 dependent steps of int32 rows, 8 ms against a 110-aa query and 17 ms against a
+// 513-aa one, on a search whose bulk takes 3 / 13 ms) and the ones that would sit on the widest 16-bit class as lone waves --
+// run with the TARGET on the rows of a wave (64 lanes x S residues per row chunk) and the query on the columns. 32-bit
+// arithmetic throughout: no range analysis decides anything here, and a lone wave is bound by latency, not by the half-rate
+// v_max_i32. In the swapped frame H'[t][q] = H[q][t]:
+//   column -1 (before the query):  H'[t][-1] = -Go - t*Ge (NW), 0 (HW, OV: leading target residues are free)
+//   row -1 (before the target):    H'[-1][q] = 0 (OV), -Go - q*Ge (NW, HW)
+//   NW  score H'[L-1][Q-1], end (Q-1, L-1)
+//   HW  score max_t H'[t][Q-1] (the LAST COLUMN), endQ = Q-1, endT = the smallest t holding it (opal.cpp:824-834: first column)
+//   OV  A = max_q H'[L-1][q] (the last ROW; the smallest q holding it), B = max_{t <= L-2} H'[t][Q-1] (smallest t);
+//       A > B: score A, end (q, L-1); otherwise score B, end (Q-1, t)   (opal.cpp:881-904)
+// Lanes hold ascending rows and the chunks run top to bottom, so "smallest t" is the first lane / first chunk that holds the
+// value, and "smallest q" the first step. The chunk's bottom row (H and the F input of the row below, two words per query
+// column) waits in LDS for the chunk below, as in opal_swap_sw.
+template <int S>
+__host__ __device__ inline int opal_swapgl_stride() { return opal_profile_stride(4, 64, S, 0); }
+template <int S>
+__host__ __device__ inline size_t opal_swapgl_lds_bytes(int Q, int A) {
+    return (size_t)(A + 1) * (size_t)opal_swapgl_stride<S>() + 4 * (size_t)(Q + 128) + 8 * (size_t)(Q + 66) + 48;
+}
+
+template <int MODE, int S>
+__global__ void __launch_bounds__(SWAP_WAVES * 64, 1) opal_swap_gl(const SwapParams p) {
+    constexpr int RB = 4;  // rows per LDS read (4-byte profile entries)
+    constexpr int SPAD = (S + RB - 1) / RB * RB;
+    constexpr int LANE_BYTES = opal_lane_bytes(4, S, 0);
+    constexpr int NBLK = SPAD / RB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int stride = opal_swapgl_stride<S>();
+    const int Q = p.Q, A = p.A, Go = p.Go, Ge = p.Ge;
+    unsigned* const qoff = reinterpret_cast<unsigned*>(lds + (size_t)(A + 1) * stride);
+    int* const bndH = reinterpret_cast<int*>(qoff + (Q + 128));
+    int* const bndF = bndH + (Q + 66);
+    unsigned char* const clkSlot = reinterpret_cast<unsigned char*>(bndF + (Q + 66));
+    clk_begin(p.clk, nullptr, clkSlot);
+
+    const int item = p.firstItem + (int)blockIdx.x;
+    const int seq = p.pairSeq[item];
+    const int L = seq >= 0 ? p.pairLen[item] : 0;
+    const uint64_t tb = p.seqOff[item];
+    const unsigned ldsBase = (unsigned)(uintptr_t)(opal_lds_u8*)lds;
+    const unsigned padOff = ldsBase + (unsigned)(A * stride);
+    constexpr int NEGINF = -(1 << 30);
+
+    // ---- once per target: column address table, the top boundary row (t = -1) of the first chunk, the pad letter's row
+    for (int i = threadIdx.x; i < Q + 128; i += blockDim.x) {
+        const int c = i - 63;
+        qoff[i] = (c >= 0 && c < Q) ? ldsBase + (unsigned)p.query[c] * (unsigned)stride : padOff;
+    }
+    for (int i = threadIdx.x; i < Q + 66; i += blockDim.x) {
+        // H'[-1][q] and the F input of row 0: F'[0][q] = H'[-1][q] - Go (F'[-1][q] = -inf)
+        const long long h = (MODE == MODE_OV) ? 0LL : -(long long)Go - (long long)i * Ge;
+        bndH[i] = (int)(h < NEGINF ? NEGINF : h);
+        bndF[i] = (int)(h - Go < NEGINF ? NEGINF : h - Go);
+    }
+    for (int i = threadIdx.x; i < 64 * SPAD; i += blockDim.x) {
+        const int k = i / SPAD, j = i - k * SPAD;
+        *reinterpret_cast<int*>(lds + (size_t)A * stride + k * LANE_BYTES + j * 4) = 0;  // (pad columns: nothing reads their results)
+    }
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int k = lane;
+    const int chunkRows = 64 * S;
+    const int nchunks = (L + chunkRows - 1) / chunkRows;
+    const unsigned qoffLane = (unsigned)(uintptr_t)(opal_lds_u8*)reinterpret_cast<unsigned char*>(qoff) + 4u * (unsigned)(63 - k);
+    const unsigned bndHBase = (unsigned)(uintptr_t)(opal_lds_u8*)reinterpret_cast<unsigned char*>(bndH);
+    const unsigned bndFBase = (unsigned)(uintptr_t)(opal_lds_u8*)reinterpret_cast<unsigned char*>(bndF);
+    typedef __attribute__((address_space(3))) unsigned lds_u32;
+    typedef __attribute__((address_space(3))) int lds_i32;
+
+    // results (per lane; reduced over the wave at the end)
+    int colBest = INT_MIN, colRow = INT_MAX;  // HW / OV: maximum of the last column over my rows (OV: rows <= L-2), smallest row holding it
+    int rowBest = INT_MIN, rowCol = -1;       // OV: maximum of the last row (t = L-1) over the columns, smallest column; NW: the final cell
+
+    for (int ch = 0; ch < nchunks; ch++) {
+        const int t0 = ch * chunkRows;
+        const int rowsHere = min(chunkRows, L - t0);
+        __syncthreads();
+        // ---- stage TP for rows [t0, t0 + 64 S): TP[a][k][j] = M[a][target[t]] (rows beyond the target: 0, they feed nothing real)
+        for (int i = threadIdx.x; i < 64 * S; i += blockDim.x) {
+            const int kk = i / S, j = i - kk * S;
+            const int t = t0 + i;
+            const int b = t < L ? (int)p.res[tb + (uint64_t)t] : -1;
+            unsigned char* dst = lds + kk * LANE_BYTES + j * 4;
+            for (int a = 0; a < A; a++) *reinterpret_cast<int*>(dst + (size_t)a * stride) = b >= 0 ? p.matrix[a * A + b] : 0;
+        }
+        __syncthreads();
+        if (wave != 0) continue;
+        __builtin_amdgcn_s_setprio(3);
+
+        const int usedLanes = (rowsHere + S - 1) / S;
+        const int nsteps = Q + usedLanes - 1;
+        const bool hasNext = ch + 1 < nchunks;
+        const int r0 = t0 + k * S;  // my first row
+        // column -1: H'[t][-1] and E'[t][0] = H'[t][-1] - Go
+        int Hp[S], En[S];
+#pragma unroll
+        for (int j = 0; j < S; j++) {
+            const long long hb = (MODE == MODE_NW) ? -(long long)Go - (long long)(r0 + j) * Ge : 0LL;
+            Hp[j] = (int)(hb < NEGINF ? NEGINF : hb);
+            En[j] = (int)(hb - Go < NEGINF ? NEGINF : hb - Go);
+        }
+        // what the lane below reads before my first column: H' of my last row at column -1
+        int outH = Hp[S - 1], outF = 0;
+        // H'[r0 - 1][-1]: the diagonal input of my first column (lane 0 of the first chunk: H'[-1][-1] = 0)
+        int diagIn = 0;
+        if (MODE == MODE_NW && r0 > 0) { const long long hb = -(long long)Go - (long long)(r0 - 1) * Ge; diagIn = (int)(hb < NEGINF ? NEGINF : hb); }
+        // the last row of the target, if it lies in this chunk: lane kL, register jL
+        const bool lastChunk = !hasNext;
+        const int kL = lastChunk ? (L - 1 - t0) / S : -1;
+        const int jL = lastChunk ? (L - 1 - t0) - kL * S : -1;
+        // my registers [0, jhi) hold rows of the target that count for the last column (OV: rows <= L-2)
+        const int lastCount = (MODE == MODE_OV) ? L - 1 : L;
+        int jhi = lastCount - r0;
+        jhi = jhi < 0 ? 0 : (jhi > S ? S : jhi);
+
+        unsigned offCur = *(lds_u32*)(uintptr_t)(qoffLane) + (unsigned)(k * LANE_BYTES);
+        unsigned offNxt = *(lds_u32*)(uintptr_t)(qoffLane + 4u) + (unsigned)(k * LANE_BYTES);
+        int bhCur = *(lds_i32*)(uintptr_t)(bndHBase), bfCur = *(lds_i32*)(uintptr_t)(bndFBase);
+        int4 pfirst = lds_ld16(offCur);
+        for (int s = 0; s < nsteps; s++) {
+            const unsigned offc = offCur;
+            const int4 pcur = pfirst;
+            const unsigned off2 = *(lds_u32*)(uintptr_t)(qoffLane + 4u * (unsigned)(s + 2)) + (unsigned)(k * LANE_BYTES);
+            const int bhNxt = *(lds_i32*)(uintptr_t)(bndHBase + 4u * (unsigned)(s + 1));
+            const int bfNxt = *(lds_i32*)(uintptr_t)(bndFBase + 4u * (unsigned)(s + 1));
+            pfirst = lds_ld16(offNxt);
+
+            int inH = (int)shr1((unsigned)outH);
+            int inF = (int)shr1((unsigned)outF);
+            inH = (k == 0) ? bhCur : inH;
+            inF = (k == 0) ? bfCur : inF;
+            const int c = s - k;  // my column
+            if (c >= 0) {  // (before my first column my boundary values must stay as they are)
+                int f = inF;
+                int diag = diagIn;
+                int4 pc = pcur;
+                static_for<NBLK>([&](auto rbc) {
+                    constexpr int rb = decltype(rbc)::value;
+                    int4 pn = pc;
+                    if constexpr (rb + 1 < NBLK) pn = lds_ld16(offc + (rb + 1) * RB * 4);
+                    const int P[4] = {pc.x, pc.y, pc.z, pc.w};
+#pragma unroll
+                    for (int i = 0; i < RB; i++) {
+                        constexpr int jb = rb * RB;
+                        const int j = jb + i;
+                        if (j < S) {
+                            // (reference core loop opal.cpp:748-771; E along the columns, F down the rows)
+                            const int e = En[j];
+                            const int d = diag + P[i];
+                            int h = d > e ? d : e;
+                            h = h > f ? h : f;
+                            const int hq = h - Go;
+                            const int e2 = e - Ge, f2 = f - Ge;
+                            En[j] = e2 > hq ? e2 : hq;
+                            f = f2 > hq ? f2 : hq;
+                            diag = Hp[j];
+                            Hp[j] = h;
+                        }
+                    }
+                    pc = pn;
+                });
+                outH = Hp[S - 1];
+                outF = f;
+                if (hasNext && k == 63 && c < Q) {
+                    *(lds_i32*)(uintptr_t)(bndHBase + 4u * (unsigned)c) = outH;
+                    *(lds_i32*)(uintptr_t)(bndFBase + 4u * (unsigned)c) = outF;
+                }
+                // ---- results
+                if (MODE != MODE_NW && c == Q - 1) {  // my rows of the LAST COLUMN: the smallest row holding their maximum
+                    int bv = INT_MIN, bj = -1;
+#pragma unroll
+                    for (int j = S - 1; j >= 0; j--)
+                        if (j < jhi && Hp[j] >= bv) { bv = Hp[j]; bj = j; }
+                    if (bj >= 0 && bv > colBest) { colBest = bv; colRow = r0 + bj; }  // (strict: earlier chunks hold smaller rows)
+                }
+                if (MODE != MODE_HW && k == kL && c < Q) {  // the LAST ROW of the target
+                    const int v = SelectRow<int, S, 0, S>::get(Hp, jL);
+                    if (MODE == MODE_NW) { if (c == Q - 1) { rowBest = v; rowCol = c; } }
+                    else if (v > rowBest) { rowBest = v; rowCol = c; }  // strict: the first column wins
+                }
+            }
+            diagIn = inH;
+            offCur = offNxt; offNxt = off2; bhCur = bhNxt; bfCur = bfNxt;
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+
+    if (wave == 0) {
+        // last column: the highest value, then the smallest row, over the lanes; last row: one lane holds it
+        int cb = colBest, cr = colRow, rbv = rowBest, rc = rowCol;
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) {
+            const int ocb = __shfl_xor(cb, dd, 64), ocr = __shfl_xor(cr, dd, 64);
+            if (ocb > cb || (ocb == cb && ocr < cr)) { cb = ocb; cr = ocr; }
+            const int orb = __shfl_xor(rbv, dd, 64), orc = __shfl_xor(rc, dd, 64);
+            if (orc >= 0 && (rc < 0 || orb > rbv)) { rbv = orb; rc = orc; }
+        }
+        if (lane == 0 && seq >= 0 && L > 0) {
+            int sc, eq, et;
+            if (MODE == MODE_NW) { sc = rbv; eq = Q - 1; et = L - 1; }
+            else if (MODE == MODE_HW) { sc = cb; eq = Q - 1; et = cr; }
+            else {  // OV (opal.cpp:881-904): the last target residue (our last row) wins only if strictly better
+                if (rc >= 0 && (cr == INT_MAX || rbv > cb)) { sc = rbv; eq = rc; et = L - 1; }
+                else { sc = cb; eq = Q - 1; et = cr; }
+            }
+            p.outScore[seq] = sc;
+            if (p.outEndQ) { p.outEndQ[seq] = eq; p.outEndT[seq] = et; }
+        }
+    }
+    clk_end(clkSlot);
+}
+
+SwapFn opal_swap_gl_kernel(int mode, int rows);   // inst_swap.hip: NW / HW / OV, rows per lane 8 / 16 (nullptr: not instantiated)
+size_t opal_swap_gl_lds(int rows, int Q, int A);

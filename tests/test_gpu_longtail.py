@@ -107,8 +107,11 @@ def test_longtail_search_score_and_end(qlen, base, gold, oracle):
         s, eq, et = out[mode]
         assert (eq >= 0).all() and (eq < qlen).all() and (et >= 0).all() and (et < lens).all()
     assert (out["SW"][0] > 0).all()
-    # which path: NW targets of more than ~32 000 residues cannot stay in 16 bits (gap extension alone exceeds the range)
-    assert paths["NW"]["width32"] >= 1
+    # which path: NW targets of more than ~32 000 residues cannot stay in 16 bits (gap extension alone exceeds the range): the
+    # 32-bit class kernels, or -- queries up to 1024 residues -- the role-swapped int32 kernels (round 4)
+    assert paths["NW"]["width32"] + paths["NW"]["swapped"] >= 1
+    if qlen <= 1024:
+        assert paths["NW"]["swapped"] >= 8 and paths["HW"]["swapped"] >= 8 and paths["OV"]["swapped"] >= 8 and paths["NW"]["width32"] == 0
     # a 2000-aa query on 100 000 sequences: the global modes stream their 16-bit part (the > 32 000-residue targets are on
     # the 32-bit rung, in row chunks: a 2000-row int32 profile exceeds the LDS); SW does not -- eight 35 213-residue
     # targets on 64 lanes each outlast the rest of this small database, so plan_stream leaves it to the class kernels

@@ -789,8 +789,8 @@ def test_randomized_differential_round4_paths(seed, ours, oracle, opal_opt):
     so that scores and the skew frame of the global modes (row position + column, times the gap extension) come close to the
     16-bit limit -- the host's safety bound decides kernel by kernel between the skewed 16-bit, the plain 16-bit and the
     32-bit path, and a wrong decision is a silently wrong score --, gap extensions up to 25, sequences shorter than the lane
-    pipeline (the fill steps run in a loop of their own), every lanes-per-sequence value, and for SW a forced number of
-    longest targets on the swapped kernel (8 or 16 rows per lane, scores and end cells)."""
+    pipeline (the fill steps run in a loop of their own), every lanes-per-sequence value, and a forced number of longest
+    targets on the swapped kernels (8 or 16 rows per lane, scores and end cells, all four modes)."""
     rng = np.random.RandomState(9100 + seed)
     for _ in range(6):
         A = int(rng.choice([4, 20, 24]))
@@ -817,7 +817,7 @@ def test_randomized_differential_round4_paths(seed, ours, oracle, opal_opt):
         for name in ("OPAL_HIP_LANES_PER_SEQ", "OPAL_HIP_SWAP", "OPAL_HIP_SWAP_ROWS"):
             opal_opt.unset(name)
         swap = ""
-        if mode == "SW" and qlen <= 420 and rng.rand() < 0.7:
+        if qlen <= 420 and rng.rand() < 0.7 and not (mode != "SW" and lanes):  # (SW: 16-bit swapped kernels; NW / HW / OV: the int32 ones)
             swap = str(int(rng.choice([1, 4, 25])))
             opal_opt.set("OPAL_HIP_SWAP", swap)
             opal_opt.set("OPAL_HIP_SWAP_ROWS", str(int(rng.choice([8, 16]))))

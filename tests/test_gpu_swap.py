@@ -87,6 +87,61 @@ def test_swapped_kernel_vs_oracle(qlen, rows, ours, oracle, opal_opt):
         np.testing.assert_array_equal(got[2][live], want[2][live], err_msg=f"swapped + end q{qlen} rows={rows} gaps {go}/{ge}: endQ")
 
 
+@pytest.mark.parametrize("rows", ["8", "16"])
+@pytest.mark.parametrize("mode", ["NW", "HW", "OV"])
+@pytest.mark.parametrize("qlen", [1, 7, 64, 110, 300, 513])
+def test_swapped_global_kernels_vs_oracle(qlen, mode, rows, ours, oracle, opal_opt):
+    """NW / HW / OV with the roles swapped (opal_swap_gl: int32, the target on the rows, boundary conditions and result rules
+    of reference src/opal.cpp:671-689, :844-904 in the transposed frame): the 20 longest targets forced onto it, scores and end
+    cells against the oracle -- targets of exactly one / two / three row chunks, one residue more or less, a partial chunk,
+    copies of the query across a chunk boundary and at the very end, gaps 11/1, 3/1, 0/0 and 5/5."""
+    from opal_amd import synth
+    from opal_amd.score_matrix import blosum50
+    q = synth.query(qlen, seed=qlen)
+    db = _database(q, int(rows), seed=qlen + int(rows) + 7)
+    db += [synth.query(1, seed=5), synth.query(2, seed=6)]  # (targets of one and two residues stay on the class kernels)
+    m = blosum50()[1]
+    opal_opt.set("OPAL_HIP_SWAP", "20")
+    opal_opt.set("OPAL_HIP_SWAP_ROWS", rows)
+    for go, ge in ((11, 1), (3, 1), (0, 0), (5, 5)):
+        for st in (1, 0):
+            before = _swapped(ours)
+            got = ours.search(q, db, go, ge, m, st, MODES[mode])[:4]
+            assert _swapped(ours) - before == 20, "the swapped kernel did not run"
+            want = oracle.search(q, db, go, ge, m, st, MODES[mode])
+            assert got[0] == want[0] == 0
+            what = f"swapped {mode} q{qlen} rows={rows} gaps {go}/{ge} st={st}"
+            np.testing.assert_array_equal(got[1], want[1], err_msg=what + ": score")
+            np.testing.assert_array_equal(got[2], want[2], err_msg=what + ": endQ")
+            np.testing.assert_array_equal(got[3], want[3], err_msg=what + ": endT")
+
+
+def test_swapped_global_kernels_take_the_32bit_targets(ours, oracle, opal_opt):
+    """Without forcing: targets beyond what 16 bits hold in the global modes (gap extension alone exceeds the range past
+    ~32 000 residues) and the long ones behind them go to the swapped kernels; the 32-bit class kernels stay idle."""
+    import ctypes as C
+    from opal_amd import synth
+    from opal_amd.score_matrix import blosum50
+    res, offs, lens = synth.database(20000, seed=42)
+    db = [res[offs[i]:offs[i + 1]] for i in range(20000)]
+    tail = [synth.query(L, seed=L) for L in (35213, 34000, 33000, 22000, 12000)]
+    m = blosum50()[1]
+    q = synth.query(110, seed=7)
+    seqs = db + tail
+    idx = list(range(len(seqs) - 5, len(seqs))) + list(range(0, len(seqs) - 5, 397))
+    for mode in ("HW", "OV", "NW"):
+        buf = (C.c_longlong * 10)(); ours.lib.opalx_counters(buf, 10)
+        w32, sw = int(buf[5]), int(buf[9])
+        got = ours.search(q, seqs, 3, 1, m, 1, MODES[mode])[:4]
+        ours.lib.opalx_counters(buf, 10)
+        assert int(buf[9]) - sw >= 3 and int(buf[5]) == w32, (mode, int(buf[9]) - sw, int(buf[5]) - w32)
+        want = oracle.search(q, [seqs[i] for i in idx], 3, 1, m, 1, MODES[mode])
+        assert got[0] == 0
+        np.testing.assert_array_equal(got[1][idx], want[1], err_msg=mode)
+        np.testing.assert_array_equal(got[2][idx], want[2], err_msg=mode)
+        np.testing.assert_array_equal(got[3][idx], want[3], err_msg=mode)
+
+
 def test_swapped_kernel_saturated_scores_rerun(ours, oracle, opal_opt):
     """Scores at the 16-bit limit leave the swapped kernel through the re-run list and come back from the 32-bit rung."""
     from opal_amd import synth
