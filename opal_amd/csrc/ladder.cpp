@@ -732,6 +732,9 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
             if (rowsG && want > 0 && want <= 240 && want >= need32) swapG = std::min(want, 2 * P - nBad);
             while (swapG > 0 && db->pairSeq[(size_t)nBad + swapG - 1] < 0) swapG--;  // (the absent last item of an odd count)
             if (swapG > 0 && swapG < need32) swapG = 0;
+            // (16 rows per lane -- half the steps -- measured for a handful of targets: 195-aa HW 6.5 -> 5.4 ms at best, but 9 ms in
+            // every other run: a 103 KB workgroup finds room only on a CU with at most one bulk workgroup, i.e. only if it gets
+            // there first; 54 KB fit beside three. 8 rows stay.)
             if (swapG > 0) {
                 void* fork = db->event(11);
                 void* side = db->swap();
