@@ -31,7 +31,8 @@ MODE = os.environ.get("MODE", "SW")
 e1 = torch.zeros(n, dtype=torch.int32, device=dev); e2 = torch.zeros(n, dtype=torch.int32, device=dev)
 torch.cuda.synchronize()
 for name in names:
-    q = read_fasta(os.path.join(ROOT, "tests", "golden", "data", f"query_{name}.fasta"), alphabet)[0]
+    # (a name that is a number: a synthetic query of that length)
+    q = synth.query(int(name), seed=7) if name.isdigit() else read_fasta(os.path.join(ROOT, "tests", "golden", "data", f"query_{name}.fasta"), alphabet)[0]
     ks = []
     for _ in range(reps):
         rc, k = pdb.search_device(q, 3, 1, matrix, ST, MODES[MODE], out.data_ptr(), e1.data_ptr() if ST else 0, e2.data_ptr() if ST else 0)
