@@ -149,8 +149,9 @@ int opal_hip_swap_rows(int query_length, int alphabet_length);
 size_t opal_hip_swap_lds_bytes(int rows_per_lane, int query_length, int alphabet_length);  /* (> 160 KiB: not launchable) */
 int opal_hip_launch_swap(const OpalHipLaunch* args);
 /* NW / HW / OV have role-swapped kernels too (int32 arithmetic, scores and end cells: out_end_* may be NULL): the same entry
-   with args->mode; rows per lane from opal_hip_swap_gl_rows (8; 16 exists). */
-int opal_hip_swap_gl_rows(int query_length, int alphabet_length);
+   with args->mode; rows per lane from opal_hip_swap_gl_rows: 16 (2-byte profile entries: every matrix entry must fit 16
+   bits) or 8 (4-byte entries). */
+int opal_hip_swap_gl_rows(int query_length, int alphabet_length, int matrix_fits_16);
 size_t opal_hip_swap_gl_lds_bytes(int rows_per_lane, int query_length, int alphabet_length);
 
 int opal_hip_device_count(void);

@@ -22,10 +22,10 @@ size_t opal_swap_lds(int rows, int Q, int A) {
 }
 
 SwapFn opal_swap_gl_kernel(int mode, int rows) {
-    if (rows == 8) return mode == MODE_NW ? (SwapFn)opal_swap_gl<MODE_NW, 8> : mode == MODE_HW ? (SwapFn)opal_swap_gl<MODE_HW, 8> : mode == MODE_OV ? (SwapFn)opal_swap_gl<MODE_OV, 8> : nullptr;
-    if (rows == 16) return mode == MODE_NW ? (SwapFn)opal_swap_gl<MODE_NW, 16> : mode == MODE_HW ? (SwapFn)opal_swap_gl<MODE_HW, 16> : mode == MODE_OV ? (SwapFn)opal_swap_gl<MODE_OV, 16> : nullptr;
+    if (rows == 8) return mode == MODE_NW ? (SwapFn)opal_swap_gl<MODE_NW, 8, 4> : mode == MODE_HW ? (SwapFn)opal_swap_gl<MODE_HW, 8, 4> : mode == MODE_OV ? (SwapFn)opal_swap_gl<MODE_OV, 8, 4> : nullptr;
+    if (rows == 16) return mode == MODE_NW ? (SwapFn)opal_swap_gl<MODE_NW, 16, 2> : mode == MODE_HW ? (SwapFn)opal_swap_gl<MODE_HW, 16, 2> : mode == MODE_OV ? (SwapFn)opal_swap_gl<MODE_OV, 16, 2> : nullptr;
     return nullptr;
 }
 size_t opal_swap_gl_lds(int rows, int Q, int A) {
-    return rows == 8 ? opal_swapgl_lds_bytes<8>(Q, A) : rows == 16 ? opal_swapgl_lds_bytes<16>(Q, A) : ((size_t)1 << 30);
+    return rows == 8 ? opal_swapgl_lds_bytes<8, 4>(Q, A) : rows == 16 ? opal_swapgl_lds_bytes<16, 2>(Q, A) : ((size_t)1 << 30);
 }

@@ -726,7 +726,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
         void* joinSwapG = nullptr;
         if (!chunkedQuery && !gplan.G && narrow != 16 && P > 0) {
             int rowsG = 0;
-            const int planned = plan_swap(Q, A, mode, seqLenOf, nBad, 2 * P - nBad, db->residues, &rowsG);
+            const int planned = plan_swap(Q, A, mode, seqLenOf, nBad, 2 * P - nBad, db->residues, &rowsG, fits16);
             const int need32 = 2 * p32 - nBad;
             const int want = std::max(planned, (rowsG && opts().swap != 0) ? need32 : 0);
             if (rowsG && want > 0 && want <= 240 && want >= need32) swapG = std::min(want, 2 * P - nBad);

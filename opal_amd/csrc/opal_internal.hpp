@@ -355,7 +355,7 @@ std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass, int sk
 bool plan_chunks(int width, int mode, int swEndPass, int Q, int A, long long nItems, double meanLen, int maxLen, int* G, int* rows, int* wpb);
 struct StreamPlan { int width = 0, G = 0, rows = 0, passes = 1; };  // passes > 1: the query runs in that many row chunks
 StreamPlan plan_stream(int Q, int A, int mode, int wantEnd, long long residues, int longest, int numSeqs);
-int plan_swap(int Q, int A, int mode, LenView lenOf, int first, int count, long long residues, int* rowsOut);  // items for swap_kernel.hpp (0: none)
+int plan_swap(int Q, int A, int mode, LenView lenOf, int first, int count, long long residues, int* rowsOut, bool fits16 = true);  // items for swap_kernel.hpp (0: none)
 
 bool args_fit_int32(int Go, int Ge, const int* M, int A);
 int ensure_query_buffers(OpalxDb* db, const unsigned char* query, int Q, const int* M, int A);

@@ -587,9 +587,12 @@ extern "C" int opal_hip_swap_rows(int query_length, int alphabet_length) {
 extern "C" size_t opal_hip_swap_lds_bytes(int rows_per_lane, int query_length, int alphabet_length) {
     return opal_swap_lds(rows_per_lane, query_length, alphabet_length);
 }
-extern "C" int opal_hip_swap_gl_rows(int query_length, int alphabet_length) {
+// 16 rows per lane hold 2-byte profile entries (the caller has checked that the matrix fits 16 bits), 8 rows 4-byte ones: the
+// same LDS (54 KB for a protein alphabet).
+extern "C" int opal_hip_swap_gl_rows(int query_length, int alphabet_length, int matrix_fits_16) {
     if (query_length < 1 || query_length > OPAL_HIP_SWAP_MAX_QUERY || alphabet_length < 1) return 0;
-    if (opal_swap_gl_lds(8, query_length, alphabet_length) <= 160 * 1024) return 8;  // (64 x 8 rows of 4-byte entries: 54 KB for a protein alphabet)
+    if (matrix_fits_16 && opal_swap_gl_lds(16, query_length, alphabet_length) <= 64 * 1024) return 16;
+    if (opal_swap_gl_lds(8, query_length, alphabet_length) <= 160 * 1024) return 8;
     return 0;
 }
 extern "C" size_t opal_hip_swap_gl_lds_bytes(int rows_per_lane, int query_length, int alphabet_length) {

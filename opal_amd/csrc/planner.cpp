@@ -234,15 +234,15 @@ std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass, int sk
  * (Q + 63) steps per chunk of 64 x rows residues -- provided it is the faster place for the longest of them and there are
  * no more of them than CUs (one workgroup fills most of a CU's LDS: the kernel is for a handful of outliers, not a class).
  */
-int plan_swap(int Q, int A, int mode, LenView lenOf, int first, int count, long long residues, int* rowsOut) {
+int plan_swap(int Q, int A, int mode, LenView lenOf, int first, int count, long long residues, int* rowsOut, bool fits16) {
     *rowsOut = 0;
     const int forced = opts().swap;  // 0: never; N > 0 (test hook): the N longest items whatever the model says
     if (forced == 0) return 0;
     const bool gl = mode != OPAL_MODE_SW;  // NW / HW / OV: the int32 swapped kernels (swap_kernel.hpp, opal_swap_gl)
-    int rows = gl ? opal_hip_swap_gl_rows(Q, A) : opal_hip_swap_rows(Q, A);
+    int rows = gl ? opal_hip_swap_gl_rows(Q, A, fits16 ? 1 : 0) : opal_hip_swap_rows(Q, A);
     if (opts().swapRows) {  // test / tuning hook
         const size_t need = gl ? opal_hip_swap_gl_lds_bytes(opts().swapRows, Q, A) : opal_hip_swap_lds_bytes(opts().swapRows, Q, A);
-        if (need <= 160 * 1024) rows = opts().swapRows;
+        if (need <= 160 * 1024 && !(gl && opts().swapRows == 16 && !fits16)) rows = opts().swapRows;
     }
     if (!rows || count <= 0) return 0;
     *rowsOut = rows;

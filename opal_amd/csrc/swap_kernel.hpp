@@ -263,21 +263,25 @@ size_t opal_swap_lds(int rows, int Q, int A);  // LDS bytes of that shape
 // Lanes hold ascending rows and the chunks run top to bottom, so "smallest t" is the first lane / first chunk that holds the
 // value, and "smallest q" the first step. The chunk's bottom row (H and the F input of the row below, two words per query
 // column) waits in LDS for the chunk below, as in opal_swap_sw.
-template <int S>
-__host__ __device__ inline int opal_swapgl_stride() { return opal_profile_stride(4, 64, S, 0); }
-template <int S>
+// ES: bytes per profile entry. 4: any matrix that passed the 32-bit argument check. 2: matrices whose entries fit 16 bits
+// (sign-extended on the way into the registers: one more instruction per row) -- twice the rows per lane in the same LDS,
+// half the steps per target; a lone wave's step is bound by its latency chain, not by its rows.
+template <int S, int ES>
+__host__ __device__ inline int opal_swapgl_stride() { return opal_profile_stride(ES, 64, S, 0); }
+template <int S, int ES>
 __host__ __device__ inline size_t opal_swapgl_lds_bytes(int Q, int A) {
-    return (size_t)(A + 1) * (size_t)opal_swapgl_stride<S>() + 4 * (size_t)(Q + 128) + 8 * (size_t)(Q + 66) + 48;
+    return (size_t)(A + 1) * (size_t)opal_swapgl_stride<S, ES>() + 4 * (size_t)(Q + 128) + 8 * (size_t)(Q + 66) + 48;
 }
 
-template <int MODE, int S>
+template <int MODE, int S, int ES>
 __global__ void __launch_bounds__(SWAP_WAVES * 64, 1) opal_swap_gl(const SwapParams p) {
-    constexpr int RB = 4;  // rows per LDS read (4-byte profile entries)
+    constexpr int RB = 16 / ES;  // rows per LDS read
     constexpr int SPAD = (S + RB - 1) / RB * RB;
-    constexpr int LANE_BYTES = opal_lane_bytes(4, S, 0);
+    constexpr int LANE_BYTES = opal_lane_bytes(ES, S, 0);
     constexpr int NBLK = SPAD / RB;
+    static_assert(ES == 4 || (ES == 2 && S % 2 == 0), "2-byte entries: the staging writes row pairs");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int stride = opal_swapgl_stride<S>();
+    const int stride = opal_swapgl_stride<S, ES>();
     const int Q = p.Q, A = p.A, Go = p.Go, Ge = p.Ge;
     unsigned* const qoff = reinterpret_cast<unsigned*>(lds + (size_t)(A + 1) * stride);
     int* const bndH = reinterpret_cast<int*>(qoff + (Q + 128));
@@ -304,9 +308,9 @@ __global__ void __launch_bounds__(SWAP_WAVES * 64, 1) opal_swap_gl(const SwapPar
         bndH[i] = (int)(h < NEGINF ? NEGINF : h);
         bndF[i] = (int)(h - Go < NEGINF ? NEGINF : h - Go);
     }
-    for (int i = threadIdx.x; i < 64 * SPAD; i += blockDim.x) {
-        const int k = i / SPAD, j = i - k * SPAD;
-        *reinterpret_cast<int*>(lds + (size_t)A * stride + k * LANE_BYTES + j * 4) = 0;  // (pad columns: nothing reads their results)
+    for (int i = threadIdx.x; i < 64 * (SPAD * ES / 4); i += blockDim.x) {
+        const int k = i / (SPAD * ES / 4), w = i - k * (SPAD * ES / 4);
+        *reinterpret_cast<int*>(lds + (size_t)A * stride + k * LANE_BYTES + w * 4) = 0;  // (pad columns: nothing reads their results)
     }
 
     const int lane = threadIdx.x & 63;
@@ -329,12 +333,27 @@ __global__ void __launch_bounds__(SWAP_WAVES * 64, 1) opal_swap_gl(const SwapPar
         const int rowsHere = min(chunkRows, L - t0);
         __syncthreads();
         // ---- stage TP for rows [t0, t0 + 64 S): TP[a][k][j] = M[a][target[t]] (rows beyond the target: 0, they feed nothing real)
-        for (int i = threadIdx.x; i < 64 * S; i += blockDim.x) {
-            const int kk = i / S, j = i - kk * S;
-            const int t = t0 + i;
-            const int b = t < L ? (int)p.res[tb + (uint64_t)t] : -1;
-            unsigned char* dst = lds + kk * LANE_BYTES + j * 4;
-            for (int a = 0; a < A; a++) *reinterpret_cast<int*>(dst + (size_t)a * stride) = b >= 0 ? p.matrix[a * A + b] : 0;
+        if constexpr (ES == 4) {
+            for (int i = threadIdx.x; i < 64 * S; i += blockDim.x) {
+                const int kk = i / S, j = i - kk * S;
+                const int t = t0 + i;
+                const int b = t < L ? (int)p.res[tb + (uint64_t)t] : -1;
+                unsigned char* dst = lds + kk * LANE_BYTES + j * 4;
+                for (int a = 0; a < A; a++) *reinterpret_cast<int*>(dst + (size_t)a * stride) = b >= 0 ? p.matrix[a * A + b] : 0;
+            }
+        } else {  // a thread owns a pair of rows: one 32-bit store per letter
+            for (int i = threadIdx.x; i < 64 * S / 2; i += blockDim.x) {
+                const int kk = i / (S / 2), j2 = i - kk * (S / 2);
+                const int t = t0 + kk * S + 2 * j2;
+                const int b0 = t < L ? (int)p.res[tb + (uint64_t)t] : -1;
+                const int b1 = t + 1 < L ? (int)p.res[tb + (uint64_t)t + 1] : -1;
+                unsigned char* dst = lds + kk * LANE_BYTES + j2 * 4;
+                for (int a = 0; a < A; a++) {
+                    const unsigned v0 = b0 >= 0 ? (unsigned)p.matrix[a * A + b0] & 0xffffu : 0u;
+                    const unsigned v1 = b1 >= 0 ? (unsigned)p.matrix[a * A + b1] & 0xffffu : 0u;
+                    *reinterpret_cast<unsigned*>(dst + (size_t)a * stride) = v0 | (v1 << 16);
+                }
+            }
         }
         __syncthreads();
         if (wave != 0) continue;
@@ -390,8 +409,13 @@ __global__ void __launch_bounds__(SWAP_WAVES * 64, 1) opal_swap_gl(const SwapPar
                 static_for<NBLK>([&](auto rbc) {
                     constexpr int rb = decltype(rbc)::value;
                     int4 pn = pc;
-                    if constexpr (rb + 1 < NBLK) pn = lds_ld16(offc + (rb + 1) * RB * 4);
-                    const int P[4] = {pc.x, pc.y, pc.z, pc.w};
+                    if constexpr (rb + 1 < NBLK) pn = lds_ld16(offc + (rb + 1) * RB * ES);
+                    int P[RB];
+                    if constexpr (ES == 4) { P[0] = pc.x; P[1] = pc.y; P[2] = pc.z; P[3] = pc.w; }
+                    else {
+                        P[0] = (pc.x << 16) >> 16; P[1] = pc.x >> 16; P[2] = (pc.y << 16) >> 16; P[3] = pc.y >> 16;
+                        P[4] = (pc.z << 16) >> 16; P[5] = pc.z >> 16; P[6] = (pc.w << 16) >> 16; P[7] = pc.w >> 16;
+                    }
 #pragma unroll
                     for (int i = 0; i < RB; i++) {
                         constexpr int jb = rb * RB;
@@ -463,5 +487,6 @@ __global__ void __launch_bounds__(SWAP_WAVES * 64, 1) opal_swap_gl(const SwapPar
     clk_end(clkSlot);
 }
 
-SwapFn opal_swap_gl_kernel(int mode, int rows);   // inst_swap.hip: NW / HW / OV, rows per lane 8 / 16 (nullptr: not instantiated)
+// inst_swap.hip: NW / HW / OV; rows per lane 8 with 4-byte profile entries, 16 with 2-byte ones (nullptr: not instantiated)
+SwapFn opal_swap_gl_kernel(int mode, int rows);
 size_t opal_swap_gl_lds(int rows, int Q, int A);
