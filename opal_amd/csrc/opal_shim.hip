@@ -577,7 +577,7 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
 // Rows per lane: a chunk profile of 64 x rows residues for every query letter. The workgroup shares its CU with the
 // search's other launches (whose workgroups need the LDS it leaves free: with 40 rows -- 133 KB -- every swapped target
 // blocked a whole CU for the bulk launch, 20 % of the chip for most of a Swiss-Prot-shaped search), and its own per-step
-// overhead is small, so the default is the largest shape within 64 KB (8 rows for a protein alphabet: 29 KB; 16 rows pad to 80 KB).
+// overhead is small, so the default is the largest shape within 64 KB (16 rows for a protein alphabet: 55 KB).
 extern "C" int opal_hip_swap_rows(int query_length, int alphabet_length) {
     if (query_length < 1 || query_length > OPAL_HIP_SWAP_MAX_QUERY || alphabet_length < 1) return 0;
     for (int rows : {40, 24, 16, 8})

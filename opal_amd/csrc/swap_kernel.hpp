@@ -50,8 +50,10 @@ typedef void (*SwapFn)(const SwapParams);
 
 // LDS: the target profile of one row chunk, the column address table (Q + 128 words: 63 pad columns in front, 65 behind),
 // the chunk boundary row (Q + 66 words), the score matrix as 16-bit entries, the probe slot.
+// (no odd-unit padding of a lane's segment as the throughput kernels have it: a lone wave does not care about a two-way
+// bank conflict, and 16 rows per lane then take 52 KB instead of 80)
 template <int S>
-__host__ __device__ inline int opal_swap_stride() { return opal_profile_stride(2, 64, S, 1); }
+__host__ __device__ inline int opal_swap_stride() { return opal_profile_stride(2, 64, S, 0); }
 template <int S>
 __host__ __device__ inline size_t opal_swap_lds_bytes(int Q, int A) {
     return (size_t)(A + 1) * (size_t)opal_swap_stride<S>() + 4 * (size_t)(Q + 128) + 4 * (size_t)(Q + 66) + (((size_t)A * A * 2 + 15) & ~(size_t)15) + 48;
@@ -71,7 +73,7 @@ __global__ void __launch_bounds__(SWAP_WAVES * 64, 1) opal_swap_sw(const SwapPar
     using reg = typename V::reg;
     constexpr int ES = 2, RB = 8;
     constexpr int SPAD = (S + RB - 1) / RB * RB;
-    constexpr int LANE_BYTES = opal_lane_bytes(ES, S, 1);
+    constexpr int LANE_BYTES = opal_lane_bytes(ES, S, 0);
     constexpr int NBLK = SPAD / RB;
     static_assert(S % 2 == 0, "rows per lane: even (the staging writes row pairs)");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
