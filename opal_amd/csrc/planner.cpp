@@ -257,7 +257,12 @@ int plan_swap(int Q, int A, int mode, LenView lenOf, int first, int count, long 
     const double totalClocks = (double)residues / (64 / G0) * (gl ? 2.15 * 6.5 * S0 + 90.0 : step_clocks(17, S0)) / 1024.0;
     const double budget = std::max(totalClocks * (opts().tailFraction > 0 ? opts().tailFraction : 0.7), 20000.0);
     auto classClocks = [&](int len) { return (len + Gw - 1) * (gl ? 4.8 * (8.0 * Sw + 28.0) : lone_step_clocks(17, Sw)); };
-    auto swapClocks = [&](int len) { return (double)((len + 64 * rows - 1) / (64 * rows)) * (Q + 63) * (gl ? 4.8 * (9.0 * rows + 20.0) : lone_step_clocks(18, rows)); };
+    // A swapped step is a latency chain with a large fixed part (address -> LDS -> first row, lane hand-off): measured on the
+    // published shape, clocks per step: the 16-bit SW kernel 600 at 8 rows per lane, 1 900 at 40; the int32 global kernels 730
+    // at 8 rows, 1 060 at 16. (With the first, optimistic model -- 4.8 clocks per instruction -- the planner sent the 5 000-residue
+    // targets of the C2 database to the int32 kernel: C3 NW / HW / OV 1.15 -> 1.67 ms.)
+    const double swapStep = gl ? 5.0 * (8.3 * rows + 80.0) : 275.0 + 40.6 * rows;
+    auto swapClocks = [&](int len) { return (double)((len + 64 * rows - 1) / (64 * rows)) * (Q + 63) * swapStep; };
     const int longest = lenOf(first);
     // (a clear win only: at 64 lanes on the chain the two are within 10 % of each other -- 390-aa query, 35 213 residues)
     if (classClocks(longest) <= budget || swapClocks(longest) >= 0.7 * classClocks(longest)) return 0;

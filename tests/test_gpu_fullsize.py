@@ -22,12 +22,21 @@ def c2():
 
 
 def test_c2_sw_sampled_vs_oracle_and_properties(c2, oracle):
+    import ctypes as C
+    from opal_amd import _lib
     pdb, q, m = c2["pdb"], c2["q"], c2["m"]
     out = {}
+    buf = (C.c_longlong * 10)()
+    _lib.lib().opalx_counters(buf, 10)
+    swapped0 = int(buf[9])
     for mode in ("SW", "OV", "HW", "NW"):
         rc, s, eq, et = pdb.search(q, 11, 1, m, 1, oracle_lib.MODES[mode])
         assert rc == 0
         out[mode] = (s, eq, et)
+    # a database without a length tail (clamped at 5 000 residues) and a 300-aa query: nothing belongs on the role-swapped
+    # kernels (an optimistic planner model once sent the 5 000-residue targets there: C3 NW / HW / OV 1.15 -> 1.67 ms)
+    _lib.lib().opalx_counters(buf, 10)
+    assert int(buf[9]) == swapped0, "the planner sent targets of a tail-less database to the swapped kernels"
     # relaxation order: every global alignment is a semi-global one, etc.
     assert (out["SW"][0] >= out["OV"][0]).all() and (out["OV"][0] >= out["HW"][0]).all() and (out["HW"][0] >= out["NW"][0]).all()
     # NW/HW end at the last query row; NW at the last target column
