@@ -10,6 +10,8 @@ timeout 600 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $
 timeout 900 python3 bench.py --workload sprot > $OUT/bench_sprot.json 2> $OUT/bench_sprot.err
 timeout 300 python3 scripts/gpu_sprot_queries.py > $OUT/sprot_queries.txt 2>&1
 OPAL_HIP_SWAP=0 timeout 300 python3 scripts/gpu_sprot_queries.py O74807 P19930 > $OUT/sprot_queries_noswap.txt 2>&1
+for m in SW HW OV NW; do ST=1 MODE=$m timeout 300 python3 scripts/gpu_sprot_queries.py; done > $OUT/sprot_queries_end.txt 2>&1
+for m in SW HW OV NW; do OPAL_HIP_SWAP=0 ST=1 MODE=$m REPS=3 timeout 300 python3 scripts/gpu_sprot_queries.py O74807 P19930 P18080; done > $OUT/sprot_queries_end_noswap.txt 2>&1
 timeout 300 python3 scripts/gpu_api_e2e.py > $OUT/e2e.txt 2>&1
 timeout 1500 bash scripts/bench_configs.sh > $OUT/bench_configs.txt 2> $OUT/bench_configs.err
 ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c2_steady -- python3 $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e > $OUT/c2_steady.json 2> $OUT/c2_steady.err )
