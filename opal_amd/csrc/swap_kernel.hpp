@@ -64,8 +64,9 @@ __host__ __device__ inline size_t opal_swap_lds_bytes(int Q, int A) {
 // opal.cpp:385-401 pick the smallest target index first). Every lane keeps the best cell of its own rows: a column whose
 // maximum over the lane's rows improves the lane's running maximum replaces it (smallest row of that column), a column
 // that TIES with it replaces it only if it holds the value in a smaller row (it comes later, so its column is larger);
-// both only inside the query (pad columns can repeat a value, never create one) and only if the value reaches what the
-// whole wave had a few steps ago. The lanes hold ascending rows and the chunks run top to bottom, so the final choice is
+// both only inside the query (a pad column can repeat a value, never create one, and never exceeds what the same row
+// held in column Q-1: it got there by one step to the right and then down, column Q-1 gets it straight down) and only if the
+// value reaches what the whole wave had a few steps ago. The lanes hold ascending rows and the chunks run top to bottom, so the final choice is
 // the highest score, then the smallest global row.
 template <int S, bool END = false>
 __global__ void __launch_bounds__(SWAP_WAVES * 64, 1) opal_swap_sw(const SwapParams p) {

@@ -29,6 +29,8 @@ for c in $CFGS; do
     q3000nw) ARGS="--workload c5 --total-seqs 100000 --qlen 3000 --mode NW --search-type 1" ;;
     q3000end) ARGS="--workload c5 --total-seqs 100000 --qlen 3000 --search-type 1" ;;
     sprot) ARGS="--workload sprot" ;;
+    sprotend) ARGS="--workload sprot --search-type 1" ;;
+    c4end) ARGS="--workload c4 --total-seqs 625000 --search-type 1" ;;
     sprot110) ARGS="--workload sprot --query-fasta $GRAFT_REPO_ROOT/tests/golden/data/query_O74807.fasta" ;;
     sprot195) ARGS="--workload sprot --query-fasta $GRAFT_REPO_ROOT/tests/golden/data/query_P19930.fasta" ;;
     sprot390) ARGS="--workload sprot --query-fasta $GRAFT_REPO_ROOT/tests/golden/data/query_Q3ZAI3.fasta" ;;

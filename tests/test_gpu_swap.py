@@ -183,3 +183,42 @@ def test_swapped_kernel_is_what_a_long_tail_runs_on(ours, oracle, opal_opt):
     before = _swapped(ours)
     assert ours.search(synth.query(600, seed=7), db + tail, 3, 1, m, 0, MODES["SW"])[0] == 0
     assert _swapped(ours) == before, "a 600-aa query reaches 64 lanes on the class kernels"
+
+
+@pytest.mark.parametrize("rows", ["8", "16"])
+@pytest.mark.parametrize("gaps", [(0, 1), (0, 0), (0, 3), (1, 1)])
+def test_swapped_end_cell_with_free_gap_opening_at_the_last_query_column(rows, gaps, ours, oracle, opal_opt):
+    """gapOpen = 0: a score reached in the LAST query column flows on, undiminished, down every row below it (F hands it on
+    for free) and through the pad columns behind the query (E keeps it). Every lane further down the chunk then holds the
+    final score too -- in the real column Q-1 already, never first in a pad column (a pad cell's value has gone one step to the
+    right and then down, the cell of column Q-1 in the same row gets it by going straight down: never less) -- and the
+    reduction must pick the smallest target index among them, not a cell a lane kept from an earlier row chunk. The query's last
+    letter occurs once in each long target (third row chunk), so the score is first reached exactly there (reference tie
+    rule: opal.h:44-45)."""
+    rng = np.random.RandomState(int(rows) * 10 + gaps[1])
+    A = 24
+    m = np.full((A, A), -3, np.int32)
+    np.fill_diagonal(m, 5)
+    q = rng.randint(0, 20, 30).astype(np.uint8)
+    q[-1] = 23
+    chunk = 64 * int(rows)
+    db = [rng.randint(0, 20, int(L)).astype(np.uint8) for L in rng.randint(50, 400, 60)]
+    where = []
+    for n in range(6):
+        t = rng.randint(0, 20, 3 * chunk + 17 * n).astype(np.uint8)
+        at = 2 * chunk + 5 + 61 * n  # third chunk, a different lane every time
+        t[at] = 23
+        where.append(at)
+        db.append(t)
+    opal_opt.set("OPAL_HIP_SWAP", "6")
+    opal_opt.set("OPAL_HIP_SWAP_ROWS", rows)
+    before = _swapped(ours)
+    got = ours.search(q, db, gaps[0], gaps[1], m, 1, MODES["SW"])[:4]
+    assert _swapped(ours) - before == 6
+    want = oracle.search(q, db, gaps[0], gaps[1], m, 1, MODES["SW"])
+    assert got[0] == want[0] == 0
+    if gaps[0] == 0:
+        assert list(want[3][-6:]) == where and (want[2][-6:] == len(q) - 1).all(), "the construction: score first reached at the rare letter"
+    np.testing.assert_array_equal(got[1], want[1])
+    np.testing.assert_array_equal(got[3], want[3])
+    np.testing.assert_array_equal(got[2], want[2])
