@@ -222,3 +222,30 @@ def test_swapped_end_cell_with_free_gap_opening_at_the_last_query_column(rows, g
     np.testing.assert_array_equal(got[1], want[1])
     np.testing.assert_array_equal(got[3], want[3])
     np.testing.assert_array_equal(got[2], want[2])
+
+
+@pytest.mark.parametrize("mode", ["SW", "HW", "NW"])
+def test_swapped_kernels_in_a_call_sharded_over_devices(mode, ours, oracle, opal_opt):
+    """The same long-tailed database through opalSearchDatabase sharded over two device contexts ("0,0": both on this box's
+    one GPU): every shard plans its own swapped prefix on its own side stream; results as unsharded, as the oracle's."""
+    from opal_amd import synth
+    from opal_amd.score_matrix import blosum50
+    res, offs, lens = synth.database(20000, seed=43)
+    db = [res[offs[i]:offs[i + 1]] for i in range(20000)]
+    tail = [synth.query(L, seed=L) for L in (35213, 34000, 30000, 22000, 12000, 9000)]
+    seqs = db + tail
+    m = blosum50()[1]
+    q = synth.query(110, seed=9)
+    opal_opt.unset("OPAL_HIP_SWAP")
+    one = ours.search(q, seqs, 3, 1, m, 1, MODES[mode])[:4]
+    opal_opt.set("OPAL_HIP_DEVICES", "0,0")
+    before = _swapped(ours)
+    two = ours.search(q, seqs, 3, 1, m, 1, MODES[mode])[:4]
+    assert _swapped(ours) - before >= 4, "the shards did not use the swapped kernels"
+    assert one[0] == two[0] == 0
+    for a, b in zip(one[1:], two[1:]):
+        np.testing.assert_array_equal(a, b)
+    idx = list(range(len(seqs) - 6, len(seqs))) + list(range(0, len(seqs) - 6, 397))
+    want = oracle.search(q, [seqs[i] for i in idx], 3, 1, m, 1, MODES[mode])
+    for a, b in zip(two[1:], want[1:4]):
+        np.testing.assert_array_equal(a[idx], b)
