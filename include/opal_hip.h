@@ -202,6 +202,9 @@ int opal_hip_max_waves_per_block(int width);
 int opal_hip_kernel_vgprs(const OpalHipLaunch* args);
 /* Bytes of LDS the launch would need (query profile), for the scheduler's shape choice. */
 size_t opal_hip_lds_bytes(int width, int lanes_per_seq, int rows_per_lane, int alphabet_length);
+/* ... and what a single-launch width-17 SW search WITH end locations adds to it: the column buffer of every slot of a
+   workgroup (two rows per word + the lane number, in whole 16-byte stores), where the column holding a slot's best cell waits for its one row scan. */
+size_t opal_hip_swend_ckpt_bytes(int lanes_per_seq, int rows_per_lane, int waves_per_block);
 const char* opal_hip_last_error(void);
 /* Timing helpers for bench.py: HIP events on the stream the kernels run on. */
 void* opal_hip_event_create(void);

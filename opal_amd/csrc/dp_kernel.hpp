@@ -44,6 +44,7 @@
 #define FLAG_WRAP 2   // width 32 SW: detect 32-bit wrap of ulH + P (reference opal.cpp:302-303,339-351)
 #define FLAG_MULTI 4  // the query is processed in several row chunks; the boundary row travels through HBM
 #define FLAG_SKEW 8   // width 17, NW/HW/OV: diagonal-skewed values, no gap-extension subtractions (see row_skew)
+#define FLAG_NOCKPT 32  // SW with end location without the column checkpoint in LDS (class bodies inside a streaming launch: its LDS is laid out otherwise)
 #define FLAG_ZC 16    // zero-copy search: the residues are read from pinned host memory and every one is also stored to
                       // KParams::resOut, the device copy (own instantiations: the store costs the SW score kernel 2.2 %)
 
@@ -409,6 +410,34 @@ template <typename V, int S, int J> struct OvColumnRow {
     }
 };
 
+// Words of a slot's column buffer (CKPT): two rows per word, then the lane number, padded to whole 16-byte stores.
+__host__ __device__ constexpr int opal_swend_ckpt_words(int S) { return ((S + 1) / 2 + 1 + 3) / 4 * 4; }
+
+// Maximum of an unsigned value over the 2^log2G lanes of a slot, left in every lane of it (all lanes of the wave active).
+// Lanes 1, 2, 4, 8 apart through DPP (quad permutes, then the two mirrors: once the quads agree, mirroring eight lanes
+// pairs every quad with its neighbour, mirroring sixteen pairs the two halves); 16 and 32 apart through the LDS crossbar.
+// (`s_nop 1`: the two wait states between a VALU write and a DPP read of the same register -- inside an asm statement the
+// compiler does not add them.)
+__device__ __forceinline__ unsigned slot_max_u32(unsigned x, const int log2G) {
+    if (log2G >= 1) {
+        asm("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(x));
+        if (log2G >= 2) {
+            asm("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(x));
+            if (log2G >= 3) {
+                asm("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(x));
+                if (log2G >= 4) {
+                    asm("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(x));
+                    if (log2G >= 5) {
+                        { const unsigned o = (unsigned)__shfl_xor((int)x, 16, 64); x = o > x ? o : x; }
+                        if (log2G >= 6) { const unsigned o = (unsigned)__shfl_xor((int)x, 32, 64); x = o > x ? o : x; }
+                    }
+                }
+            }
+        }
+    }
+    return x;
+}
+
 // ------------------------------------------------------------------ the DP kernel
 // (the second launch bound asks the register allocator for 4 waves per SIMD, i.e. at most 128 VGPRs, on the single-launch
 // plain-16-bit kernels: OV at 38-39 rows per lane compiled to 129-131 registers without it, one wave per SIMD less)
@@ -427,6 +456,13 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
     constexpr bool MULTI = (FLAGS & FLAG_MULTI) != 0;
     constexpr bool PLAIN = WIDTH == 17 || WIDTH == 18;  // one sequence per lane, plain 16-bit instructions
     constexpr bool SKEW = (FLAGS & FLAG_SKEW) != 0 && WIDTH == 17 && MODE != MODE_SW && !MULTI;
+#ifndef OPAL_SWEND_CKPT
+#define OPAL_SWEND_CKPT 1
+#endif
+    // SW with end location, single launch: the best cell of a SLOT is kept exactly, step by step (two DPP reductions over the
+    // slot's lanes), and the column that holds it waits in LDS -- its rows are scanned once per sequence, not at every
+    // improvement (see the column loop).
+    constexpr bool CKPT = OPAL_SWEND_CKPT != 0 && MODE == MODE_SW && (FLAGS & FLAG_SWEND) != 0 && WIDTH == 17 && !MULTI && (FLAGS & FLAG_NOCKPT) == 0;
     // NW and OV read the first row block of the NEXT step's profile column at the top of the current step (measured on
     // the C3 workload: NW 1.183 -> 1.117 ms, OV 1.266 -> 1.248 ms; HW and SW gain nothing from it and the 4 extra live
     // registers push their 39/40-row shapes over 128, so they read it at the start of their own step; OV had it in round 2
@@ -680,6 +716,12 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
 
     reg bestF = V::splat(-32768);            // SKEW, HW/OV: last-row maximum so far, in the skewed frame of the step at hand
     int slotMax = 0;                         // SW end location: slot-wide running maximum (see the scan filter)
+    // CKPT: the slot's best cell so far (the same in every lane of the slot) and its column buffer behind the profile and the
+    // probe slot: two rows per word + the lane number, a multiple of four words per slot (opal_shim.hip adds them to the
+    // launch's LDS request)
+    int bestV = 0, bestC = INT_MIN;  // (INT_MIN: a tie at score 0 replaces nothing)
+    typedef __attribute__((address_space(3))) unsigned ckpt_word;
+    ckpt_word* const ckpt = (ckpt_word*)(opal_lds_u8*)(clkSlot + 48) + (size_t)((threadIdx.x >> 6) * (64 >> log2G) + ((threadIdx.x & 63) >> log2G)) * opal_swend_ckpt_words(S);
     int topHv = V::clampv(-(long long)Go);  // NW: H[-1][0]
     reg sRv = 0;                             // SKEW: s*Ge as a 16-bit value
     // One column step. MASKED: lanes before their first column sit the step out (NW/HW/OV; SW needs no test: its state is
@@ -693,7 +735,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
         for (int h = 0; h < NH; h++) offc[h] = offv[h];
         const int4 pcur = pfirst;
         if constexpr (PF_TOP) { advance(s + 1); pfirst = lds_ld16(offv[0]); }
-        if (MODE == MODE_SW && SWEND && NH == 1 && (s & 7) == 0) {
+        if (MODE == MODE_SW && SWEND && !CKPT && NH == 1 && (s & 7) == 0) {
             int v = V::half(mx, 0);
             for (int d = 1; d < G; d <<= 1) { const int o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
             slotMax = v;
@@ -772,7 +814,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
                             constexpr int n = (S - j0) < 4 ? (S - j0) : 4;
                             constexpr bool last = j0 + n == S;
                             const reg* Pn = &Pv[j0 - rb * RB + 1];  // profile of the row BELOW each row
-                            reg& acc = SWEND ? ch[(j0 / 4) * 2 / NBLK4H] : mx;
+                            reg& acc = CKPT ? cm : (SWEND ? ch[(j0 / 4) * 2 / NBLK4H] : mx);
                             V::template rows<KIND, n, last>(&Hp[j0], &En[j0], Pn, f, acc, d, t, SKEW ? GQs : Qs, Rs);
                         }
                     });
@@ -780,7 +822,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
                 });
                 if constexpr (LATE) pfirst = pc;
                 h = Hp[S - 1];
-                if constexpr (SWEND) cm = V::maxs(ch[0], ch[1]);
+                if constexpr (SWEND && !CKPT) cm = V::maxs(ch[0], ch[1]);
             } else {
 #pragma unroll
             for (int rb = 0; rb < SPAD / RB; rb++) {
@@ -833,7 +875,45 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
             outF = f;
             if (hasNext && k == G - 1 && c >= 0 && c < slotLen) p.bnd[bndIdx(c)] = make_uint2((unsigned)outH, (unsigned)outF);
 
-            if (MODE == MODE_SW && SWEND) {
+            if constexpr (CKPT) {
+                // End location in the same pass, exactly and per SLOT. The cell wanted is the one with the highest score, then
+                // the smallest column, then the smallest row (opal.h:44-45); bestV / bestC hold the slot's best score so far
+                // and its column, the same in every lane of the slot. A lane's column maximum matters only if it beats
+                // that -- a higher value, or the same value in a smaller column (the lanes of a slot sit on different
+                // columns, lane k on s - k; the same column comes to larger lanes = larger rows later, which never wins).
+                // Only when some lane of the WAVE has such a column do the slots settle who holds their best: one
+                // all-reduce of (value, lane) keys -- among the lanes of a slot that hold the step's highest value the
+                // LARGEST lane has the smallest column -- and the winner writes its column (H of its S rows) and its lane
+                // number to the slot's LDS buffer. The smallest row holding the score is looked up there once, after the
+                // last column. Before: a row scan, 2 instructions per row, for every improvement of any lane's own maximum
+                // -- with cheap gaps (scores grow along the whole sequence) in every step.
+                const unsigned cv = (unsigned)cm & 0xffffu;  // (SW values are >= 0)
+                const bool cand = (int)cv > bestV || ((int)cv == bestV && c < bestC);
+                if (__builtin_amdgcn_ballot_w64(cand)) {
+                    const unsigned key = slot_max_u32(cand ? ((cv << 6) | (unsigned)k) + 1u : 0u, log2G);
+                    if (key) {  // (the same in every lane of a slot)
+                        const unsigned kw = (key - 1u) & 63u;
+                        bestV = (int)((key - 1u) >> 6); bestC = s - (int)kw;
+                        if ((unsigned)k == kw) {
+                            // (two rows per word, four words per store: the LDS pipe is paid per instruction, whatever the
+                            // number of lanes writing -- 20 two-word stores of unpacked rows per change made LDS the bound)
+                            typedef unsigned ckpt_vec4 __attribute__((ext_vector_type(4)));
+                            typedef __attribute__((address_space(3))) ckpt_vec4 ckpt_quad;
+                            constexpr int NW = (S + 1) / 2;  // packed words
+                            unsigned pk[(NW + 3) / 4 * 4];
+#pragma unroll
+                            for (int w = 0; w < (NW + 3) / 4 * 4; w++)
+                                pk[w] = w < NW ? __builtin_amdgcn_perm(2 * w + 1 < S ? Hp[2 * w + 1] : 0u, Hp[2 * w], 0x05040100u) : (unsigned)k;
+#pragma unroll
+                            for (int w = 0; w < (NW + 3) / 4 * 4; w += 4) {
+                                ckpt_vec4 q4; q4.x = pk[w]; q4.y = pk[w + 1]; q4.z = pk[w + 2]; q4.w = pk[w + 3];
+                                *(ckpt_quad*)(ckpt + w) = q4;
+                            }
+                            if constexpr (NW % 4 == 0) ckpt[NW] = (unsigned)k;  // (otherwise the lane number sits in the padding words)
+                        }
+                    }
+                }
+            } else if (MODE == MODE_SW && SWEND) {
                 // End location in the same pass. cm = this column's maximum over my rows. Only a STRICT
                 // improvement of my running maximum can be the first cell holding the final score
                 // (smallest column first, opal.h:44-45); the row scan below runs for those columns only.
@@ -1007,6 +1087,14 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
         for (int hh = 0; hh < NH; hh++) {
             // best cell over the slot's lanes: highest score, then smallest column, then smallest lane (= rows)
             int sc = V::half(mx, hh), col = endCol[hh], row = endRow[hh], src = k;
+            if constexpr (CKPT) {  // the slot's best cell is known in every lane; its row: the smallest one of the kept column holding the score
+                sc = bestV; col = bestV > 0 ? bestC : INT_MAX;
+                int r = 0;
+#pragma unroll
+                for (int j = S - 1; j >= 0; j--)
+                    if (((ckpt[j / 2] >> (16 * (j & 1))) & 0xffffu) == (unsigned)sc) r = j;
+                row = q0 + (int)ckpt[(S + 1) / 2] * S - padTop + r;
+            } else
             for (int d = 1; d < G; d <<= 1) {
                 const int osc = __shfl_xor(sc, d, 64);
                 if (SWEND) {

@@ -292,6 +292,17 @@ static size_t lds_bytes(int width, int G, int rows, int A) {
     return (size_t)(A + 1) * (size_t)opal_profile_stride(es, G, rows, width == 18) + 48;  // (+48: probe / zero-copy slot, dp_kernel.hpp)
 }
 
+// SW with end location on the single-launch width-17 kernels: a column buffer of rows + 1 words per slot of the workgroup,
+// behind the profile (dp_kernel.hpp, CKPT)
+static size_t swend_ckpt_bytes(const OpalHipLaunch* a, int G, int rows, int wpb) {
+    if (!(a->width == 17 && a->mode == MODE_SW && a->want_end && !a->chunk_flags)) return 0;
+    return (size_t)(wpb * 64 / G) * (size_t)opal_swend_ckpt_words(rows) * 4;
+}
+
+extern "C" size_t opal_hip_swend_ckpt_bytes(int lanes_per_seq, int rows_per_lane, int waves_per_block) {
+    return (size_t)(waves_per_block * 64 / lanes_per_seq) * (size_t)opal_swend_ckpt_words(rows_per_lane) * 4;
+}
+
 extern "C" size_t opal_hip_lds_bytes(int width, int lanes_per_seq, int rows_per_lane, int alphabet_length) {
     return lds_bytes(width, lanes_per_seq, rows_per_lane, alphabet_length);
 }
@@ -403,7 +414,7 @@ extern "C" int opal_hip_launch_uber(const OpalHipUberLaunch* u) {
         const int slots = 64 / lanes[k];
         const int jobs = (items[k] + slots - 1) / slots;
         blocks += (jobs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-        const size_t need = lds_bytes(17, lanes[k], rows[k], a->alphabet_length);
+        const size_t need = lds_bytes(17, lanes[k], rows[k], a->alphabet_length) + swend_ckpt_bytes(a, lanes[k], rows[k], WAVES_PER_BLOCK);
         if (need > lds) lds = need;
     }
     if (blocks == 0) return 0;
@@ -456,8 +467,12 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
     const int maxWpb = opal_max_waves_per_block(a->width);
     int wpb = (a->waves_per_block >= 1 && a->waves_per_block <= maxWpb) ? a->waves_per_block : WAVES_PER_BLOCK;
     if (opal_host::opts().wavesPerBlock >= 1 && opal_host::opts().wavesPerBlock <= maxWpb) wpb = opal_host::opts().wavesPerBlock;
+    size_t lds = lds_bytes(a->width, G, a->rows_per_lane, a->alphabet_length) + swend_ckpt_bytes(a, G, a->rows_per_lane, wpb);
+    if (lds > 160 * 1024 && wpb > 4) {  // (the plan priced the column buffer of four waves)
+        wpb = 4;
+        lds = lds_bytes(a->width, G, a->rows_per_lane, a->alphabet_length) + swend_ckpt_bytes(a, G, a->rows_per_lane, wpb);
+    }
     const int blocks = (jobs + wpb - 1) / wpb;
-    size_t lds = lds_bytes(a->width, G, a->rows_per_lane, a->alphabet_length);
     if (a->lds_bytes_min > 0 && (size_t)a->lds_bytes_min > lds && a->lds_bytes_min <= 160 * 1024) lds = (size_t)a->lds_bytes_min;
     if (lds > 160 * 1024) {
         snprintf(g_err, sizeof g_err, "query profile needs %zu bytes of LDS (>160 KiB)", lds);

@@ -151,7 +151,8 @@ std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass, int sk
             const int rows = opal_hip_rows_supported(width, mode, swEndPass | (skew ? 4 : 0), want);
             if (!rows || rows == prevRows) continue;
             prevRows = rows;
-            const size_t lds = opal_hip_lds_bytes(width, G, rows, A);
+            // (SW with end locations, single launch: + the slots' column buffers, priced at four waves per workgroup)
+            const size_t lds = opal_hip_lds_bytes(width, G, rows, A) + ((swEndPass && mode == OPAL_MODE_SW && width == 17) ? opal_hip_swend_ckpt_bytes(G, rows, 4) : 0);
             if (lds > 160 * 1024) continue;
             if (G > 1 && (G / 2) * rows >= Q && !forceG) continue;  // half the lanes would hold padding only
             int wpb = 4, ldsPad = 0;

@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
             // for longer than the whole search takes run on the class body instead, on 4G lanes x S/4 rows, as the FIRST
             // workgroups of this very grid -- inside one launch the dispatch order is ours; as a launch of their own on a
             // side stream they started before or after the persistent workgroups from run to run (13.9 / 15.4 / 18.9 ms).
-            opal_dp_body<17, MODE_SW, SWEND ? FLAG_SWEND : 0, (S + 3) / 4>(p, sp.side, (int)blockIdx.x, STREAM_SIDE_WAVES);
+            opal_dp_body<17, MODE_SW, SWEND ? (FLAG_SWEND | FLAG_NOCKPT) : 0, (S + 3) / 4>(p, sp.side, (int)blockIdx.x, STREAM_SIDE_WAVES);
             return;
         }
     }
