@@ -5,6 +5,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/r4final
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 if [ "$1" = with-tests ]; then timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -12 > $OUT/pytest_gpu.log; fi
+if [ "$1" = with-tests ]; then OPAL_TEST_SEEDS=2000 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k randomized_differential_round4 2>&1 | tail -4 > $OUT/stress_seeds2000.log; fi
 timeout 600 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 timeout 600 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err
 timeout 900 python3 bench.py --workload sprot > $OUT/bench_sprot.json 2> $OUT/bench_sprot.err

@@ -75,6 +75,30 @@ def test_every_wave_geometry(lanes, mode, ours, oracle, opal_opt):
     _check((rc, s, eq, et), want, mode, f"G={lanes} {mode}")
 
 
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 32, 64])
+def test_sw_end_cells_with_ties_in_every_wave_geometry(lanes, ours, oracle, opal_opt):
+    """SW end cells where ties are the rule: two-letter sequences, match +1 / mismatch -1, gaps 0/0, 1/0, 0/1 and 2/1 -- the
+    final score is reached in many cells of many lanes, in the same step on different columns and in later steps on SMALLER
+    columns (a lane further down the slot sits on an earlier column). The single-launch kernels settle the slot's best cell
+    by an all-reduce over its lanes (dp_kernel.hpp, CKPT: DPP up to 16 lanes, the LDS crossbar beyond) and look the row up in
+    the column they kept in LDS: smallest target index, then smallest query index (opal.h:44-45), for every lanes-per-sequence
+    value and sequences shorter than the lane pipeline."""
+    rng = np.random.RandomState(lanes)
+    qlen = {1: 29, 2: 61, 4: 97, 8: 200, 16: 300, 32: 513, 64: 700}[lanes]
+    A = 4
+    m = np.full((A, A), -1, np.int32)
+    np.fill_diagonal(m, 1)
+    q = rng.randint(0, 2, qlen).astype(np.uint8)
+    db = [rng.randint(0, 2, int(L)).astype(np.uint8) for L in rng.randint(1, 700, 150)]
+    db += [np.tile(q[:7], 40)[: 250 + 3 * i].copy() for i in range(6)]   # periodic: the same score over and over
+    db += [q.copy(), q[::-1].copy(), np.zeros(300, np.uint8), np.ones(2, np.uint8)]
+    opal_opt.set("OPAL_HIP_LANES_PER_SEQ", str(lanes))
+    for go, ge in ((0, 0), (1, 0), (0, 1), (2, 1)):
+        got = ours.search(q, db, go, ge, m, 1, MODES["SW"])[:4]
+        want = oracle.search(q, db, go, ge, m, 1, MODES["SW"])
+        _check(got, want, "SW", f"ties G={lanes} gaps {go}/{ge}")
+
+
 def test_api_rules(ours, oracle):
     q, db, m = cases.materialise(cases.CASES["readme_example"])
     # score-only search: end locations -1; alignment fields post-filled (opal.cpp:1508-1515)
