@@ -292,14 +292,15 @@ static size_t lds_bytes(int width, int G, int rows, int A) {
     return (size_t)(A + 1) * (size_t)opal_profile_stride(es, G, rows, width == 18) + 48;  // (+48: probe / zero-copy slot, dp_kernel.hpp)
 }
 
-// SW with end location on the single-launch width-17 kernels: a column buffer of rows + 1 words per slot of the workgroup,
-// behind the profile (dp_kernel.hpp, CKPT)
+// SW with end location on the single-launch width-17 kernels: a column buffer per slot of the workgroup behind the profile
+// (dp_kernel.hpp, CKPT: two rows per word + the lane number, whole 16-byte stores)
 static size_t swend_ckpt_bytes(const OpalHipLaunch* a, int G, int rows, int wpb) {
     if (!(a->width == 17 && a->mode == MODE_SW && a->want_end && !a->chunk_flags)) return 0;
     return (size_t)(wpb * 64 / G) * (size_t)opal_swend_ckpt_words(rows) * 4;
 }
 
 extern "C" size_t opal_hip_swend_ckpt_bytes(int lanes_per_seq, int rows_per_lane, int waves_per_block) {
+    if (lanes_per_seq < 1 || lanes_per_seq > 64 || rows_per_lane < 1 || waves_per_block < 1) return 0;
     return (size_t)(waves_per_block * 64 / lanes_per_seq) * (size_t)opal_swend_ckpt_words(rows_per_lane) * 4;
 }
 
