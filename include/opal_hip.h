@@ -189,6 +189,15 @@ int opal_hip_pack_tokens(const unsigned char* raw, const uint64_t* raw_off, cons
    as one flat device buffer in caller order, into item order). */
 int opal_hip_reorder_residues(const unsigned char* src, const uint64_t* src_off, const uint64_t* dst_off, const int* len,
                               int count, unsigned char* dst, void* stream);
+/* The length ordering on the device (order_kernel.hip): a stable counting sort of `n` lengths (caller order, on the device,
+   every one in [0, max_len]) by length, longest first. Writes, for every item k < num_nonempty, the caller index, length and
+   byte offset (items back to back in item order) of the k-th sequence; the absent item num_nonempty if that is odd
+   {-1, 0, total bytes}; and the caller indices of the zero-length sequences, in caller order, into d_empty_seqs.
+   max_len must not exceed opal_hip_order_max_length(); d_scratch holds opal_hip_order_scratch_bytes(n, max_len) bytes. */
+int opal_hip_order_max_length(void);
+size_t opal_hip_order_scratch_bytes(int n, int max_len);
+int opal_hip_order_by_length(const int* d_lens, int n, int max_len, int num_nonempty, void* d_scratch, int* d_item_seq,
+                             int* d_item_len, uint64_t* d_item_off, int* d_empty_seqs, void* stream);
 /* Enqueue one DP kernel. 0 on success, non-zero if the shape is not launchable. */
 int opal_hip_launch(const OpalHipLaunch* args);
 /* Smallest rows_per_lane >= min_rows for which this kernel variant is instantiated (0: none).
@@ -292,6 +301,11 @@ int opalx_counters(long long* out, int capacity);
    lengths left out; an absent last item when their number is odd: seq -1, len 0). Fills seq / len / off (byte offset in
    the packed residue buffer), `capacity` entries each. Returns the number of items or -1 if capacity is too small. */
 int opalx_debug_order(const int* lens, int n, int* seq, int* len, unsigned long long* off, int capacity);
+/* Test hook (needs the device): the same ordering computed by the device (order_kernel.hip), whatever the size; also the
+   caller indices of the zero-length sequences (`empties`, capacity entries; *num_empties their count). Returns the number of
+   items, or -1 if the device ordering does not apply (a length beyond opal_hip_order_max_length()) or failed. */
+int opalx_debug_order_device(const int* lens, int n, int* seq, int* len, unsigned long long* off, int capacity, int* empties,
+                             int* num_empties);
 /* Test hook, no device needed: stress of the library's host thread pool (`rounds` jobs of 1..300 tasks, synchronous and
    asynchronous in turn, from `callers` threads at once). 0 if every task of every job ran exactly once. */
 int opalx_debug_pool_selftest(int rounds, int callers);

@@ -118,7 +118,63 @@ static bool order_into(int n, const int* lens, OrderScratch& scratch, std::vecto
     return true;
 }
 
-static bool order_sequences(OpalxDb* db, int n, const int* lens) {
+// The same ordering on the DEVICE (order_kernel.hip): the lengths go up in one copy, four small launches sort them and
+// write the item arrays where the DP kernels read them, and the host's copies (the scheduler reads lengths, the gather
+// reads caller indices and offsets) come back in three copies. One pass of one host thread over the lengths (copy into pinned
+// memory, maximum, count of the empty ones, sum) instead of the histogram + scattered placement: on a cold
+// opalSearchDatabase call the ordering is what stands between the call and its first gathered residue.
+// Returns 0 done, 1 not applicable (small database, lengths beyond the kernel's table: the host orders), -1 failed.
+static int order_sequences_device(OpalxDb* db, int n, const int* lens, bool force = false) {
+    const int mode = force ? 1 : opts().deviceOrder;
+    if (mode == 0 || n <= 0 || (mode < 0 && n < 16384)) return 1;
+    const double t0 = now_ms();
+    const double slack = db->cached ? 1.15 : 1.0;
+    if (!db->hLens.resize((size_t)n, slack)) return -1;
+    int* h = db->hLens.data();
+    int maxLen = 0, nonEmpty = 0;
+    int64_t total = 0;
+    for (int i = 0; i < n; i++) {
+        const int len = lens[i] > 0 ? lens[i] : 0;
+        h[i] = len;
+        maxLen = std::max(maxLen, len);
+        nonEmpty += len > 0;
+        total += len;
+    }
+    if (maxLen > opal_hip_order_max_length()) return 1;
+    const size_t items = ((size_t)nonEmpty + 1) / 2 * 2;
+    const size_t empties = (size_t)n - (size_t)nonEmpty;
+    void* st = db->main();
+    if (!st || !db->dLens.ensure((size_t)n, slack) || !db->dOrderScratch.ensure(opal_hip_order_scratch_bytes(n, maxLen), slack) ||
+        !db->dSeqOff.ensure(items + 1, slack) || !db->dPairLen.ensure(items + 1, slack) || !db->dPairSeq.ensure(items + 1, slack) ||
+        !db->pairLen.resize(items, slack) || !db->pairSeq.resize(items, slack) || !db->seqOff.resize(items, slack) ||
+        (empties && (!db->dEmpty.ensure(empties, slack) || !db->hEmpty.resize(empties, slack))))
+        return -1;
+    const double t1 = now_ms();
+    bool ok = !opal_hip_memcpy_h2d(db->dLens.p, h, (size_t)n * sizeof(int), st) &&
+              !opal_hip_order_by_length(db->dLens.p, n, maxLen, nonEmpty, db->dOrderScratch.p, db->dPairSeq.p, db->dPairLen.p, db->dSeqOff.p,
+                                        db->dEmpty.p, st);
+    if (ok && items)
+        ok = !opal_hip_memcpy_d2h(db->pairSeq.data(), db->dPairSeq.p, items * sizeof(int), st) &&
+             !opal_hip_memcpy_d2h(db->seqOff.data(), db->dSeqOff.p, items * sizeof(uint64_t), st) &&
+             !opal_hip_memcpy_d2h(db->pairLen.data(), db->dPairLen.p, items * sizeof(int), st);
+    if (ok && empties) ok = !opal_hip_memcpy_d2h(db->hEmpty.data(), db->dEmpty.p, empties * sizeof(int), st);
+    if (!ok || opal_hip_stream_sync(st)) return -1;
+    db->emptySeqs.assign(db->hEmpty.data(), db->hEmpty.data() + empties);
+    db->numSeqs = n;
+    db->numPairs = (int)(items / 2);
+    db->residues = total;
+    db->ordScratch.pos.clear(); db->ordScratch.byte.clear();  // (no bucket table of the host ordering: the chunk cuts search seqOff)
+    db->deviceOrdered = true;
+    if (debug_on()) fprintf(stderr, "[opal] order on the device: lengths staged %.3f ms, upload + sort + item arrays back %.3f ms\n", t1 - t0, now_ms() - t1);
+    return 0;
+}
+
+static bool order_sequences(OpalxDb* db, int n, const int* lens, bool mayUseDevice) {
+    db->deviceOrdered = false;
+    if (mayUseDevice) {
+        const int r = order_sequences_device(db, n, lens);
+        if (r <= 0) return r == 0;
+    }
     db->numSeqs = n;
     const double slack = db->cached ? 1.15 : 1.0;
     OrderScratch& scratch = db->ordScratch;
@@ -154,6 +210,7 @@ void db_release(OpalxDb* db) {
     db->quiesce();  // (searches queued by opalx_search_device_async and never waited for: nothing may still read these buffers)
     db->res.release(); db->dSeqOff.release(); db->dPairLen.release(); db->dPairSeq.release();
     db->pairLen.release(); db->pairSeq.release(); db->seqOff.release();
+    db->hLens.release(); db->hEmpty.release(); db->dLens.release(); db->dEmpty.release(); db->dOrderScratch.release();
     db->tokens.release(); db->pairOff.release(); db->hPairOff.release();
     db->timeline.release();
     db->header.release(); db->hHeader.release(); db->ovfItems.release(); db->boundary.release(); db->scratch.release();
@@ -198,7 +255,7 @@ bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::funct
     if (!reuse) {
         db->seqItemValid = false;
         db->planCache.clear();
-        if (!order_sequences(db, n, lens)) return false;
+        if (!order_sequences(db, n, lens, kind == RAW_POINTERS)) return false;
         if (db->cached && kind == RAW_POINTERS) db->lastLens.assign(lens, lens + n);
     }
     const double tf1 = now_ms();
@@ -211,7 +268,7 @@ bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::funct
     if (!ok) return false;
     if (!items) return true;
     // (pinned sources: the copies need no wait on the host side)
-    if (!reuse)
+    if (!reuse && !db->deviceOrdered)
         ok = !opal_hip_memcpy_h2d(db->dSeqOff.p, db->seqOff.data(), items * sizeof(uint64_t), st) &&
              !opal_hip_memcpy_h2d(db->dPairLen.p, db->pairLen.data(), items * sizeof(int), st) &&
              !opal_hip_memcpy_h2d(db->dPairSeq.p, db->pairSeq.data(), items * sizeof(int), st);
@@ -234,25 +291,16 @@ bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::funct
     db->hRaw.deviceCached = true;
     if (!db->hRaw.ensure(total + 16, slack) || !db->copy()) return false;
     UploadGate& g = db->gate;
-    const uint64_t chunkBytes = std::max<uint64_t>(2u << 20, total / 96);
-    const uint64_t pieceBytes = std::max<uint64_t>(128u << 10, chunkBytes / 16);
+    const uint64_t chunkBytes = opts().chunkBytes > 0 ? (uint64_t)opts().chunkBytes : std::max<uint64_t>(2u << 20, total / 96);
+    const uint64_t pieceBytes = opts().chunkBytes > 0 ? std::max<uint64_t>(1024, chunkBytes / 4) : std::max<uint64_t>(128u << 10, chunkBytes / 16);
     g.cutItem.assign(1, 0);
     g.pieceCut.assign(1, 0);
     g.pieceChunk.clear();
-    const OrderScratch& sc = db->ordScratch;
-    if (sc.pos.size() >= 2 && sc.pos.size() == sc.byte.size()) {
-        // cuts from the bucket table (all sequences of a bucket have the same length): first item at or behind a byte
-        // offset = a binary search over the buckets and a division, instead of a walk over every item
-        const size_t nb = sc.pos.size() - 2;  // buckets [0, nb): lengths nb - b; pos/byte[nb] = the end (the tables hold one spare entry)
-        auto item_at = [&](uint64_t target) -> int {
-            size_t b = (size_t)(std::upper_bound(sc.byte.begin(), sc.byte.begin() + (long)nb + 1, target) - sc.byte.begin());
-            if (b == 0) return 0;
-            b--;
-            if (b >= nb) return sc.pos[nb];
-            const uint64_t len = (uint64_t)(nb - b);
-            return std::min<int>(sc.pos[b + 1], sc.pos[b] + (int)((target - sc.byte[b] + len - 1) / len));
-        };
-        const int mReal = sc.pos[nb];
+    {
+        // cuts: the first item at or behind a byte offset = a binary search over the items' offsets (increasing in item order)
+        const uint64_t* so = db->seqOff.data();
+        auto item_at = [&](uint64_t target) -> int { return (int)(std::lower_bound(so, so + items, target) - so); };
+        const int mReal = (int)items;
         for (uint64_t cb = 0; cb < total; cb += chunkBytes) {
             const int c = (int)g.cutItem.size() - 1;
             const uint64_t ce = std::min<uint64_t>(cb + chunkBytes, total);
@@ -534,6 +582,24 @@ extern "C" int opalx_debug_order(const int* lens, int n, int* seq, int* len, uns
         return true;
     });
     return fits ? (int)items : -1;
+}
+
+// Test hook (needs the device): the same ordering by order_kernel.hip, same outputs; `empties` (capacity entries) receives the
+// caller indices of the zero-length sequences, *num_empties their count. -1 if it does not apply or fails.
+extern "C" int opalx_debug_order_device(const int* lens, int n, int* seq, int* len, unsigned long long* off, int capacity, int* empties,
+                                        int* num_empties) {
+    if (!device_ok()) return -1;
+    OpalxDb* db = new (std::nothrow) OpalxDb;
+    if (!db) return -1;
+    int items = -1;
+    if (order_sequences_device(db, n, lens, /*force=*/true) == 0 && db->pairLen.size() <= (size_t)capacity) {
+        items = (int)db->pairLen.size();
+        for (int i = 0; i < items; i++) { seq[i] = db->pairSeq[(size_t)i]; len[i] = db->pairLen[(size_t)i]; off[i] = db->seqOff[(size_t)i]; }
+        *num_empties = (int)db->emptySeqs.size();
+        for (size_t i = 0; i < db->emptySeqs.size() && i < (size_t)capacity; i++) empties[i] = db->emptySeqs[i];
+    }
+    opalx_db_destroy(db);
+    return items;
 }
 
 // Test hook (no device needed): a stress of the host thread pool -- jobs of 1..300 tasks, synchronous and begin/end in

@@ -588,6 +588,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                     count(CNT_SWAPPED, swapN);
                 }
                 rc = launch_range(c, narrow, wantEnd, 0, nullptr, swapN, nNarrow - swapN, seqLenOf, db->ovfCount.p);
+                if (rc && swapN > 0) db->quiesce();  // (the swapped launch may still be writing results and the re-run list on its stream)
                 if (!rc && joinSwap && opal_hip_stream_wait_event(st, joinSwap)) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
             }
             if (rc) return rc;

@@ -246,6 +246,7 @@ extern "C" int opalx_multi_search_device_async(OpalxMultiDb* m, const unsigned c
     const int slot = (int)(m->head % OPALX_ASYNC_DEPTH);
     void* prevDone = m->head > m->tail ? m->rootDone[(m->head - 1) % OPALX_ASYNC_DEPTH] : nullptr;
     std::vector<int> rcs(K, 0);
+    std::vector<char> queued(K, 1);  // the shard's search took a place in its handle's queue
     const int cur = opal_hip_get_device();
     run_on_device_workers(K, [&](size_t k) {
         const int n = m->count[k];
@@ -254,9 +255,13 @@ extern "C" int opalx_multi_search_device_async(OpalxMultiDb* m, const unsigned c
         if (!device_ok() || opal_hip_set_device(m->devices[k])) { rcs[k] = OPAL_ERR_NO_SIMD_SUPPORT; return; }
         OpalxDb* db = m->shard[k];
         int* r = m->res[k].p;
+        const unsigned headBefore = db->asyncHead;
         rcs[k] = opalx_search_device_async(db, query, query_length, gap_open, gap_ext, score_matrix, alphabet_length, search_type, mode, r,
                                            wantEnd ? r + n : nullptr, wantEnd ? r + 2 * (size_t)n : nullptr);
         if (rcs[k] == OPAL_ERR_NO_SIMD_SUPPORT || rcs[k] == OPAL_ERR_INVALID_MODE) return;
+        // (a search refused before anything was launched -- arguments beyond 32 bits: OPAL_ERR_OVERFLOW -- took no place in
+        // the shard's queue and wrote no block: there is nothing to gather and nothing to wait for)
+        if (db->asyncHead == headBefore) { queued[k] = 0; return; }
         // the path's only exchange: this shard's block to the root GPU (peer DMA over xGMI), vector by vector into its
         // place in the gathered block, on the shard's own stream behind its kernels
         void* st = db->main();
@@ -272,7 +277,17 @@ extern "C" int opalx_multi_search_device_async(OpalxMultiDb* m, const unsigned c
         if (rcs[k] == OPAL_ERR_NO_SIMD_SUPPORT || rcs[k] == OPAL_ERR_INVALID_MODE) rc = rcs[k];
         else if (rcs[k] && !rc) rc = rcs[k];
     }
+    // Nothing was enqueued anywhere (every shard refused the same arguments): the multi-GPU queue keeps its length too, so
+    // that opalx_multi_wait never pops a shard entry that belongs to another search. (Some shards queued, others not, cannot
+    // come from the arguments -- they are the same everywhere --: treated as a failure, the queues are drained below.)
+    size_t nQueued = 0, nAsked = 0;
+    for (size_t k = 0; k < K; k++) if (m->count[k]) { nAsked++; nQueued += queued[k] ? 1 : 0; }
+    if (rc != OPAL_ERR_NO_SIMD_SUPPORT && rc != OPAL_ERR_INVALID_MODE && nAsked > 0 && nQueued == 0) {
+        if (cur >= 0) opal_hip_set_device(cur);
+        return rc ? rc : OPAL_ERR_NO_SIMD_SUPPORT;
+    }
     int e = opal_hip_set_device(m->devices[0]);
+    if (nQueued != nAsked) e = 1;
     if (!e && rc != OPAL_ERR_NO_SIMD_SUPPORT && rc != OPAL_ERR_INVALID_MODE) {
         // root: behind every shard's copy, the three vectors into database order
         for (size_t k = 0; k < K; k++)

@@ -155,6 +155,12 @@ struct OpalxDb {
     bool lastValid = false;               // ... if its fill completed: the next call may find the same database again
     bool speculate = true;                // search a re-seen database before its residues have been compared (db_fill)
     opal_host::OrderScratch ordScratch;   // scratch of the ordering, kept across calls (no fresh pages per call)
+    // the ordering on the device (order_kernel.hip): lengths in caller order (pinned staging + device), its scratch, the
+    // zero-length sequences it found
+    opal_host::PinVec<int> hLens, hEmpty;
+    opal_host::DevBuf<int> dLens, dEmpty;
+    opal_host::DevBuf<unsigned char> dOrderScratch;
+    bool deviceOrdered = false;           // the item arrays of the current database were written on the device (nothing to upload)
     // device: the packed database
     opal_host::DevBuf<unsigned char> res;
     opal_host::DevBuf<uint64_t> dSeqOff;

@@ -69,6 +69,7 @@ const std::vector<Desc>& table() {
         integer("OPAL_HIP_DEVICE", &Options::device, 0, 1023),
         integer("OPAL_HOST_THREADS", &Options::hostThreads, 1, 4096),
         integer("OPAL_ORDER_THREADS", &Options::orderThreads, 1, 4096),
+        one_of("OPAL_HIP_DEVICE_ORDER", &Options::deviceOrder, {0, 1}),
         integer("OPAL_HOST_WIDE", &Options::hostWide, 0, 1),
         big("OPAL_TRACEBACK_BYTES", &Options::tracebackBytes),
         big("OPAL_TRACEBACK_DEVICE_BYTES", &Options::tracebackDeviceBytes),
@@ -76,6 +77,7 @@ const std::vector<Desc>& table() {
         flag("OPAL_HIP_NO_REUSE", &Options::noReuse),
         flag("OPAL_HIP_NO_SPECULATION", &Options::noSpeculation),
         flag("OPAL_HIP_NO_ZERO_COPY", &Options::noZeroCopy),
+        integer("OPAL_HIP_CHUNK_BYTES", &Options::chunkBytes, 4096, 1 << 30),
         {"OPAL_HIP_COPY_STREAMS", [](Options& o, const char* v) { long long x; if (!parse_ll(v, 1, 2, &x)) return false; o.oneCopyStream = x == 1; return true; }, back(&Options::oneCopyStream)},
         flag("OPAL_HIP_SPIN_SYNC", &Options::spinSync),
         flag("OPAL_HIP_HOST_STARTS", &Options::hostStarts),
@@ -188,7 +190,7 @@ namespace opal_host {
 // (what a cached launch plan depends on besides the search itself)
 std::string Options::plan_key() const {
     char buf[96];
-    snprintf(buf, sizeof buf, "%d|%g|%d|%d", lanesPerSeq, tailFraction, (int)tailPipeModel, (int)uberOnly);
+    snprintf(buf, sizeof buf, "%d|%g|%d|%d|%d", lanesPerSeq, tailFraction, (int)tailPipeModel, (int)uberOnly, sideStreams);
     return buf;
 }
 }  // namespace opal_host

@@ -21,6 +21,7 @@ struct Options {
     // ---- host side
     int hostThreads = 0;              // OPAL_HOST_THREADS: width of the host thread pool (0: from the CPU quota)
     int orderThreads = 0;             // OPAL_ORDER_THREADS: threads of the length ordering (0: automatic)
+    int deviceOrder = -1;             // OPAL_HIP_DEVICE_ORDER: the length ordering on the device (order_kernel.hip): 0 never, 1 whenever possible, -1 automatic (large databases)
     int hostWide = -1;                // OPAL_HOST_WIDE: host traceback lanes (-1: automatic)
     long long tracebackBytes = 0;     // OPAL_TRACEBACK_BYTES: memory budget of the host traceback (0: default)
     long long tracebackDeviceBytes = 0;  // OPAL_TRACEBACK_DEVICE_BYTES: flag-matrix budget of the device traceback (0: 8 GiB)
@@ -28,6 +29,7 @@ struct Options {
     bool noReuse = false;             // OPAL_HIP_NO_REUSE: never recognise the previous call's database
     bool noSpeculation = false;       // OPAL_HIP_NO_SPECULATION: a re-seen database is compared before it is searched
     bool noZeroCopy = false;          // OPAL_HIP_NO_ZERO_COPY: a new database is uploaded, never read from pinned memory by the kernels
+    int chunkBytes = 0;               // OPAL_HIP_CHUNK_BYTES (test hook): size of an upload chunk of a fill (0: 2 MB or a 96th of the database)
     bool oneCopyStream = false;       // OPAL_HIP_COPY_STREAMS=1: one copy stream instead of two
     bool spinSync = false;            // OPAL_HIP_SPIN_SYNC: poll the stream instead of blocking on it
     bool hostStarts = false;          // OPAL_HIP_HOST_STARTS: start cells by the host's reverse pass

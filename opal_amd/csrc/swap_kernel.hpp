@@ -273,7 +273,7 @@ template <int S, int ES>
 __host__ __device__ inline int opal_swapgl_stride() { return opal_profile_stride(ES, 64, S, 0); }
 template <int S, int ES>
 __host__ __device__ inline size_t opal_swapgl_lds_bytes(int Q, int A) {
-    return (size_t)(A + 1) * (size_t)opal_swapgl_stride<S, ES>() + 4 * (size_t)(Q + 128) + 8 * (size_t)(Q + 66) + 48;
+    return (size_t)(A + 1) * (size_t)opal_swapgl_stride<S, ES>() + 4 * (size_t)(Q + 128) + 8 * (size_t)(Q + 66) + 16 + 48;  // (+16: the clock probe's slot is 16-byte aligned)
 }
 
 template <int MODE, int S, int ES>
@@ -289,7 +289,8 @@ __global__ void __launch_bounds__(SWAP_WAVES * 64, 1) opal_swap_gl(const SwapPar
     unsigned* const qoff = reinterpret_cast<unsigned*>(lds + (size_t)(A + 1) * stride);
     int* const bndH = reinterpret_cast<int*>(qoff + (Q + 128));
     int* const bndF = bndH + (Q + 66);
-    unsigned char* const clkSlot = reinterpret_cast<unsigned char*>(bndF + (Q + 66));
+    // (the probe's slot holds 64-bit words: bndF ends on a 4-byte boundary when Q is odd)
+    unsigned char* const clkSlot = lds + ((((size_t)(A + 1) * stride + 4 * (size_t)(Q + 128) + 8 * (size_t)(Q + 66)) + 15) & ~(size_t)15);
     clk_begin(p.clk, nullptr, clkSlot);
 
     const int item = p.firstItem + (int)blockIdx.x;

@@ -164,3 +164,35 @@ def have_ref():
 
 def RefLib():
     return OpalABI(ref_lib_path(), prefix="ref_")
+
+
+class RefThreads:
+    """The reference's own AVX2 library on every host core (oracle/ref_bench.c: ref_search_run): what the full-size GPU
+    tests compare EVERY sequence of a BASELINE-sized database with ("bit-exact ... for every sequence").
+    The scalar oracle cannot finish 1e10 cells in seconds; this does in well under one."""
+
+    def __init__(self):
+        bench_so = os.path.join(ORACLE_DIR, "_ref", "libref_bench.so")
+        self.ok = have_ref() and os.path.exists(bench_so)
+        if self.ok:
+            C.CDLL(ref_lib_path(), mode=C.RTLD_GLOBAL)
+            self.lib = C.CDLL(bench_so)
+            self.ok = hasattr(self.lib, "ref_search_run")
+        if self.ok:
+            self.lib.ref_search_run.restype = C.c_double
+
+    def search(self, query, res, offs, matrix, gap_open, gap_ext, search_type, mode_code, threads=None):
+        """-> (rc, score, endQ, endT, seconds) over all len(offs) - 1 sequences"""
+        n = len(offs) - 1
+        if threads is None:
+            threads = max(1, min(os.cpu_count() or 1, 64))
+        q = np.ascontiguousarray(query, np.uint8); o = np.ascontiguousarray(offs, np.int64)
+        m = np.ascontiguousarray(matrix, np.int32); r = np.ascontiguousarray(res, np.uint8)
+        s = np.empty(n, np.int32); eq = np.empty(n, np.int32); et = np.empty(n, np.int32)
+        rc = C.c_int(0)
+        up = lambda a: a.ctypes.data_as(C.POINTER(C.c_ubyte))
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+        sec = self.lib.ref_search_run(up(q), len(q), up(r), o.ctypes.data_as(C.POINTER(C.c_int64)), int(n), int(gap_open),
+                                      int(gap_ext), ip(m), int(m.shape[0]), int(mode_code), int(search_type), int(threads),
+                                      ip(s), ip(eq), ip(et), C.byref(rc))
+        return rc.value, s, eq, et, sec

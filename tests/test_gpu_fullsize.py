@@ -58,6 +58,31 @@ def test_c2_sw_sampled_vs_oracle_and_properties(c2, oracle):
         np.testing.assert_array_equal(out[mode][2][pick], et, err_msg=mode)
 
 
+@pytest.mark.skipif(not oracle_lib.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_c2_c3_every_sequence_vs_reference_library(c2):
+    """SURVEY.md 8d, C3 as written: score, endQ, endT of EVERY sequence of the 100 000-sequence database, all four modes,
+    against the reference's own AVX2 library (oracle/_ref, opal.cpp:1435-1519) run on every host core; and C2's score-only
+    search for both gap settings. SW with score 0 has no defined end cell in the reference: masked."""
+    ref = oracle_lib.RefThreads()
+    if not ref.ok:
+        pytest.skip("oracle/_ref/libref_bench.so lacks ref_search_run")
+    pdb, q, m = c2["pdb"], c2["q"], c2["m"]
+    for go in (11, 3):
+        rc, s, eq, et = pdb.search(q, go, 1, m, 0, oracle_lib.MODE_SW)
+        rrc, rs, _, _, sec = ref.search(q, c2["res"], c2["offs"], m, go, 1, 0, oracle_lib.MODE_SW)
+        assert rc == rrc == 0
+        np.testing.assert_array_equal(s, rs, err_msg=f"C2 score-only, gaps {go}/1")
+    for go in (11, 3):
+        for mode in ("SW", "NW", "HW", "OV"):
+            rc, s, eq, et = pdb.search(q, go, 1, m, 1, oracle_lib.MODES[mode])
+            rrc, rs, rq, rt, sec = ref.search(q, c2["res"], c2["offs"], m, go, 1, 1, oracle_lib.MODES[mode])
+            assert rc == rrc == 0, (mode, go, rc, rrc)
+            np.testing.assert_array_equal(s, rs, err_msg=f"C3 {mode} gaps {go}/1: scores")
+            live = rs != 0 if mode == "SW" else np.ones(len(rs), bool)
+            np.testing.assert_array_equal(eq[live], rq[live], err_msg=f"C3 {mode} gaps {go}/1: endQ")
+            np.testing.assert_array_equal(et[live], rt[live], err_msg=f"C3 {mode} gaps {go}/1: endT")
+
+
 def test_c2_order_independence_and_gaps(c2):
     """Per-sequence results do not depend on database order or on its neighbours (shuffle = permuted results)."""
     from opal_amd.api import PreparedDb
@@ -361,6 +386,20 @@ def test_sprot_shape_full_size(oracle):
         np.testing.assert_array_equal(et[pick], ot, err_msg=mode)
         out[mode] = (s, eq, et)
     np.testing.assert_array_equal(out["SW"][0], sw["P19930"], err_msg="SW score-only (swapped tail) != SW with end locations (class kernels)")
+    # every one of the 541 762 sequences against the reference's own library (all host cores; NW left out: targets this long
+    # need the reference's 32-bit NW, which is undefined behaviour and returns OPAL_ERR_OVERFLOW here)
+    ref = oracle_lib.RefThreads() if oracle_lib.have_ref() else None
+    if ref is not None and ref.ok:
+        host_res = d_res.cpu().numpy()
+        for mode in ("SW", "HW", "OV"):
+            rrc, rs, rq, rt, sec = ref.search(q, host_res, offs, m, 3, 1, 1, oracle_lib.MODES[mode])
+            assert rrc == 0, (mode, rrc)
+            s, eq, et = out[mode]
+            np.testing.assert_array_equal(s, rs, err_msg=f"sprot shape {mode}: scores of all sequences vs the reference library")
+            live = rs != 0 if mode == "SW" else np.ones(len(rs), bool)
+            np.testing.assert_array_equal(eq[live], rq[live], err_msg=f"sprot shape {mode}: endQ")
+            np.testing.assert_array_equal(et[live], rt[live], err_msg=f"sprot shape {mode}: endT")
+            print(f"P19930 {mode} + end: all {n} sequences equal the reference library's ({sec:.2f} s on the host)")
     assert (out["SW"][0] >= out["OV"][0]).all() and (out["OV"][0] >= out["HW"][0]).all() and (out["HW"][0] >= out["NW"][0]).all()
     assert (out["NW"][1] == Q - 1).all() and (out["NW"][2] == lens - 1).all() and (out["HW"][1] == Q - 1).all()
     for mode in ("SW", "OV", "HW"):

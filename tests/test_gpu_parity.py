@@ -912,3 +912,74 @@ def test_reentrant_streaming_and_alignment_from_host_threads(ours, oracle, opal_
     assert not errs and all(not th.is_alive() for th in threads), errs
     for i, (q, db, mode, st) in enumerate(jobs):
         _check(out[i], oracle.search(q, db, 11, 1, m, min(st, 1), MODES[mode]), mode, f"thread {i} {mode} st={st}")
+
+
+def test_device_ordering_equals_stable_sort_by_length():
+    """order_kernel.hip (the ordering of a cold opalSearchDatabase call, on the device): the same inputs as the host ordering's
+    test (tests/test_host_logic.py::test_ordering_is_a_stable_sort_by_length) plus sizes around the kernel's range cuts --
+    stable by length, longest first, zero lengths listed apart in caller order, byte offsets = running sum, the absent item
+    of an odd count; a length beyond the kernel's table is refused (the host orders then)."""
+    import ctypes as C
+    from opal_amd import _lib, synth
+    L = _lib.lib()
+    L.opalx_debug_order_device.restype = C.c_int
+    L.opal_hip_order_max_length.restype = C.c_int
+    rng = np.random.RandomState(5)
+    cases_ = [np.array([0, 0], np.int32), np.array([7], np.int32), np.array([3, 0, 3, 9, 3], np.int32),
+              rng.randint(0, 50, 1000).astype(np.int32), synth.lengths(42, 0, 100001, "sprot"),
+              rng.randint(1, 4, 70000).astype(np.int32), np.concatenate([synth.lengths(42, 0, 66000), [0, 0, 35213]]).astype(np.int32),
+              np.concatenate([synth.lengths(42, 0, 450000, "sprot"), [0, 17]]).astype(np.int32),
+              rng.randint(0, 3, 2048 * 256 + 77).astype(np.int32), np.full(4097, 5, np.int32), synth.lengths(42, 0, 1000003)]
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    for lens in cases_:
+        lens = np.ascontiguousarray(lens, np.int32)
+        n = len(lens)
+        cap = n + 2
+        seq = np.full(cap, -7, np.int32); ln = np.full(cap, -7, np.int32); off = np.zeros(cap, np.uint64)
+        emp = np.full(cap, -7, np.int32); nemp = C.c_int(-1)
+        items = L.opalx_debug_order_device(ip(lens), n, ip(seq), ip(ln), off.ctypes.data_as(C.POINTER(C.c_ulonglong)), cap, ip(emp), C.byref(nemp))
+        nz = np.nonzero(lens > 0)[0]
+        want = nz[np.argsort(-lens[nz].astype(np.int64), kind="stable")]
+        m = len(want)
+        assert items == (m + 1) // 2 * 2, (n, items, m)
+        np.testing.assert_array_equal(seq[:m], want)
+        np.testing.assert_array_equal(ln[:m], lens[want])
+        np.testing.assert_array_equal(off[:m], np.concatenate([[0], np.cumsum(lens[want].astype(np.int64))])[:m].astype(np.uint64))
+        if items > m:
+            assert (seq[m], ln[m], off[m]) == (-1, 0, int(lens[want].astype(np.int64).sum()))
+        assert nemp.value == n - m
+        np.testing.assert_array_equal(emp[:n - m], np.nonzero(lens <= 0)[0])
+    too_long = np.array([5, L.opal_hip_order_max_length() + 1, 9], np.int32)
+    seq = np.zeros(5, np.int32); ln = np.zeros(5, np.int32); off = np.zeros(5, np.uint64); emp = np.zeros(5, np.int32); nemp = C.c_int(0)
+    assert L.opalx_debug_order_device(ip(too_long), 3, ip(seq), ip(ln), off.ctypes.data_as(C.POINTER(C.c_ulonglong)), 5, ip(emp), C.byref(nemp)) == -1
+
+
+@pytest.mark.parametrize("device_order", ["0", "1"])
+def test_api_results_do_not_depend_on_where_the_ordering_runs(device_order, oracle, opal_opt):
+    """opalSearchDatabase with the ordering forced onto the host / onto the device (OPAL_HIP_DEVICE_ORDER): the same answers,
+    the oracle's, on a database with empty sequences, duplicates of one length and an odd count; twice (the second call finds
+    the database of the first)."""
+    import opal_amd
+    from opal_amd import synth
+    from opal_amd.score_matrix import blosum50
+    opal_opt.set("OPAL_HIP_DEVICE_ORDER", device_order)
+    n = 3001
+    res, offs, lens = synth.database(n, seed=11)
+    db = [res[offs[i]:offs[i + 1]] for i in range(n)]
+    for i in (0, 17, 18, 2999):
+        db[i] = db[i][:0]
+    for i in range(100, 140):
+        db[i] = db[99].copy()
+    q = synth.query(150, seed=3)
+    m = blosum50()[1]
+    for mode_name in ("SW", "NW", "HW", "OV"):
+        mode = opal_amd.MODES[mode_name]
+        orc, os_, oq, ot = oracle.search(q, db, 3, 1, m, 1, mode)
+        for rep in range(2):
+            rc, results = opal_amd.search_database(q, db, 3, 1, m, opal_amd.OPAL_SEARCH_SCORE_END, mode)
+            assert rc == orc == 0
+            s, eq, et = opal_amd.result_fields(results, "score", "endLocationQuery", "endLocationTarget")
+            live = os_ != 0 if mode_name == "SW" else np.ones(n, bool)
+            np.testing.assert_array_equal(s, os_, err_msg=mode_name)
+            np.testing.assert_array_equal(eq[live], oq[live], err_msg=mode_name)
+            np.testing.assert_array_equal(et[live], ot[live], err_msg=mode_name)

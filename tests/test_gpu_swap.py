@@ -249,3 +249,34 @@ def test_swapped_kernels_in_a_call_sharded_over_devices(mode, ours, oracle, opal
     want = oracle.search(q, [seqs[i] for i in idx], 3, 1, m, 1, MODES[mode])
     for a, b in zip(two[1:], want[1:4]):
         np.testing.assert_array_equal(a[idx], b)
+
+
+@pytest.mark.parametrize("rows", ["8", "16"])
+@pytest.mark.parametrize("mode", ["SW", "NW", "HW", "OV"])
+def test_swapped_kernels_with_an_asymmetric_matrix(mode, rows, ours, oracle, opal_opt):
+    """The swapped kernels transpose the DP; the score matrix must NOT be transposed with it: S(a, b) keeps a = query letter
+    (reference src/opal.cpp:190, opal.h:115-116). Every other case of this file uses a symmetric matrix, which cannot tell
+    M[a*A+b] from M[b*A+a]; this one is BLOSUM50 with a seeded, asymmetric perturbation of every entry. Scores and end cells
+    of the 20 longest targets forced onto the swapped kernels, against the oracle."""
+    from opal_amd import synth
+    from opal_amd.score_matrix import blosum50
+    m = blosum50()[1].astype(np.int32).copy()
+    rng = np.random.RandomState(91)
+    m += rng.randint(-3, 4, m.shape).astype(np.int32)
+    assert (m != m.T).sum() > 100
+    q = synth.query(110, seed=4)
+    db = _database(q, int(rows), seed=77 + int(rows))
+    opal_opt.set("OPAL_HIP_SWAP", "20")
+    opal_opt.set("OPAL_HIP_SWAP_ROWS", rows)
+    for go, ge in ((11, 1), (3, 1)):
+        for st in (0, 1):
+            before = _swapped(ours)
+            got = ours.search(q, db, go, ge, m, st, MODES[mode])[:4]
+            assert _swapped(ours) - before == 20, "the swapped kernel did not run"
+            want = oracle.search(q, db, go, ge, m, st, MODES[mode])
+            assert got[0] == want[0] == 0
+            np.testing.assert_array_equal(got[1], want[1], err_msg=f"asymmetric matrix, {mode} rows={rows} gaps {go}/{ge}: score")
+            if st:
+                live = want[1] != 0 if mode == "SW" else np.ones(len(db), bool)
+                np.testing.assert_array_equal(got[2][live], want[2][live], err_msg=f"asymmetric matrix, {mode}: endQ")
+                np.testing.assert_array_equal(got[3][live], want[3][live], err_msg=f"asymmetric matrix, {mode}: endT")

@@ -278,6 +278,27 @@ def test_host_code_sanitized():
     assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
 
 
+def test_host_scheduler_under_thread_sanitizer():
+    """The host scheduler's concurrency under ThreadSanitizer (tests/fake_device): the library's real host translation
+    units -- thread pool, gather beside the search, chunk gates, the speculative search of a re-seen database, zero-copy
+    fills, the queue of asynchronous searches, two caller threads, a call sharded over three device slots, the multi-GPU
+    handle's queued searches -- compiled with -fsanitize=thread against a FAKE device whose streams are host threads and
+    whose kernels are the scalar oracle. Every answer must be the oracle's and ThreadSanitizer must stay silent (a report
+    makes the exit code 66). The fake device is test infrastructure: libopal.so never contains it."""
+    import subprocess
+    d = os.path.join(ROOT, "tests", "fake_device")
+    try:
+        subprocess.check_call(["make", "-s", "-j", "4", "-C", d, "host_stress"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError):
+        pytest.skip("ThreadSanitizer build not available here")
+    env = dict(os.environ, TSAN_OPTIONS="exitcode=66 halt_on_error=1")
+    for k in list(env):
+        if k.startswith("OPAL_HIP_") or k.startswith("OPAL_HOST_"):
+            del env[k]
+    p = subprocess.run([os.path.join(d, "host_stress")], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "host_stress ok" in p.stdout, p.stdout[-2000:] + p.stderr[-6000:]
+
+
 def test_options_are_typed_and_validated(opal_opt):
     """opalx_set_option (options.cpp): unknown names and values that do not parse are refused and change nothing; the
     environment is not read again after the first use (a later setenv has no effect)."""
