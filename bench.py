@@ -68,6 +68,9 @@ def parse_args(argv=None):
     ap.add_argument("--mode", default="SW")
     ap.add_argument("--search-type", type=int, default=None)
     ap.add_argument("--in-flight", type=int, default=2, choices=[1, 2], help="N = 1: searches queued on the handle (2: step i is enqueued behind step i-1, then the host waits for step i-1)")
+    ap.add_argument("--settle-ms", type=float, default=40.0, help="untimed steps for this many ms BEFORE the W warm-up steps: the GPU's clock "
+                    "governor raises the shader clock with sustained activity (2.07 GHz after an idle gap, 2.38 after ~20 ms of back-to-back "
+                    "launches: profiles/r05_clock_c2.txt); 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--query-fasta", default=None, help="use the first record of this FASTA file as the query")
@@ -468,6 +471,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # settle: the process has just generated and packed its database (host work, the GPU idle): the clock governor starts every
+    # burst of launches at its low point and needs ~20 ms of sustained activity to reach what it holds under load
+    settle_steps = 0
+    if args.settle_ms > 0:
+        t_settle = time.perf_counter()
+        while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms and settle_steps < 1000:
+            step()
+            settle_steps += 1
     for _ in range(args.warmup):
         step()
     flush()
@@ -552,14 +563,26 @@ def main():
         L.opalx_db_clock_probe.argtypes = [C.c_void_p, C.c_int]
         L.opalx_db_last_clock_ghz.restype = C.c_double
         L.opalx_db_last_clock_ghz.argtypes = [C.c_void_p]
+        # (round 5: the probed searches are QUEUED like the timed ones -- two in flight, no host round trip between them -- and run
+        # for >= 30 ms before the counters of the last one are read: a synchronous probe search starts after an idle gap, and the
+        # clock governor answers idle gaps of 2 ms with a lower clock (profiles/r05_clock_c2.txt: C2 read 2.13 GHz that way while
+        # its timed steps ran at ~2.3))
         L.opalx_db_clock_probe(pdb._h, 1)
-        clocks = []
-        for _ in range(5):
-            pdb.search_device(query, args.gap_open, args.gap_ext, matrix, args.search_type, mode, outs[0].data_ptr(),
-                              outs[0][npad:].data_ptr() if want_end else 0, outs[0][2 * npad:].data_ptr() if want_end else 0)
-            clocks.append(L.opalx_db_last_clock_ghz(pdb._h))
+        nprobe = int(min(40, max(4, np.ceil(30.0 / max(kms, 1e-3)))))
+        queued = 0
+        for i in range(nprobe):
+            o = outs[i % len(outs)]
+            if pdb.search_device_async(query, args.gap_open, args.gap_ext, matrix, args.search_type, mode, o.data_ptr(),
+                                       o[npad:].data_ptr() if want_end else 0, o[2 * npad:].data_ptr() if want_end else 0) != 0:
+                break
+            queued += 1
+            if queued == 2:
+                pdb.wait(); queued -= 1
+        clock_ghz = L.opalx_db_last_clock_ghz(pdb._h) if nprobe else 0.0  # (waits for the last search, reads ITS counters)
+        while queued > 0:
+            pdb.wait(); queued -= 1
         L.opalx_db_clock_probe(pdb._h, 0)
-        clock_ghz = float(np.median(clocks)) if clocks and min(clocks) > 0 else None
+        clock_ghz = float(clock_ghz) if clock_ghz and clock_ghz > 0 else None
 
         instr_per_cell = 9.0 if args.mode == "SW" else 6.0
         peak = valu_peak_gcups(instr_per_cell)
@@ -608,6 +631,9 @@ def main():
                                        ("two searches queued on the handle: step i enqueued behind step i-1, then step i-1 waited for" if args.in_flight == 2
                                         else "one search at a time: enqueued, waited for"))},
             "in_flight": 1 if multi else args.in_flight,
+            "settle": {"ms": args.settle_ms, "steps": settle_steps,
+                       "what": "untimed steps before the W warm-up steps, so that the timed region does not start on the clock governor's ramp "
+                               "(shader clock 2.07 GHz after an idle gap, 2.38 after ~20 ms of back-to-back launches: profiles/r05_clock_c2.txt)"},
             "ranks": {"kernel_ms": {"min": round(min(rank_kms), 4), "max": round(max(rank_kms), 4), "mean": round(float(np.mean(rank_kms)), 4),
                                     "per_rank": [round(v, 4) for v in rank_kms]},
                       "cells_per_step": {"min": min(rank_cells), "max": max(rank_cells)},
@@ -628,7 +654,8 @@ def main():
                          "model": f"1024 SIMDs x 2.4 GHz x 64 lanes / ({instr_per_cell:.0f} full-rate 16-bit instr x 2 clk per cell); "
                                   "kernel_ms = HIP events around all DP launches of a step on the launch stream (rank 0); clock_ghz = "
                                   "shader cycles / constant-rate ticks over one wave's lifetime per workgroup, measured in the DP kernels "
-                                  "themselves on 5 more searches after the timed region; frac_at_measured_clock prices the bound at it",
+                                  "themselves on the last of >= 30 ms of searches queued two deep after the timed region (as the timed steps are); "
+                                  "frac_at_measured_clock prices the bound at it",
                          "hbm": hbm},
         }
         if not verified:

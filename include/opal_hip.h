@@ -172,6 +172,15 @@ int opal_hip_memcpy_peer(void* dst, int dst_device, const void* src, int src_dev
 int opal_hip_enable_peer(int peer);   /* direct access from the current device to `peer` (0: enabled or same device) */
 /* out[perm[i]] = in[i] for i < count, on the device */
 int opal_hip_permute(const int* in, const int* perm, int count, int* out, void* stream);
+/* out[perm[k * per + j]] = in[k * block_stride + j] for k < blocks, j < per; perm < 0 = padding (the layout an RCCL gather of
+   equal-sized shard blocks leaves on the root) */
+int opal_hip_permute_blocks(const int* in, const int* perm, int blocks, int per, int block_stride, int* out, void* stream);
+/* The path's one collective through RCCL: a single-process communicator group over `devices` (all different;
+   librccl.so is dlopen()ed here, not linked), and one ncclGather of `count` ints per rank to rank 0 inside a group call --
+   send[k] and streams[k] on device k, recv_root ([n][count] ints) on devices[0]. init returns NULL if RCCL is not usable. */
+void* opal_hip_rccl_init(const int* devices, int n);
+void opal_hip_rccl_destroy(void* group);
+int opal_hip_rccl_gather(void* group, const void* const* send, void* recv_root, size_t count, void* const* streams);
 int opal_hip_memset(void* dst, int value, size_t bytes, void* stream);
 int opal_hip_memset32(void* dst, int value, size_t count, void* stream);   /* `count` 32-bit words */
 /* score[quads[4i]] = quads[4i+1], end_query[..] = quads[4i+2], end_target[..] = quads[4i+3]; `quads` on the device. */
@@ -198,6 +207,11 @@ int opal_hip_order_max_length(void);
 size_t opal_hip_order_scratch_bytes(int n, int max_len);
 int opal_hip_order_by_length(const int* d_lens, int n, int max_len, int num_nonempty, void* d_scratch, int* d_item_seq,
                              int* d_item_len, uint64_t* d_item_off, int* d_empty_seqs, void* stream);
+/* ... and, behind it on the same stream: for every byte offset d_targets[t], d_out[2t] = the first item at or behind it (of the
+   num_nonempty real items), d_out[2t+1] = that item's offset (total_bytes if there is none) -- where the fill's upload chunks and
+   gather pieces begin. */
+int opal_hip_order_cuts(const uint64_t* d_targets, int num_targets, const uint64_t* d_item_off, int num_nonempty,
+                        uint64_t total_bytes, uint64_t* d_out, void* stream);
 /* Enqueue one DP kernel. 0 on success, non-zero if the shape is not launchable. */
 int opal_hip_launch(const OpalHipLaunch* args);
 /* Smallest rows_per_lane >= min_rows for which this kernel variant is instantiated (0: none).
@@ -331,6 +345,9 @@ double opalx_db_last_clock_ghz(const OpalxDb* db);
    (opal_hip_wall_clock_hz per second) at its start and end; opalx_db_last_timeline copies them out
    ({start, end} per workgroup, in grid order; returns the number of workgroups, at most capacity / 2). */
 int opalx_db_last_timeline(OpalxDb* db, unsigned long long* out, int capacity);
+/* ... and the shader-clock cycle counter at the same two moments of every workgroup (same layout, same return value): cycles
+   per tick x opal_hip_wall_clock_hz = the clock that workgroup saw over its life. */
+int opalx_db_last_timeline_cycles(OpalxDb* db, unsigned long long* out, int capacity);
 int opalx_db_num_sequences(const OpalxDb* db);
 int64_t opalx_db_num_residues(const OpalxDb* db);
 
@@ -391,6 +408,10 @@ int opalx_multi_search_device_async(OpalxMultiDb* mdb, const unsigned char* quer
                                     const int* score_matrix, int alphabet_length, int search_type, int mode,
                                     int* d_score, int* d_end_query, int* d_end_target);
 int opalx_multi_wait(OpalxMultiDb* mdb, float* kernel_ms);
+/* How this handle gathers its shards' results on the root GPU: 0 = peer copies (hipMemcpyPeerAsync per shard and vector, the
+   default), 1 = one RCCL ncclGather per search (option OPAL_HIP_MULTI_GATHER=rccl when the handle was created; needs every
+   listed device to be a different GPU -- otherwise, or if librccl.so cannot be loaded, the handle falls back to peer copies). */
+int opalx_multi_gather_kind(const OpalxMultiDb* mdb);
 
 /*
  * Host traceback (no device work): for every result that holds a score and an end location, fill

@@ -118,24 +118,64 @@ static bool order_into(int n, const int* lens, OrderScratch& scratch, std::vecto
     return true;
 }
 
+// Upload chunks and gather pieces of a fill (db_fill): a CHUNK (~2 MB, fewer and larger ones for gigabyte databases) is what one
+// copy moves, a PIECE (~128 KB) what one pool task gathers.
+static void chunk_geometry(uint64_t total, uint64_t* chunkBytes, uint64_t* pieceBytes) {
+    *chunkBytes = opts().chunkBytes > 0 ? (uint64_t)opts().chunkBytes : std::max<uint64_t>(2u << 20, total / 96);
+    *pieceBytes = opts().chunkBytes > 0 ? std::max<uint64_t>(1024, *chunkBytes / 4) : std::max<uint64_t>(128u << 10, *chunkBytes / 16);
+}
+
+// Where they begin. item_at(b) -> {first item at or behind byte offset b, that item's own offset}; it is asked about the same
+// offsets in the same order whatever it answers, so the questions can be recorded first and answered by the device
+// (opal_hip_order_cuts) before the answers are replayed.
+template <typename F>
+static void plan_cuts(UploadGate& g, uint64_t total, size_t items, uint64_t chunkBytes, uint64_t pieceBytes, F&& item_at) {
+    g.cutItem.assign(1, 0); g.cutByte.assign(1, 0);
+    g.pieceCut.assign(1, 0); g.pieceByte.assign(1, 0);
+    g.pieceChunk.clear();
+    for (uint64_t cb = 0; cb < total; cb += chunkBytes) {
+        const int c = (int)g.cutItem.size() - 1;
+        const uint64_t ce = std::min<uint64_t>(cb + chunkBytes, total);
+        for (uint64_t pb = cb + pieceBytes; pb < ce; pb += pieceBytes) {
+            const std::pair<int, uint64_t> at = item_at(pb);
+            if (at.first > g.pieceCut.back() && at.first < (int)items) { g.pieceChunk.push_back(c); g.pieceCut.push_back(at.first); g.pieceByte.push_back(at.second); }
+        }
+        const std::pair<int, uint64_t> at = ce >= total ? std::make_pair((int)items, total) : item_at(ce);
+        if (at.first > g.pieceCut.back()) { g.pieceChunk.push_back(c); g.pieceCut.push_back(at.first); g.pieceByte.push_back(at.second); }
+        if (at.first > g.cutItem.back()) { g.cutItem.push_back(at.first); g.cutByte.push_back(at.second); }
+        if (at.first >= (int)items) break;
+    }
+    if (g.cutItem.back() != (int)items) {  // (rounding left a tail: it joins the last chunk)
+        if (g.cutItem.size() > 1) { g.cutItem.back() = (int)items; g.cutByte.back() = total; }
+        else { g.cutItem.push_back((int)items); g.cutByte.push_back(total); }
+        if (g.pieceCut.back() != (int)items) { g.pieceChunk.push_back((int)g.cutItem.size() - 2); g.pieceCut.push_back((int)items); g.pieceByte.push_back(total); }
+    } else {
+        g.cutByte.back() = total; g.pieceByte.back() = total;  // (the absent last item of an odd count sits AT the total)
+    }
+}
+
 // The same ordering on the DEVICE (order_kernel.hip): the lengths go up in one copy, four small launches sort them and
 // write the item arrays where the DP kernels read them, and the host's copies (the scheduler reads lengths, the gather
 // reads caller indices and offsets) come back in three copies. One pass of one host thread over the lengths (copy into pinned
 // memory, maximum, count of the empty ones, sum) instead of the histogram + scattered placement: on a cold
 // opalSearchDatabase call the ordering is what stands between the call and its first gathered residue.
 // Returns 0 done, 1 not applicable (small database, lengths beyond the kernel's table: the host orders), -1 failed.
-static int order_sequences_device(OpalxDb* db, int n, const int* lens, bool force = false) {
+static int order_sequences_device(OpalxDb* db, int n, const int* lens, bool force = false, const std::function<bool()>* meanwhile = nullptr,
+                                  bool wantCuts = false, std::vector<int>* keepLens = nullptr) {
     const int mode = force ? 1 : opts().deviceOrder;
     if (mode == 0 || n <= 0 || (mode < 0 && n < 16384)) return 1;
     const double t0 = now_ms();
     const double slack = db->cached ? 1.15 : 1.0;
     if (!db->hLens.resize((size_t)n, slack)) return -1;
+    if (keepLens) keepLens->resize((size_t)n);
     int* h = db->hLens.data();
     int maxLen = 0, nonEmpty = 0;
     int64_t total = 0;
+    int* const keep = keepLens ? keepLens->data() : nullptr;  // (cached contexts: the lengths as handed over, for the next call's "same database?")
     for (int i = 0; i < n; i++) {
         const int len = lens[i] > 0 ? lens[i] : 0;
         h[i] = len;
+        if (keep) keep[i] = lens[i];
         maxLen = std::max(maxLen, len);
         nonEmpty += len > 0;
         total += len;
@@ -143,38 +183,66 @@ static int order_sequences_device(OpalxDb* db, int n, const int* lens, bool forc
     if (maxLen > opal_hip_order_max_length()) return 1;
     const size_t items = ((size_t)nonEmpty + 1) / 2 * 2;
     const size_t empties = (size_t)n - (size_t)nonEmpty;
+    // the byte offsets at which the fill will want to cut its upload chunks and gather pieces (plan_cuts, recorded): the device
+    // answers them right behind the sort, so the item offsets themselves never come back to the host
+    db->cutTargets.clear();
+    if (wantCuts && total > 0) {
+        uint64_t chunkBytes, pieceBytes;
+        chunk_geometry((uint64_t)total, &chunkBytes, &pieceBytes);
+        db->cutTargetsChunk = chunkBytes; db->cutTargetsPiece = pieceBytes;
+        UploadGate scratchGate;
+        plan_cuts(scratchGate, (uint64_t)total, items, chunkBytes, pieceBytes, [&](uint64_t b) { db->cutTargets.push_back(b); return std::make_pair(0, (uint64_t)0); });
+    }
+    const size_t T = db->cutTargets.size();
     void* st = db->main();
     if (!st || !db->dLens.ensure((size_t)n, slack) || !db->dOrderScratch.ensure(opal_hip_order_scratch_bytes(n, maxLen), slack) ||
         !db->dSeqOff.ensure(items + 1, slack) || !db->dPairLen.ensure(items + 1, slack) || !db->dPairSeq.ensure(items + 1, slack) ||
-        !db->pairLen.resize(items, slack) || !db->pairSeq.resize(items, slack) || !db->seqOff.resize(items, slack) ||
+        !db->pairLen.resize(items, slack) || !db->pairSeq.resize(items, slack) ||
+        (!wantCuts && !db->seqOff.resize(items, slack)) ||
+        (T && (!db->dCuts.ensure(3 * T, 1.5) || !db->hCuts.resize(3 * T, 1.5))) ||
         (empties && (!db->dEmpty.ensure(empties, slack) || !db->hEmpty.resize(empties, slack))))
         return -1;
+    for (size_t t = 0; t < T; t++) db->hCuts[t] = db->cutTargets[t];
     const double t1 = now_ms();
     bool ok = !opal_hip_memcpy_h2d(db->dLens.p, h, (size_t)n * sizeof(int), st) &&
+              (!T || !opal_hip_memcpy_h2d(db->dCuts.p, db->hCuts.data(), T * sizeof(uint64_t), st)) &&
               !opal_hip_order_by_length(db->dLens.p, n, maxLen, nonEmpty, db->dOrderScratch.p, db->dPairSeq.p, db->dPairLen.p, db->dSeqOff.p,
-                                        db->dEmpty.p, st);
+                                        db->dEmpty.p, st) &&
+              (!T || !opal_hip_order_cuts(db->dCuts.p, (int)T, db->dSeqOff.p, nonEmpty, (uint64_t)total, db->dCuts.p + T, st));
     if (ok && items)
         ok = !opal_hip_memcpy_d2h(db->pairSeq.data(), db->dPairSeq.p, items * sizeof(int), st) &&
-             !opal_hip_memcpy_d2h(db->seqOff.data(), db->dSeqOff.p, items * sizeof(uint64_t), st) &&
-             !opal_hip_memcpy_d2h(db->pairLen.data(), db->dPairLen.p, items * sizeof(int), st);
+             !opal_hip_memcpy_d2h(db->pairLen.data(), db->dPairLen.p, items * sizeof(int), st) &&
+             (wantCuts || !opal_hip_memcpy_d2h(db->seqOff.data(), db->dSeqOff.p, items * sizeof(uint64_t), st));
+    if (ok && T) ok = !opal_hip_memcpy_d2h(db->hCuts.data() + T, db->dCuts.p + T, 2 * T * sizeof(uint64_t), st);
     if (ok && empties) ok = !opal_hip_memcpy_d2h(db->hEmpty.data(), db->dEmpty.p, empties * sizeof(int), st);
+    // (while the device sorts: whatever else the caller has to do before the gather can begin -- opalSearchDatabase looks
+    // through its N result structs for the ones that need computing; if they are not all of them, this ordering is dropped)
+    if (ok && meanwhile && !(*meanwhile)()) { opal_hip_stream_sync(st); return -2; }
     if (!ok || opal_hip_stream_sync(st)) return -1;
     db->emptySeqs.assign(db->hEmpty.data(), db->hEmpty.data() + empties);
     db->numSeqs = n;
     db->numPairs = (int)(items / 2);
     db->residues = total;
-    db->ordScratch.pos.clear(); db->ordScratch.byte.clear();  // (no bucket table of the host ordering: the chunk cuts search seqOff)
+    db->ordScratch.pos.clear(); db->ordScratch.byte.clear();
     db->deviceOrdered = true;
+    db->hostSeqOffValid = !wantCuts;
     if (debug_on()) fprintf(stderr, "[opal] order on the device: lengths staged %.3f ms, upload + sort + item arrays back %.3f ms\n", t1 - t0, now_ms() - t1);
     return 0;
 }
 
-static bool order_sequences(OpalxDb* db, int n, const int* lens, bool mayUseDevice) {
+static bool order_sequences(OpalxDb* db, int n, const int* lens, bool mayUseDevice, const std::function<bool()>* meanwhile, bool* keptLens) {
     db->deviceOrdered = false;
+    db->hostSeqOffValid = true;
+    db->cutTargets.clear();
+    *keptLens = false;
     if (mayUseDevice) {
-        const int r = order_sequences_device(db, n, lens);
+        const bool keep = db->cached;
+        const int r = order_sequences_device(db, n, lens, false, meanwhile, /*wantCuts=*/true, keep ? &db->lastLens : nullptr);
+        *keptLens = keep && r == 0;
+        if (r == -2) db->fillAborted = true;
         if (r <= 0) return r == 0;
     }
+    if (meanwhile && !(*meanwhile)()) { db->fillAborted = true; return false; }
     db->numSeqs = n;
     const double slack = db->cached ? 1.15 : 1.0;
     OrderScratch& scratch = db->ordScratch;
@@ -234,8 +302,9 @@ void db_release(OpalxDb* db) {
 }
 
 bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::function<const unsigned char*(int)>& getSeq,
-             const unsigned char* flatDevice, const std::function<uint64_t(int)>& flatOff, bool async) {
+             const unsigned char* flatDevice, const std::function<uint64_t(int)>& flatOff, bool async, const std::function<bool()>* meanwhile) {
     db->device = opal_hip_get_device();
+    db->fillAborted = false;
     db->gate.active = false;
     db->gate.speculated = false;
     db->gate.reuse = false;
@@ -252,11 +321,13 @@ bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::funct
     const bool reuse = db->cached && kind == RAW_POINTERS && db->lastValid && db->lastLens.size() == (size_t)n && n > 0 &&
                        !opts().noReuse && memcmp(db->lastLens.data(), lens, (size_t)n * sizeof(int)) == 0;
     db->lastValid = false;
+    if (reuse && meanwhile && !(*meanwhile)()) { db->fillAborted = true; return false; }
     if (!reuse) {
         db->seqItemValid = false;
         db->planCache.clear();
-        if (!order_sequences(db, n, lens, kind == RAW_POINTERS)) return false;
-        if (db->cached && kind == RAW_POINTERS) db->lastLens.assign(lens, lens + n);
+        bool keptLens = false;
+        if (!order_sequences(db, n, lens, kind == RAW_POINTERS, meanwhile, &keptLens)) return false;
+        if (db->cached && kind == RAW_POINTERS && !keptLens) db->lastLens.assign(lens, lens + n);
     }
     const double tf1 = now_ms();
     const size_t items = db->pairLen.size();
@@ -291,56 +362,67 @@ bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::funct
     db->hRaw.deviceCached = true;
     if (!db->hRaw.ensure(total + 16, slack) || !db->copy()) return false;
     UploadGate& g = db->gate;
-    const uint64_t chunkBytes = opts().chunkBytes > 0 ? (uint64_t)opts().chunkBytes : std::max<uint64_t>(2u << 20, total / 96);
-    const uint64_t pieceBytes = opts().chunkBytes > 0 ? std::max<uint64_t>(1024, chunkBytes / 4) : std::max<uint64_t>(128u << 10, chunkBytes / 16);
-    g.cutItem.assign(1, 0);
-    g.pieceCut.assign(1, 0);
-    g.pieceChunk.clear();
-    {
-        // cuts: the first item at or behind a byte offset = a binary search over the items' offsets (increasing in item order)
-        const uint64_t* so = db->seqOff.data();
-        auto item_at = [&](uint64_t target) -> int { return (int)(std::lower_bound(so, so + items, target) - so); };
-        const int mReal = (int)items;
-        for (uint64_t cb = 0; cb < total; cb += chunkBytes) {
-            const int c = (int)g.cutItem.size() - 1;
-            const uint64_t ce = std::min<uint64_t>(cb + chunkBytes, total);
-            for (uint64_t pb = cb + pieceBytes; pb < ce; pb += pieceBytes) {
-                const int at = item_at(pb);
-                if (at > g.pieceCut.back() && at < mReal) { g.pieceChunk.push_back(c); g.pieceCut.push_back(at); }
+    uint64_t chunkBytes, pieceBytes;
+    chunk_geometry(total, &chunkBytes, &pieceBytes);
+    const double tf2 = now_ms();
+    // (the same database as last time: the same cuts -- unless the chunk size was changed in between)
+    const bool keepCuts = reuse && g.cutsTotal == total && g.cutsItems == items && g.cutsChunkBytes == chunkBytes && g.cutsPieceBytes == pieceBytes &&
+                          g.cutItem.size() >= 2;
+    if (!keepCuts) {
+        auto host_seq_off = [&]() -> bool {  // the item offsets on the host (a device ordering leaves them on the device)
+            if (db->hostSeqOffValid) return true;
+            if (!db->seqOff.resize(items, slack) || opal_hip_memcpy_d2h(db->seqOff.data(), db->dSeqOff.p, items * sizeof(uint64_t), st) || opal_hip_stream_sync(st)) return false;
+            db->hostSeqOffValid = true;
+            return true;
+        };
+        if (db->deviceOrdered && !db->cutTargets.empty() && db->cutTargetsChunk == chunkBytes && db->cutTargetsPiece == pieceBytes) {
+            // the device has answered plan_cuts' questions already (order_sequences_device): replayed in the order they were asked
+            const size_t T = db->cutTargets.size();
+            size_t next = 0;
+            plan_cuts(g, total, items, chunkBytes, pieceBytes, [&](uint64_t) {
+                const size_t t = std::min(next++, T - 1);
+                return std::make_pair((int)db->hCuts[T + 2 * t], (uint64_t)db->hCuts[T + 2 * t + 1]);
+            });
+        } else {
+            if (!host_seq_off()) return false;
+            const uint64_t* so = db->seqOff.data();
+            plan_cuts(g, total, items, chunkBytes, pieceBytes, [&](uint64_t b) {
+                const size_t it = (size_t)(std::lower_bound(so, so + items, b) - so);
+                return std::make_pair((int)it, it < items ? so[it] : total);
+            });
+        }
+        // (strictly increasing cuts, every piece inside one chunk, offsets in step; otherwise: the plain walk over the items)
+        bool cutsOk = g.cutItem.size() >= 2 && g.cutItem.back() == (int)items && g.pieceCut.size() >= 2 && g.pieceCut.back() == (int)items &&
+                      g.pieceChunk.size() + 1 == g.pieceCut.size() && g.cutByte.size() == g.cutItem.size() && g.pieceByte.size() == g.pieceCut.size() &&
+                      g.cutByte.back() == total && g.pieceByte.back() == total;
+        for (size_t c = 0; cutsOk && c + 1 < g.cutItem.size(); c++) cutsOk = g.cutItem[c] < g.cutItem[c + 1] && g.cutByte[c] <= g.cutByte[c + 1];
+        for (size_t q = 0; cutsOk && q + 1 < g.pieceCut.size(); q++) {
+            const int c = g.pieceChunk[q];
+            cutsOk = g.pieceCut[q] < g.pieceCut[q + 1] && g.pieceByte[q] <= g.pieceByte[q + 1] && c >= 0 && c + 1 < (int)g.cutItem.size() &&
+                     g.cutItem[(size_t)c] <= g.pieceCut[q] && g.pieceCut[q + 1] <= g.cutItem[(size_t)c + 1];
+        }
+        if (!cutsOk) {
+            if (debug_on()) fprintf(stderr, "[opal] fill: chunk cuts rejected, walking the items\n");
+            if (!host_seq_off()) return false;
+            g.cutItem.assign(1, 0); g.cutByte.assign(1, 0);
+            g.pieceCut.assign(1, 0); g.pieceByte.assign(1, 0);
+            g.pieceChunk.clear();
+            for (size_t i = 0; i < items; i++) {
+                if (db->seqOff[i] - db->seqOff[(size_t)g.cutItem.back()] >= chunkBytes) {
+                    g.cutItem.push_back((int)i); g.cutByte.push_back(db->seqOff[i]);
+                    if (g.pieceCut.back() != (int)i) { g.pieceChunk.push_back((int)g.cutItem.size() - 2); g.pieceCut.push_back((int)i); g.pieceByte.push_back(db->seqOff[i]); }
+                } else if (db->seqOff[i] - db->seqOff[(size_t)g.pieceCut.back()] >= pieceBytes) {
+                    g.pieceChunk.push_back((int)g.cutItem.size() - 1); g.pieceCut.push_back((int)i); g.pieceByte.push_back(db->seqOff[i]);
+                }
             }
-            const int at = ce >= total ? (int)items : item_at(ce);
-            if (at > g.pieceCut.back()) { g.pieceChunk.push_back(c); g.pieceCut.push_back(at); }
-            if (at > g.cutItem.back()) g.cutItem.push_back(at);
-            if (at >= (int)items) break;
+            g.cutItem.push_back((int)items); g.cutByte.push_back(total);
+            if (g.pieceCut.back() != (int)items) { g.pieceChunk.push_back((int)g.cutItem.size() - 2); g.pieceCut.push_back((int)items); g.pieceByte.push_back(total); }
         }
-        if (g.cutItem.back() != (int)items) {  // (rounding left a tail: it joins the last chunk)
-            if (g.cutItem.size() > 1) g.cutItem.back() = (int)items; else g.cutItem.push_back((int)items);
-            if (g.pieceCut.back() != (int)items) { g.pieceChunk.push_back((int)g.cutItem.size() - 2); g.pieceCut.push_back((int)items); }
-        }
-    }
-    // (the arithmetic above must give strictly increasing cuts, every piece inside one chunk; otherwise: the plain walk)
-    bool cutsOk = g.cutItem.size() >= 2 && g.cutItem.back() == (int)items && g.pieceCut.size() >= 2 && g.pieceCut.back() == (int)items &&
-                  g.pieceChunk.size() + 1 == g.pieceCut.size();
-    for (size_t c = 0; cutsOk && c + 1 < g.cutItem.size(); c++) cutsOk = g.cutItem[c] < g.cutItem[c + 1];
-    for (size_t q = 0; cutsOk && q + 1 < g.pieceCut.size(); q++) {
-        const int c = g.pieceChunk[q];
-        cutsOk = g.pieceCut[q] < g.pieceCut[q + 1] && c >= 0 && c + 1 < (int)g.cutItem.size() && g.cutItem[(size_t)c] <= g.pieceCut[q] &&
-                 g.pieceCut[q + 1] <= g.cutItem[(size_t)c + 1];
-    }
-    if (!cutsOk) {
-        if (debug_on()) fprintf(stderr, "[opal] fill: chunk cuts from the bucket table rejected, walking the items\n");
-        g.cutItem.assign(1, 0);
-        g.pieceCut.assign(1, 0);
-        g.pieceChunk.clear();
-        for (size_t i = 0; i < items; i++) {
-            if (db->seqOff[i] - db->seqOff[(size_t)g.cutItem.back()] >= chunkBytes) { g.cutItem.push_back((int)i); if (g.pieceCut.back() != (int)i) { g.pieceChunk.push_back((int)g.cutItem.size() - 2); g.pieceCut.push_back((int)i); } }
-            else if (db->seqOff[i] - db->seqOff[(size_t)g.pieceCut.back()] >= pieceBytes) { g.pieceChunk.push_back((int)g.cutItem.size() - 1); g.pieceCut.push_back((int)i); }
-        }
-        g.cutItem.push_back((int)items);
-        if (g.pieceCut.back() != (int)items) { g.pieceChunk.push_back((int)g.cutItem.size() - 2); g.pieceCut.push_back((int)items); }
+        g.cutsTotal = total; g.cutsItems = items; g.cutsChunkBytes = chunkBytes; g.cutsPieceBytes = pieceBytes;
     }
     const int nchunks = (int)g.cutItem.size() - 1;
     const int npieces = (int)g.pieceCut.size() - 1;
+    const double tf3 = now_ms();
     if (debug_on() && !g.timed) {  // (debug: timed chunk events, to print when each chunk's copy completed)
         for (void*& ev : g.events) opal_hip_event_destroy(ev);
         g.events.clear();
@@ -362,19 +444,22 @@ bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::funct
     for (int p = 0; p < npieces; p++) g.left[(size_t)g.pieceChunk[(size_t)p]].fetch_add(1, std::memory_order_relaxed);
     const int dev = db->device;
     for (int c = 0; c < nchunks; c++) { g.dirty[(size_t)c].store(reuse ? 0 : 1, std::memory_order_relaxed); g.copied[(size_t)c].store(0, std::memory_order_relaxed); }
-    db->gatherFn = [db, getSeq, dev, total, items, reuse](int p) {
+    db->gatherFn = [db, getSeq, dev, reuse](int p) {
         static thread_local int myDevice = -1;  // pool threads start on device 0: the copy below names a stream of `dev`
         if (myDevice != dev) { opal_hip_set_device(dev); myDevice = dev; }
         UploadGate& gg = db->gate;
         unsigned char* h = db->hRaw.p;
-        const int* len = db->pairLen.data(); const int* seq = db->pairSeq.data(); const uint64_t* off = db->seqOff.data();
+        const int* len = db->pairLen.data(); const int* seq = db->pairSeq.data();
         const int c = gg.pieceChunk[(size_t)p];
         bool changed = false;
+        uint64_t off = gg.pieceByte[(size_t)p];  // items lie back to back in item order: the offset runs along
         for (size_t i = (size_t)gg.pieceCut[(size_t)p], i1 = (size_t)gg.pieceCut[(size_t)p + 1]; i < i1; i++) {
             if (seq[i] < 0 || len[i] <= 0) continue;
             const unsigned char* src = getSeq(seq[i]);
-            if (reuse && memcmp(h + off[i], src, (size_t)len[i]) == 0) continue;  // what the device already holds
-            memcpy(h + off[i], src, (size_t)len[i]);
+            unsigned char* dst = h + off;
+            off += (uint64_t)len[i];
+            if (reuse && memcmp(dst, src, (size_t)len[i]) == 0) continue;  // what the device already holds
+            memcpy(dst, src, (size_t)len[i]);
             changed = true;
         }
         if (reuse && changed) gg.dirty[(size_t)c].store(1, std::memory_order_relaxed);
@@ -384,8 +469,7 @@ bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::funct
         bool good = true;
         if (gg.dirty[(size_t)c].load(std::memory_order_relaxed) && !gg.zeroCopy) {
             gg.copied[(size_t)c].store(1, std::memory_order_relaxed);
-            const size_t i0 = (size_t)gg.cutItem[(size_t)c], i1 = (size_t)gg.cutItem[(size_t)c + 1];
-            const uint64_t b0 = off[i0], b1 = i1 < items ? off[i1] : total;
+            const uint64_t b0 = gg.cutByte[(size_t)c], b1 = gg.cutByte[(size_t)c + 1];
             const bool two = !opts().oneCopyStream;
             void* cs = (two && (c & 1)) ? db->copyStream2 : db->copyStream;
             if (b1 > b0 && opal_hip_memcpy_h2d(db->res.p + b0, h + b0, b1 - b0, cs)) good = false;
@@ -408,7 +492,7 @@ bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::funct
     HostPool& pool = HostPool::get();
     if (g.timed) opal_hip_event_record(db->event(7), db->copyStream);  // (debug reference: the copy stream when the gather begins)
     db->fillT0 = now_ms();
-    if (debug_on()) fprintf(stderr, "[opal] fill: %s %.3f ms, metadata + chunk plan %.3f ms, %d chunks of ~%.1f MB in %d pieces\n", reuse ? "same lengths as the last call (order kept):" : "order", tf1 - tf0, db->fillT0 - tf1, nchunks, (double)chunkBytes / 1048576.0, npieces);
+    if (debug_on()) fprintf(stderr, "[opal] fill: %s %.3f ms, metadata + chunk plan %.3f ms (buffers %.3f, cuts %.3f), %d chunks of ~%.1f MB in %d pieces\n", reuse ? "same lengths as the last call (order kept):" : "order", tf1 - tf0, db->fillT0 - tf1, tf2 - tf1, tf3 - tf2, nchunks, (double)chunkBytes / 1048576.0, npieces);
     if (async) {
         // A database found again is searched SPECULATIVELY: the launches do not wait for the comparison (no gate), the
         // caller repeats the search if db_fill_finish reports that a chunk had changed after all (fill_changed()).
@@ -486,9 +570,7 @@ bool gate_items(OpalxDb* db, void* stream, int firstItem, int count, bool needDe
         if (!needDevice) continue;
         if (g.zeroCopy && g.copied[(size_t)c].exchange(1, std::memory_order_acq_rel) == 0) {
             // a zero-copy fill copies a chunk only when something asks for its device copy: now
-            const size_t items = db->pairLen.size();
-            const size_t i0 = (size_t)g.cutItem[(size_t)c], i1 = (size_t)g.cutItem[(size_t)c + 1];
-            const uint64_t b0 = db->seqOff[i0], b1 = i1 < items ? db->seqOff[i1] : (uint64_t)db->residues;
+            const uint64_t b0 = g.cutByte[(size_t)c], b1 = g.cutByte[(size_t)c + 1];
             void* cs = (c & 1) ? db->copyStream2 : db->copyStream;
             if ((b1 > b0 && opal_hip_memcpy_h2d(db->res.p + b0, db->hRaw.p + b0, b1 - b0, cs)) || opal_hip_event_record(g.events[(size_t)c], cs)) return false;
             g.uploaded.fetch_add(1, std::memory_order_relaxed);
@@ -592,7 +674,7 @@ extern "C" int opalx_debug_order_device(const int* lens, int n, int* seq, int* l
     OpalxDb* db = new (std::nothrow) OpalxDb;
     if (!db) return -1;
     int items = -1;
-    if (order_sequences_device(db, n, lens, /*force=*/true) == 0 && db->pairLen.size() <= (size_t)capacity) {
+    if (order_sequences_device(db, n, lens, /*force=*/true) == 0 && db->pairLen.size() <= (size_t)capacity) {  // (without cuts: the offsets come back)
         items = (int)db->pairLen.size();
         for (int i = 0; i < items; i++) { seq[i] = db->pairSeq[(size_t)i]; len[i] = db->pairLen[(size_t)i]; off[i] = db->seqOff[(size_t)i]; }
         *num_empties = (int)db->emptySeqs.size();
@@ -661,6 +743,25 @@ extern "C" int opalx_db_last_timeline(OpalxDb* db, unsigned long long* out, int 
     while (n > 0 && out[2 * (size_t)n - 1] == 0) n--;
     return n;
 }
-extern "C" double opalx_db_last_clock_ghz(const OpalxDb* db) { return db ? db->lastClockGhz : 0.0; }
+extern "C" int opalx_db_last_timeline_cycles(OpalxDb* db, unsigned long long* out, int capacity) {
+    if (!db || !db->timeline.p || db->timeline.cap < 4 * 65536 || capacity < 2) return 0;
+    const int blocks = std::min(capacity / 2, 65536);
+    void* st = db->main();
+    if (opal_hip_memcpy_d2h(out, db->timeline.p + 2 * 65536, (size_t)blocks * 2 * sizeof(unsigned long long), st) || opal_hip_stream_sync(st)) return 0;
+    int n = blocks;
+    while (n > 0 && out[2 * (size_t)n - 1] == 0) n--;
+    return n;
+}
+extern "C" double opalx_db_last_clock_ghz(const OpalxDb* dbc) {
+    OpalxDb* db = const_cast<OpalxDb*>(dbc);
+    if (!db) return 0.0;
+    if (db->clockProbe && db->header.p) {  // (the counters of the last search enqueued on the handle: waits for it)
+        unsigned long long v[2] = {0, 0};
+        void* st = db->main();
+        if (st && !opal_hip_memcpy_d2h(v, db->header.p + 16, sizeof v, st) && !opal_hip_stream_sync(st) && v[1])
+            db->lastClockGhz = (double)v[0] / (double)v[1] * opal_hip_wall_clock_hz() * 1e-9;
+    }
+    return db->lastClockGhz;
+}
 extern "C" int opalx_db_num_sequences(const OpalxDb* db) { return db ? db->numSeqs : 0; }
 extern "C" int64_t opalx_db_num_residues(const OpalxDb* db) { return db ? db->residues : 0; }

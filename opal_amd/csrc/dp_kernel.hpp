@@ -86,7 +86,8 @@ struct KParams {
     // sustained under THIS kernel (it clocks to its power budget: MI355X_MICROARCH.md, DVFS).
     unsigned long long* clk;
     // Timeline probe (off = nullptr): every workgroup writes the constant-rate ticks at its start and end to
-    // tl[2 * blockIdx.x], tl[2 * blockIdx.x + 1] (scripts/gpu_timeline.py: where the time of a launch goes).
+    // tl[2 * blockIdx.x], tl[2 * blockIdx.x + 1] (scripts/gpu_timeline.py: where the time of a launch goes), and the shader
+    // cycles at the same moments to tl[2 * 65536 + ...] (scripts/gpu_clock_timeline.py: the clock over the life of a launch).
     unsigned long long* tl;
 };
 
@@ -110,7 +111,11 @@ __device__ __forceinline__ void clk_end(const unsigned char* slot) {
             atomicAdd(clk + 1, (unsigned long long)wall_clock64() - s[1]);
         }
         unsigned long long* tl = reinterpret_cast<unsigned long long*>((uintptr_t)s[3]);
-        if (tl && blockIdx.x < 65536u) { tl[2 * (size_t)blockIdx.x] = s[1]; tl[2 * (size_t)blockIdx.x + 1] = (unsigned long long)wall_clock64(); }
+        if (tl && blockIdx.x < 65536u) {
+            tl[2 * (size_t)blockIdx.x] = s[1]; tl[2 * (size_t)blockIdx.x + 1] = (unsigned long long)wall_clock64();
+            // ... and the shader cycles at the same two moments (second half of the buffer): the clock this workgroup saw
+            tl[2 * 65536 + 2 * (size_t)blockIdx.x] = s[0]; tl[2 * 65536 + 2 * (size_t)blockIdx.x + 1] = (unsigned long long)clock64();
+        }
     }
 }
 

@@ -22,7 +22,9 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -89,10 +91,34 @@ public:
         submit_.unlock();
     }
 
+    // CPU cores this process may use on average (cgroup v2 cpu.max, v1 cfs quota), 0 = no limit known.
+    static double cpu_quota_cores() {
+        double cores = 0;
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64] = {0};
+            double period = 0;
+            if (fscanf(f, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) cores = atof(q) / period;
+            fclose(f);
+            return cores;
+        }
+        double quota = 0, period = 0;
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(f, "%lf", &quota) != 1) quota = 0; fclose(f); }
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f, "%lf", &period) != 1) period = 0; fclose(f); }
+        return quota > 0 && period > 0 ? quota / period : 0;
+    }
     static int default_threads() {
         unsigned nt = std::thread::hardware_concurrency();
         if (nt == 0) nt = 1;
         if (nt > 64) nt = 64;  // memcpy-bound work: more threads than memory channels do not help
+        // A container with a CPU quota: one and a half times the quota, not every hardware thread. Measured on the GPU box (256
+        // hardware threads, quota 16 cores), cold opalSearchDatabase call on C2, best of 12, two rounds: 64 threads 2.46-2.60 ms,
+        // 48 threads 2.43-2.45, 32 threads 2.33-2.48, 24 threads 2.31-2.33, 16 threads 2.37-2.52 (profiles/r05_e2e_variants.txt) --
+        // 64 runnable threads on 16 cores' worth of time get throttled in the middle of a gather.
+        const double quota = cpu_quota_cores();
+        if (quota > 0) {
+            const unsigned cap = (unsigned)(1.5 * quota + 0.5);
+            if (nt > cap) nt = cap < 4 ? 4 : cap;
+        }
         if (opal_host::opts().hostThreads >= 1) nt = (unsigned)opal_host::opts().hostThreads;  // (read when the pool is created: once per process)
         return (int)nt;
     }

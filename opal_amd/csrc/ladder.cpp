@@ -196,8 +196,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
         // (a database seen for the first time: the launches read the pinned staging buffer over PCIe and write the device copy
         // -- on the kernels instantiated with that store: SW score searches that run as one grid, inst_uber_swzc.hip)
         zc.zeroCopy = g.zeroCopy && oneGrid && width == 17 && c.mode == OPAL_MODE_SW && !swEndPass && opal_hip_uber_supported(OPAL_MODE_SW, 16, 0, bulk.rows);
-        if (zc.zeroCopy && firstItem == 0 && numItems == 2 * db->numPairs) db->gate.kernelFilled = true;  // ... and write the device copy)
-        else if (zc.zeroCopy && firstItem + numItems == 2 * db->numPairs) db->gate.kernelFilledFrom = firstItem;  // (the items before: the swapped launch asked for their chunks' copies)
+        const int zcFrom = opts().zcFromSlice;  // slices [0, zcFrom) take the upload path (their chunks copied when asked for), the others read pinned memory
         // chunks per slice, the rest in the last one (C2: 17 chunks of 2 MB). The FIRST slice holds the long classes: its
         // longest sequence is the critical path of the whole search, so it is as small as it can be (it starts as soon as
         // one chunk has landed) and runs on a high-priority side stream of its own; the others take `main` and `aux` in
@@ -224,6 +223,14 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
             }
         }
         cut.push_back(firstItem + numItems);
+        if (zc.zeroCopy) {
+            // ... and the kernels that read pinned memory write the device copy: of every item, or of the items from some slice on
+            // (the chunks of the items before it are copied when their launches -- or the swapped launch -- ask for them)
+            const int filledFrom = zcFrom < (int)cut.size() - 1 ? cut[(size_t)zcFrom] : INT_MAX;
+            if (filledFrom == 0 && numItems == 2 * db->numPairs) db->gate.kernelFilled = true;
+            else if (filledFrom != INT_MAX && firstItem + numItems == 2 * db->numPairs) db->gate.kernelFilledFrom = filledFrom;
+            if (filledFrom == INT_MAX) zc.zeroCopy = false;
+        }
         void* fork = db->event(0);
         void* aux = db->aux();
         void* side = db->stream(0);
@@ -246,16 +253,18 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
             if (j > 0 && how == 1) stream = (j & 1) ? db->main() : aux;
             if (j > 0 && how == 2) stream = j == 1 ? db->main() : j == 2 ? aux : db->stream(1 + (int)(j & 1));
             auxUsed |= stream != side && stream != db->main();
-            if (!gate_items(db, stream, cut[j], cut[j + 1] - cut[j], /*needDevice=*/!zc.zeroCopy)) { err = 1; break; }
+            const bool zcj = zc.zeroCopy && (int)j >= zcFrom;
+            const SearchCtx& cx = zcj ? zc : c;
+            if (!gate_items(db, stream, cut[j], cut[j + 1] - cut[j], /*needDevice=*/!zcj)) { err = 1; break; }
             if (dbg) { void* ev = opal_hip_event_create(); marks.push_back(ev); if (ev) opal_hip_event_record(ev, stream); }
-            if (oneGrid) err = launch_grid(zc, cut[j], cut[j + 1], stream);
+            if (oneGrid) err = launch_grid(cx, cut[j], cut[j + 1], stream);
             else
                 for (size_t ki = 0; ki < classes.size() && !err; ki++) {
                     LaunchClass k = classes[ki];
                     const int a = std::max(k.first, cut[j]), b = std::min(k.first + k.count, cut[j + 1]);
                     if (b <= a) continue;
                     k.first = a; k.count = b - a;
-                    err = launch_class(zc, width, swEndPass, detectWrap, nullptr, k, maySkew && skew_ok(classes[ki].first), ovfCounter, stream, ki + 1 < classes.size());
+                    err = launch_class(cx, width, swEndPass, detectWrap, nullptr, k, maySkew && skew_ok(classes[ki].first), ovfCounter, stream, ki + 1 < classes.size());
                 }
             if (dbg) { void* ev = opal_hip_event_create(); marks.push_back(ev); if (ev) opal_hip_event_record(ev, stream); }
         }
@@ -429,7 +438,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
     if (Q == 0 || P == 0) return opal_hip_stream_sync(st) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
 
     if (ensure_query_buffers(db, query, Q, M, A)) return OPAL_ERR_NO_SIMD_SUPPORT;  // (also zeroes the counters)
-    if (db->clockProbe && db->timelineProbe && (!db->timeline.ensure(2 * 65536) || opal_hip_memset(db->timeline.p, 0, 2 * 65536 * sizeof(unsigned long long), st)))
+    if (db->clockProbe && db->timelineProbe && (!db->timeline.ensure(4 * 65536) || opal_hip_memset(db->timeline.p, 0, 4 * 65536 * sizeof(unsigned long long), st)))
         return OPAL_ERR_NO_SIMD_SUPPORT;
 
     long long maxS = 0, minS = 0;
@@ -800,7 +809,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
     // (a caller that copies the results back on the same stream and waits for that copy needs no wait of its own here)
     if ((finalSync || kernelMs) && opal_hip_stream_sync(st)) return OPAL_ERR_NO_SIMD_SUPPORT;
     if (kernelMs && evStart && evStop) *kernelMs = opal_hip_event_elapsed_ms(evStart, evStop);
-    if (db->clockProbe) {  // (measurement runs only: one more small copy and wait)
+    if (db->clockProbe && !db->asyncTimed) {  // (measurement runs only: one more small copy and wait; queued searches: opalx_db_last_clock_ghz reads it)
         unsigned long long v[2] = {0, 0};
         if (!opal_hip_memcpy_d2h(v, db->header.p + 16, sizeof v, st) && !opal_hip_stream_sync(st) && v[1])
             db->lastClockGhz = (double)v[0] / (double)v[1] * opal_hip_wall_clock_hz() * 1e-9;

@@ -155,6 +155,12 @@ struct OpalxMultiDb {
     unsigned head = 0, tail = 0;
     void* rootDone[OPALX_ASYNC_DEPTH] = {};  // recorded on the root stream behind a search's permutation
     int queuedRc[OPALX_ASYNC_DEPTH] = {};
+    // OPAL_HIP_MULTI_GATHER=rccl: the gather is ONE ncclGather per search instead of peer copies. Every shard's
+    // block is padded to the largest shard (a gather moves equal counts): res[k] = [3][maxCount], the root receives
+    // [shards][3][maxCount] and permutes through permPad (-1 = padding).
+    void* rccl = nullptr;
+    int maxCount = 0;
+    opal_host::DevBuf<int> gatheredR, permPad;
 };
 
 using namespace opal_host;
@@ -168,9 +174,10 @@ extern "C" void opalx_multi_destroy(OpalxMultiDb* m) {
         if (k < m->res.size()) m->res[k].release();
         if (k < m->done.size()) opal_hip_event_destroy(m->done[k]);
     }
+    if (m->rccl) opal_hip_rccl_destroy(m->rccl);
     if (!m->devices.empty()) {
         opal_hip_set_device(m->devices[0]);
-        m->gathered.release(); m->perm.release();
+        m->gathered.release(); m->perm.release(); m->gatheredR.release(); m->permPad.release();
         if (m->rootStream) opal_hip_stream_sync(m->rootStream);
         for (void*& ev : m->rootDone) { opal_hip_event_destroy(ev); ev = nullptr; }
         opal_hip_stream_destroy(m->rootStream);
@@ -199,6 +206,11 @@ extern "C" OpalxMultiDb* opalx_multi_create_flat(const unsigned char* residues, 
     std::vector<int> permHost;
     permHost.reserve((size_t)db_length);
     bool ok = true;
+    for (const auto& ids : deal) m->maxCount = std::max(m->maxCount, (int)ids.size());
+    if (opts().multiGatherRccl) {
+        m->rccl = opal_hip_rccl_init(devices, num_devices);
+        if (!m->rccl) fprintf(stderr, "[opal] OPAL_HIP_MULTI_GATHER=rccl: %s -- this handle gathers by peer copies\n", opal_hip_last_error());
+    }
     for (int k = 0; k < num_devices && ok; k++) {
         const std::vector<int>& ids = deal[(size_t)k];
         m->first.push_back((int)permHost.size());
@@ -212,7 +224,8 @@ extern "C" OpalxMultiDb* opalx_multi_create_flat(const unsigned char* residues, 
         m->shard[(size_t)k] = db;
         ok = db_fill(db, (int)ids.size(), slens.data(), RAW_POINTERS,
                      [residues, offsets, &ids](int i) { return residues + offsets[ids[(size_t)i]]; }, nullptr, nullptr) &&
-             m->res[(size_t)k].ensure(3 * std::max<size_t>(ids.size(), 1)) && (m->done[(size_t)k] = opal_hip_event_create_untimed()) != nullptr;
+             m->res[(size_t)k].ensure(3 * std::max<size_t>(m->rccl ? (size_t)m->maxCount : ids.size(), 1)) &&
+             (m->done[(size_t)k] = opal_hip_event_create_untimed()) != nullptr;
         if (ok && devices[k] != devices[0]) opal_hip_enable_peer(devices[0]);  // (without it the copy is staged through the host)
     }
     if (ok) {
@@ -220,6 +233,14 @@ extern "C" OpalxMultiDb* opalx_multi_create_flat(const unsigned char* residues, 
              m->perm.ensure(std::max<size_t>((size_t)db_length, 1)) && (m->rootStream = opal_hip_stream_create()) != nullptr;
         if (ok && db_length)
             ok = !opal_hip_memcpy_h2d(m->perm.p, permHost.data(), (size_t)db_length * sizeof(int), m->rootStream) && !opal_hip_stream_sync(m->rootStream);
+        if (ok && m->rccl && db_length) {
+            const size_t K = (size_t)num_devices, per = (size_t)m->maxCount;
+            std::vector<int> pad(K * per, -1);
+            for (size_t k = 0; k < K; k++)
+                for (int i = 0; i < m->count[k]; i++) pad[k * per + (size_t)i] = permHost[(size_t)m->first[k] + (size_t)i];
+            ok = m->gatheredR.ensure(K * 3 * per) && m->permPad.ensure(K * per) &&
+                 !opal_hip_memcpy_h2d(m->permPad.p, pad.data(), pad.size() * sizeof(int), m->rootStream) && !opal_hip_stream_sync(m->rootStream);
+        }
     }
     if (cur >= 0) opal_hip_set_device(cur);
     if (!ok) { opalx_multi_destroy(m); return nullptr; }
@@ -250,14 +271,19 @@ extern "C" int opalx_multi_search_device_async(OpalxMultiDb* m, const unsigned c
     const int cur = opal_hip_get_device();
     run_on_device_workers(K, [&](size_t k) {
         const int n = m->count[k];
-        if (!n) return;
+        if (!n && !m->rccl) return;
         // device_ok() first: its once-per-thread OPAL_HIP_DEVICE selection must not override the shard's GPU
         if (!device_ok() || opal_hip_set_device(m->devices[k])) { rcs[k] = OPAL_ERR_NO_SIMD_SUPPORT; return; }
         OpalxDb* db = m->shard[k];
+        if (!n) {  // (RCCL: a shard without sequences still takes part in the gather, behind the root's previous permutation)
+            if (prevDone && db->main() && opal_hip_stream_wait_event(db->main(), prevDone)) rcs[k] = OPAL_ERR_NO_SIMD_SUPPORT;
+            return;
+        }
         int* r = m->res[k].p;
+        const size_t vs = m->rccl ? (size_t)m->maxCount : (size_t)n;  // stride between the three result vectors of the shard's block
         const unsigned headBefore = db->asyncHead;
         rcs[k] = opalx_search_device_async(db, query, query_length, gap_open, gap_ext, score_matrix, alphabet_length, search_type, mode, r,
-                                           wantEnd ? r + n : nullptr, wantEnd ? r + 2 * (size_t)n : nullptr);
+                                           wantEnd ? r + vs : nullptr, wantEnd ? r + 2 * vs : nullptr);
         if (rcs[k] == OPAL_ERR_NO_SIMD_SUPPORT || rcs[k] == OPAL_ERR_INVALID_MODE) return;
         // (a search refused before anything was launched -- arguments beyond 32 bits: OPAL_ERR_OVERFLOW -- took no place in
         // the shard's queue and wrote no block: there is nothing to gather and nothing to wait for)
@@ -266,6 +292,7 @@ extern "C" int opalx_multi_search_device_async(OpalxMultiDb* m, const unsigned c
         // place in the gathered block, on the shard's own stream behind its kernels
         void* st = db->main();
         int e = prevDone ? opal_hip_stream_wait_event(st, prevDone) : 0;
+        if (m->rccl) { if (e) rcs[k] = OPAL_ERR_NO_SIMD_SUPPORT; return; }  // (the gather is one group call, below)
         for (int v = 0; v < nres; v++)
             e |= opal_hip_memcpy_peer(m->gathered.p + (size_t)v * total + (size_t)m->first[k], m->devices[0], r + (size_t)v * n, m->devices[k],
                                       (size_t)n * sizeof(int), st);
@@ -288,11 +315,28 @@ extern "C" int opalx_multi_search_device_async(OpalxMultiDb* m, const unsigned c
     }
     int e = opal_hip_set_device(m->devices[0]);
     if (nQueued != nAsked) e = 1;
+    if (!e && m->rccl && rc != OPAL_ERR_NO_SIMD_SUPPORT && rc != OPAL_ERR_INVALID_MODE) {
+        // the path's one collective: every shard's padded block to the root in ONE ncclGather, each rank on its shard's stream
+        // behind its kernels (a shard without sequences still takes part: a collective needs every rank)
+        std::vector<const void*> send(K);
+        std::vector<void*> streams(K);
+        for (size_t k = 0; k < K; k++) { send[k] = m->res[k].p; streams[k] = m->shard[k]->main(); }
+        e |= opal_hip_rccl_gather(m->rccl, send.data(), m->gatheredR.p, (size_t)nres * (size_t)m->maxCount, streams.data());
+        for (size_t k = 0; k < K && !e; k++) {
+            e |= opal_hip_set_device(m->devices[k]);
+            e |= opal_hip_event_record(m->done[k], streams[k]);
+        }
+        e |= opal_hip_set_device(m->devices[0]);
+    }
     if (!e && rc != OPAL_ERR_NO_SIMD_SUPPORT && rc != OPAL_ERR_INVALID_MODE) {
         // root: behind every shard's copy, the three vectors into database order
         for (size_t k = 0; k < K; k++)
-            if (m->count[k]) e |= opal_hip_stream_wait_event(m->rootStream, m->done[k]);
+            if (m->count[k] || m->rccl) e |= opal_hip_stream_wait_event(m->rootStream, m->done[k]);
         int* outs[3] = {d_score, d_end_query, d_end_target};
+        if (m->rccl)
+            for (int v = 0; v < nres; v++)
+                e |= opal_hip_permute_blocks(m->gatheredR.p + (size_t)v * (size_t)m->maxCount, m->permPad.p, (int)K, m->maxCount, nres * m->maxCount, outs[v], m->rootStream);
+        else
         for (int v = 0; v < nres; v++) e |= opal_hip_permute(m->gathered.p + (size_t)v * total, m->perm.p, m->total, outs[v], m->rootStream);
         if (!m->rootDone[slot]) m->rootDone[slot] = opal_hip_event_create_untimed();
         e |= !m->rootDone[slot] || opal_hip_event_record(m->rootDone[slot], m->rootStream);
@@ -338,6 +382,8 @@ extern "C" int opalx_multi_wait(OpalxMultiDb* m, float* kernel_ms) {
     if (cur >= 0) opal_hip_set_device(cur);
     return e ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
 }
+
+extern "C" int opalx_multi_gather_kind(const OpalxMultiDb* m) { return m && m->rccl ? 1 : 0; }
 
 extern "C" int opalx_multi_search_device(OpalxMultiDb* m, const unsigned char* query, int query_length, int gap_open, int gap_ext,
                                          const int* score_matrix, int alphabet_length, int search_type, int mode,

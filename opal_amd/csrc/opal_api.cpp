@@ -22,6 +22,8 @@ using namespace opal_host;
 
 namespace {
 
+constexpr int RUN_SHARD_DROPPED = -1000;  // run_shard: the `meanwhile` hook ended the fill (not an error of the device)
+
 /*
  * One shard of an opalSearchDatabase call on the calling thread's current device: order, gather + upload, search,
  * download. `ids` (may be null = identity) maps shard position -> caller index; results land in
@@ -31,7 +33,8 @@ namespace {
  */
 static int run_shard(int device, const unsigned char* query, int Q, unsigned char* const* db, const int* dbLens, const int* ids,
                      int n, int Go, int Ge, const int* M, int A, int searchType, int mode, int* score, int* endQ, int* endT,
-                     double* tms, int* startQ = nullptr, int* startT = nullptr, TraceOut* trace = nullptr) {
+                     double* tms, int* startQ = nullptr, int* startT = nullptr, TraceOut* trace = nullptr,
+                     const std::function<bool()>* meanwhile = nullptr) {
     BorrowedContext ctx(device);
     OpalxDb* pdb = ctx.db;
     if (!pdb) return OPAL_ERR_NO_SIMD_SUPPORT;
@@ -49,8 +52,8 @@ static int run_shard(int device, const unsigned char* query, int Q, unsigned cha
         ~FillGuard() { db_fill_finish(db); }
     } guard{pdb};
     const bool async = !opts().syncFill;
-    if (!db_fill(pdb, n, lens, RAW_POINTERS, [db, ids](int i) { return (const unsigned char*)db[ids ? ids[i] : i]; }, nullptr, nullptr, async))
-        return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (!db_fill(pdb, n, lens, RAW_POINTERS, [db, ids](int i) { return (const unsigned char*)db[ids ? ids[i] : i]; }, nullptr, nullptr, async, meanwhile))
+        return pdb->fillAborted ? RUN_SHARD_DROPPED : OPAL_ERR_NO_SIMD_SUPPORT;
     const double t2 = now_ms();
     const size_t nn = (size_t)std::max(n, 1);
     const int wantEnd = searchType != OPAL_SEARCH_SCORE;
@@ -259,9 +262,17 @@ static int search_into_results(unsigned char query[], int Q, unsigned char* db[]
                                int* starts, unsigned char* traced = nullptr) {
     const double tA = now_ms();
     std::vector<int> todo;
-    const bool all = collect_todo(results, dbLength, searchType, todo);
-    const int n = all ? dbLength : (int)todo.size();
-    const int* ids = all ? nullptr : todo.data();
+    // One GPU and a database large enough to be ordered on the device: the look through the N result structs for the ones
+    // that need computing (a pool job) runs WHILE the device orders the lengths, on the assumption -- the usual case, and what
+    // both applications of the reference do -- that all of them do. If some hold results already, that fill is dropped and the
+    // call goes on with the sequences that are left.
+    const std::vector<int> devicesEarly = call_devices();
+    bool all = false, looked = false;
+    const std::function<bool()> look = [&]() { looked = true; all = collect_todo(results, dbLength, searchType, todo); return all; };
+    const bool overlapLook = devicesEarly.size() <= 1 && dbLength >= 16384 && opts().deviceOrder != 0;
+    if (!overlapLook) look();
+    int n = overlapLook ? dbLength : all ? dbLength : (int)todo.size();
+    const int* ids = overlapLook || all ? nullptr : todo.data();
     int rc = 0;
     double tms[4] = {0, 0, 0, 0};
     const double tB = now_ms();
@@ -274,14 +285,23 @@ static int search_into_results(unsigned char query[], int Q, unsigned char* db[]
         if (!buf) return OPAL_ERR_NO_SIMD_SUPPORT;
         int* score = buf.get(); int* endQ = score + n; int* endT = score + 2 * (size_t)n;
         int* startQ = starts ? score + 3 * (size_t)n : nullptr; int* startT = starts ? score + 4 * (size_t)n : nullptr;
-        std::vector<int> devices = call_devices();
+        const std::vector<int>& devices = devicesEarly;
         // alignment search: operation strings traced on the device, per shard (positions of a shard in the to-do list: tracePos)
         std::vector<TraceOut> traces(std::max<size_t>(devices.size(), 1));
         std::vector<std::vector<int>> tracePos;
         if (devices.size() <= 1 || n < 2 * 64) {
             if (devices.size() == 1 && opal_hip_set_device(devices[0])) return OPAL_ERR_NO_SIMD_SUPPORT;
             rc = run_shard(opal_hip_get_device(), query, Q, db, dbSeqLengths, ids, n, Go, Ge, M, A, st, mode, score, endQ, endT, tms,
-                           startQ, startT, traced ? &traces[0] : nullptr);
+                           startQ, startT, traced ? &traces[0] : nullptr, overlapLook ? &look : nullptr);
+            if (overlapLook && !looked) look();  // (cannot happen: db_fill calls the hook exactly once; kept as a guard)
+            if (rc == RUN_SHARD_DROPPED || (overlapLook && !all)) {
+                // some results were there already: the plain way, with the sequences that are left
+                n = (int)todo.size();
+                ids = todo.data();
+                rc = n > 0 ? run_shard(opal_hip_get_device(), query, Q, db, dbSeqLengths, ids, n, Go, Ge, M, A, st, mode, score, endQ, endT, tms,
+                                       startQ, startT, traced ? &traces[0] : nullptr)
+                           : (args_fit_int32(Go, Ge, M, A) ? 0 : OPAL_ERR_OVERFLOW);
+            }
             tracePos.resize(1);  // (identity: shard position = position in the to-do list)
         } else {
             // several GPUs: deal 64-sequence groups balancing the residue count, one host thread per GPU, each

@@ -117,6 +117,9 @@ struct UploadGate {
     bool timed = false;  // (debug) the chunk events carry timestamps
     std::vector<int> cutItem;
     std::vector<int> pieceCut, pieceChunk;  // the pool's tasks: piece p = items [pieceCut[p], pieceCut[p+1]) of chunk pieceChunk[p]
+    std::vector<uint64_t> cutByte, pieceByte;  // byte offset (in item order) at which chunk c / piece p begins; one more entry: the total
+    uint64_t cutsTotal = 0, cutsChunkBytes = 0, cutsPieceBytes = 0;  // what the cuts above were made for
+    size_t cutsItems = 0;
     std::vector<void*> events;  // (owned by the context: kept across calls)
     std::unique_ptr<std::atomic<int>[]> state;
     std::unique_ptr<std::atomic<int>[]> left;  // pieces of chunk c still being gathered
@@ -159,7 +162,13 @@ struct OpalxDb {
     // zero-length sequences it found
     opal_host::PinVec<int> hLens, hEmpty;
     opal_host::DevBuf<int> dLens, dEmpty;
+    opal_host::PinVec<uint64_t> hCuts;    // answers of opal_hip_order_cuts: {item, byte offset} per target of cutTargets
+    opal_host::DevBuf<uint64_t> dCuts;
+    std::vector<uint64_t> cutTargets;     // ... the byte offsets asked about, in the order plan_cuts asks (empty: ask the host's seqOff)
+    uint64_t cutTargetsChunk = 0, cutTargetsPiece = 0;  // ... for this chunk / piece size
+    bool hostSeqOffValid = true;          // db->seqOff (host) holds the item offsets (a device ordering does not bring them back)
     opal_host::DevBuf<unsigned char> dOrderScratch;
+    bool fillAborted = false;             // db_fill gave up because its `meanwhile` hook said so (not a failure of the device)
     bool deviceOrdered = false;           // the item arrays of the current database were written on the device (nothing to upload)
     // device: the packed database
     opal_host::DevBuf<unsigned char> res;
@@ -183,7 +192,7 @@ struct OpalxDb {
     bool hdrEvSet[OPALX_ASYNC_DEPTH] = {};
     bool clockProbe = false;   // opalx_db_clock_probe
     bool timelineProbe = false;
-    opal_host::DevBuf<unsigned long long> timeline;  // [2 x 65536 workgroups], zeroed before a probed search
+    opal_host::DevBuf<unsigned long long> timeline;  // [2 x 65536 workgroups] ticks, then [2 x 65536] shader cycles; zeroed before a probed search
     double lastClockGhz = 0;
     // One "search header" per search, uploaded with a single copy: {counters[4], clock probe[2 x u64], score matrix, query}. ovfCount[0] =
     // length of the 16-bit rung's re-run list, [1] = width-32 wrap count.
@@ -282,7 +291,10 @@ void db_release(OpalxDb* db);
  */
 enum RawKind { RAW_POINTERS, RAW_DEVICE_FLAT };
 bool db_fill(OpalxDb* db, int n, const int* lens, RawKind kind, const std::function<const unsigned char*(int)>& getSeq,
-             const unsigned char* flatDevice, const std::function<uint64_t(int)>& flatOff, bool async = false);
+             const unsigned char* flatDevice, const std::function<uint64_t(int)>& flatOff, bool async = false,
+             const std::function<bool()>* meanwhile = nullptr);
+// (`meanwhile`, if given, is called exactly once, at the point of the fill where the calling thread would otherwise wait --
+// while the device orders the lengths --; if it returns false the fill is dropped: db_fill returns false with db->fillAborted set)
 bool db_fill_finish(OpalxDb* db);  // waits for the pool; false if a chunk failed
 // After db_fill_finish: the fill had recognised the previous call's database, searched it without waiting for the
 // comparison, and some chunk turned out to differ (it has been uploaded since): the search must be repeated.

@@ -2,6 +2,8 @@
 // device selection, memory, copies, events and the single kernel-launch entry. No DP logic and
 // no scheduling here: the kernels are in dp_kernel.hpp, the scheduler in opal_api.cpp.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types only: the library is loaded with dlopen, on request (opal_hip_rccl_init)
+#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -10,6 +12,7 @@
 #include <mutex>
 #include <set>
 #include <utility>
+#include <vector>
 
 #include "dp_kernel.hpp"
 #include "stream_kernel.hpp"
@@ -257,6 +260,91 @@ extern "C" int opal_hip_permute(const int* in, const int* perm, int count, int* 
     hipLaunchKernelGGL(opal_permute_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, perm, count, out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("permute kernel launch", e);
+}
+
+// out[perm[k * per + j]] = in[k * block_stride + j] for k < blocks, j < per (perm < 0: padding): the blocks an RCCL gather of
+// equal-sized (padded) shard blocks leaves on the root, back into database order.
+__global__ void opal_permute_blocks_kernel(const int* __restrict__ in, const int* __restrict__ perm, int blocks, int per, int blockStride,
+                                           int* __restrict__ out) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= blocks * per) return;
+    const int k = i / per, j = i - k * per;
+    const int to = perm[i];
+    if (to >= 0) out[to] = in[(size_t)k * (size_t)blockStride + (size_t)j];
+}
+extern "C" int opal_hip_permute_blocks(const int* in, const int* perm, int blocks, int per, int block_stride, int* out, void* stream) {
+    if (blocks <= 0 || per <= 0) return 0;
+    hipLaunchKernelGGL(opal_permute_blocks_kernel, dim3((blocks * per + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, perm, blocks, per,
+                       block_stride, out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("permute-blocks kernel launch", e);
+}
+
+// ---- the path's one collective through RCCL (ncclCommInitAll over the device list + one ncclGather per search).
+// librccl.so is loaded on request only (dlopen): a process that never asks for it does not pay for loading it.
+namespace {
+struct RcclGroup {
+    void* lib = nullptr;
+    int n = 0;
+    std::vector<int> devices;
+    std::vector<ncclComm_t> comms;
+    ncclResult_t (*commInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*commDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*gather)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*groupStart)() = nullptr;
+    ncclResult_t (*groupEnd)() = nullptr;
+};
+}  // namespace
+
+extern "C" void opal_hip_rccl_destroy(void* h) {
+    RcclGroup* g = (RcclGroup*)h;
+    if (!g) return;
+    for (ncclComm_t c : g->comms) if (c && g->commDestroy) g->commDestroy(c);
+    // (the library stays loaded: unloading RCCL under a live HIP runtime is not worth the risk)
+    delete g;
+}
+
+extern "C" void* opal_hip_rccl_init(const int* devices, int n) {
+    if (n < 1) return nullptr;
+    for (int a = 0; a < n; a++)
+        for (int b = a + 1; b < n; b++)
+            if (devices[a] == devices[b]) { snprintf(g_err, sizeof g_err, "RCCL: device %d listed twice (one rank per GPU)", devices[a]); return nullptr; }
+    RcclGroup* g = new RcclGroup;
+    g->lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!g->lib) g->lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!g->lib) { snprintf(g_err, sizeof g_err, "RCCL: %s", dlerror()); delete g; return nullptr; }
+    g->commInitAll = (decltype(g->commInitAll))dlsym(g->lib, "ncclCommInitAll");
+    g->commDestroy = (decltype(g->commDestroy))dlsym(g->lib, "ncclCommDestroy");
+    g->gather = (decltype(g->gather))dlsym(g->lib, "ncclGather");
+    g->groupStart = (decltype(g->groupStart))dlsym(g->lib, "ncclGroupStart");
+    g->groupEnd = (decltype(g->groupEnd))dlsym(g->lib, "ncclGroupEnd");
+    if (!g->commInitAll || !g->commDestroy || !g->gather || !g->groupStart || !g->groupEnd) { snprintf(g_err, sizeof g_err, "RCCL: symbols missing"); delete g; return nullptr; }
+    g->n = n;
+    g->devices.assign(devices, devices + n);
+    g->comms.assign((size_t)n, nullptr);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    const ncclResult_t r = g->commInitAll(g->comms.data(), n, devices);
+    (void)hipSetDevice(cur);
+    if (r != ncclSuccess) { snprintf(g_err, sizeof g_err, "ncclCommInitAll failed (%d)", (int)r); g->comms.clear(); opal_hip_rccl_destroy(g); return nullptr; }
+    return g;
+}
+
+// One gather of `count` ints per rank to rank 0: send[k] on device k (stream streams[k]), recv on device 0 ([n][count]).
+extern "C" int opal_hip_rccl_gather(void* h, const void* const* send, void* recv_root, size_t count, void* const* streams) {
+    RcclGroup* g = (RcclGroup*)h;
+    if (!g) return 1;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    ncclResult_t r = g->groupStart();
+    for (int k = 0; k < g->n && r == ncclSuccess; k++) {
+        (void)hipSetDevice(g->devices[(size_t)k]);
+        r = g->gather(send[k], recv_root, count, ncclInt32, 0, g->comms[(size_t)k], (hipStream_t)streams[k]);
+    }
+    const ncclResult_t e = g->groupEnd();
+    (void)hipSetDevice(cur);
+    if (r != ncclSuccess || e != ncclSuccess) { snprintf(g_err, sizeof g_err, "ncclGather failed (%d, %d)", (int)r, (int)e); return 1; }
+    return 0;
 }
 
 // Let the calling thread's current device access `peer`'s memory directly (xGMI peer DMA for the gather of a multi-GPU

@@ -67,6 +67,9 @@ const std::vector<Desc>& table() {
                  for (const char* p = v; *p; p++) if (!((*p >= '0' && *p <= '9') || *p == ',')) return false;
              o.devices = v; return true; }, back(&Options::devices)},
         integer("OPAL_HIP_DEVICE", &Options::device, 0, 1023),
+        {"OPAL_HIP_MULTI_GATHER", [](Options& o, const char* v) {
+             if (!strcmp(v, "rccl")) o.multiGatherRccl = true; else if (!strcmp(v, "peer")) o.multiGatherRccl = false; else return false;
+             return true; }, back(&Options::multiGatherRccl)},
         integer("OPAL_HOST_THREADS", &Options::hostThreads, 1, 4096),
         integer("OPAL_ORDER_THREADS", &Options::orderThreads, 1, 4096),
         one_of("OPAL_HIP_DEVICE_ORDER", &Options::deviceOrder, {0, 1}),
@@ -77,6 +80,7 @@ const std::vector<Desc>& table() {
         flag("OPAL_HIP_NO_REUSE", &Options::noReuse),
         flag("OPAL_HIP_NO_SPECULATION", &Options::noSpeculation),
         flag("OPAL_HIP_NO_ZERO_COPY", &Options::noZeroCopy),
+        integer("OPAL_HIP_ZC_FROM_SLICE", &Options::zcFromSlice, 0, 64),
         integer("OPAL_HIP_CHUNK_BYTES", &Options::chunkBytes, 4096, 1 << 30),
         {"OPAL_HIP_COPY_STREAMS", [](Options& o, const char* v) { long long x; if (!parse_ll(v, 1, 2, &x)) return false; o.oneCopyStream = x == 1; return true; }, back(&Options::oneCopyStream)},
         flag("OPAL_HIP_SPIN_SYNC", &Options::spinSync),

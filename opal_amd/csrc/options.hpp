@@ -17,6 +17,7 @@ struct Options {
     bool debug = false;               // OPAL_HIP_DEBUG: scheduler decisions and timings on stderr
     // ---- devices
     std::string devices;              // OPAL_HIP_DEVICES: "all" or "0,1,..": opalSearchDatabase shards every call over these GPUs
+    bool multiGatherRccl = false;     // OPAL_HIP_MULTI_GATHER=rccl: opalx_multi_* handles gather with one ncclGather per search instead of peer copies
     int device = -1;                  // OPAL_HIP_DEVICE: the GPU of threads that have not chosen one (-1: the current device)
     // ---- host side
     int hostThreads = 0;              // OPAL_HOST_THREADS: width of the host thread pool (0: from the CPU quota)
@@ -29,6 +30,7 @@ struct Options {
     bool noReuse = false;             // OPAL_HIP_NO_REUSE: never recognise the previous call's database
     bool noSpeculation = false;       // OPAL_HIP_NO_SPECULATION: a re-seen database is compared before it is searched
     bool noZeroCopy = false;          // OPAL_HIP_NO_ZERO_COPY: a new database is uploaded, never read from pinned memory by the kernels
+    int zcFromSlice = 0;              // OPAL_HIP_ZC_FROM_SLICE: the slices before this one wait for their chunks' copies, those from it on read pinned memory (0: all zero-copy)
     int chunkBytes = 0;               // OPAL_HIP_CHUNK_BYTES (test hook): size of an upload chunk of a fill (0: 2 MB or a 96th of the database)
     bool oneCopyStream = false;       // OPAL_HIP_COPY_STREAMS=1: one copy stream instead of two
     bool spinSync = false;            // OPAL_HIP_SPIN_SYNC: poll the stream instead of blocking on it

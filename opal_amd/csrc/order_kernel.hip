@@ -136,6 +136,23 @@ __global__ void __launch_bounds__(64) opal_order_place(const int* __restrict__ l
     }
 }
 
+// Where the upload chunks and gather pieces of the fill begin (db_pack.cpp): for every byte offset asked for, the first item
+// at or behind it and that item's own offset -- a binary search over the item offsets just written, here rather than on the host,
+// whose copy of that array would be freshly DMA-written memory: every probe a cache miss (44 us for 272 searches, measured).
+__global__ void opal_order_cuts(const unsigned long long* __restrict__ targets, int T, const unsigned long long* __restrict__ itemOff,
+                                int nonEmpty, unsigned long long total, unsigned long long* __restrict__ out) {
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= T) return;
+    const unsigned long long want = targets[t];
+    int lo = 0, hi = nonEmpty;  // first item in [0, nonEmpty) whose offset is >= want
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (itemOff[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    out[2 * t] = (unsigned long long)lo;
+    out[2 * t + 1] = lo < nonEmpty ? itemOff[lo] : total;
+}
+
 // (more than 64 KiB of dynamic LDS: the limit is raised once per kernel and device, as in opal_shim.hip)
 int raise_lds_limit(const void* fn) {
     static std::mutex m;
@@ -164,6 +181,15 @@ extern "C" size_t opal_hip_order_scratch_bytes(int n, int max_len) {
     if (n <= 0 || max_len < 0 || max_len >= ORDER_MAX_KEYS) return 0;
     const size_t B = (size_t)max_len + 1;
     return ((size_t)order_blocks(n, (int)B) * B + 2 * B) * sizeof(int) + B * sizeof(unsigned long long) + 16;
+}
+
+extern "C" int opal_hip_order_cuts(const uint64_t* d_targets, int num_targets, const uint64_t* d_item_off, int num_nonempty,
+                                   uint64_t total_bytes, uint64_t* d_out, void* stream) {
+    if (num_targets <= 0) return 0;
+    hipLaunchKernelGGL(opal_order_cuts, dim3((num_targets + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned long long*>(d_targets), num_targets, reinterpret_cast<const unsigned long long*>(d_item_off),
+                       num_nonempty, (unsigned long long)total_bytes, reinterpret_cast<unsigned long long*>(d_out));
+    return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 extern "C" int opal_hip_order_by_length(const int* d_lens, int n, int max_len, int num_nonempty, void* d_scratch, int* d_item_seq,

@@ -1,0 +1,92 @@
+"""Planner regression sweep: over query lengths x database sizes x {synthetic, Swiss-Prot-like tail} x four modes x
+{score, score + end}, the kernel time of the scheduler's NATURAL plan against every forced alternative it could have taken
+(streaming kernels on / off, the other narrow widths, no role-swapped kernel, length classes as separate launches). A row is a
+MISS when the natural plan is more than 10 % behind the best alternative. Results must be identical across alternatives.
+
+  python3 scripts/gpu_planner_sweep.py            the full grid (minutes of GPU time), table on stdout
+  SWEEP=quick python3 scripts/gpu_planner_sweep.py   the grid tests/test_gpu_planner.py runs
+Environment: QS, NS, SHAPES, MODES, TYPES (comma lists) narrow the grid; REPS (default 3) searches per timing (median).
+Exit code 1 if any miss (or any result mismatch)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import opal_amd
+from opal_amd import synth
+from opal_amd.api import PreparedDb
+from opal_amd.score_matrix import blosum50
+
+quick = os.environ.get("SWEEP") == "quick"
+def env_list(name, default, cast=int):
+    v = os.environ.get(name)
+    return [cast(x) for x in v.split(",")] if v else default
+QS = env_list("QS", [110, 300, 1000, 2000] if quick else [40, 110, 195, 300, 513, 1000, 1400, 1700, 2000, 2600, 4100])
+NS = env_list("NS", [20000, 100000] if quick else [2000, 20000, 100000, 541762])
+SHAPES = env_list("SHAPES", ["c2", "sprot"], str)
+MODES = env_list("MODES", ["SW", "HW"] if quick else ["SW", "NW", "HW", "OV"], str)
+TYPES = env_list("TYPES", [0, 1])
+REPS = int(os.environ.get("REPS", "3"))
+TOL = float(os.environ.get("TOL", "1.10"))
+# (name, options): every alternative the scheduler could have taken; an option that does not apply to a search changes nothing
+ALTS = [("natural", {}), ("stream=0", {"OPAL_HIP_STREAM": "0"}), ("stream=1", {"OPAL_HIP_STREAM": "1"}), ("narrow=16", {"OPAL_HIP_NARROW": "16"}),
+        ("narrow=18", {"OPAL_HIP_NARROW": "18"}), ("swap=0", {"OPAL_HIP_SWAP": "0"}), ("no_uber", {"OPAL_HIP_NO_UBER": "1"})]
+dev = torch.device("cuda", 0)
+m = blosum50()[1]
+misses, mismatches, rows = [], [], 0
+t_start = time.time()
+print(f"# planner sweep: Q {QS} x N {NS} x {SHAPES} x {MODES} x types {TYPES}; median of {REPS} searches; miss = natural > {TOL:.2f} x best")
+print(f"# {'shape':5s} {'N':>7s} {'Q':>5s} {'mode':4s} {'end':3s} | " + " ".join(f"{a[0]:>10s}" for a in ALTS) + " | natural/best  best")
+for shape in SHAPES:
+    for n in NS:
+        lens = synth.lengths(42, 0, n, "sprot" if shape == "sprot" else "c2")
+        stride = synth.SPROT_STRIDE if shape == "sprot" else 5000
+        d_res, offs = synth.residues_device(np.arange(n, dtype=np.int64), lens, 42, dev, stride=stride)
+        torch.cuda.synchronize()
+        pdb = PreparedDb(None, offs, device_ptr=d_res.data_ptr())
+        outs = [torch.zeros(3 * n, dtype=torch.int32, device=dev) for _ in range(2)]
+        cells1 = float(offs[-1])
+        for Q in QS:
+            q = synth.query(Q, seed=7)
+            for mode in MODES:
+                for st in TYPES:
+                    if cells1 * Q > 6e12:
+                        continue
+                    times, ref = [], None
+                    for name, o in ALTS:
+                        for k, v in o.items():
+                            opal_amd.set_option(k, v)
+                        try:
+                            ks = []
+                            out = outs[0] if name == "natural" else outs[1]
+                            out.fill_(-7)
+                            for _ in range(REPS):
+                                rc, k = pdb.search_device(q, 3 if shape == "sprot" else 11, 1, m, st, opal_amd.MODES[mode], out.data_ptr(),
+                                                          out[n:].data_ptr() if st else 0, out[2 * n:].data_ptr() if st else 0)
+                                ks.append(k)
+                            if rc not in (0, 1):
+                                times.append(float("nan")); continue
+                            times.append(float(np.median(ks)))
+                            got = out[: (3 if st else 1) * n]
+                            if ref is None:
+                                ref = got.clone()
+                            elif not torch.equal(ref, got):
+                                mismatches.append((shape, n, Q, mode, st, name))
+                        finally:
+                            for k in o:
+                                opal_amd.set_option(k, None)
+                    best = np.nanmin(times)
+                    ratio = times[0] / best
+                    rows += 1
+                    flag = "  MISS" if ratio > TOL else ""
+                    print(f"  {shape:5s} {n:7d} {Q:5d} {mode:4s} {st:3d} | " + " ".join(f"{t:10.3f}" for t in times) + f" | {ratio:6.3f}  {ALTS[int(np.nanargmin(times))][0]}{flag}", flush=True)
+                    if ratio > TOL:
+                        misses.append((shape, n, Q, mode, st, ratio, ALTS[int(np.nanargmin(times))][0]))
+        del pdb, d_res, outs
+        torch.cuda.empty_cache()
+print(f"# {rows} rows in {time.time() - t_start:.0f} s; {len(misses)} misses, {len(mismatches)} result mismatches")
+for x in misses:
+    print("# MISS", x)
+for x in mismatches:
+    print("# MISMATCH", x)
+sys.exit(1 if misses or mismatches else 0)

@@ -148,6 +148,16 @@ int opal_hip_memset32(void* dst, int value, size_t count, void* stream) {
 int opal_hip_permute(const int* in, const int* perm, int count, int* out, void* stream) {
     return enqueue(stream, [=] { for (int i = 0; i < count; i++) out[perm[i]] = in[i]; });
 }
+int opal_hip_permute_blocks(const int* in, const int* perm, int blocks, int per, int stride, int* out, void* stream) {
+    return enqueue(stream, [=] {
+        for (int k = 0; k < blocks; k++)
+            for (int j = 0; j < per; j++)
+                if (perm[k * per + j] >= 0) out[perm[k * per + j]] = in[(size_t)k * stride + j];
+    });
+}
+void* opal_hip_rccl_init(const int*, int) { return nullptr; }  // (no RCCL on the fake device: the handle keeps its peer copies)
+void opal_hip_rccl_destroy(void*) {}
+int opal_hip_rccl_gather(void*, const void* const*, void*, size_t, void* const*) { return 1; }
 int opal_hip_scatter_results(const int* quads, int count, int* score, int* eq, int* et, void* stream) {
     return enqueue(stream, [=] {
         for (int i = 0; i < count; i++) {
@@ -221,6 +231,16 @@ int opal_hip_order_by_length(const int* lens, int n, int max_len, int nonEmpty, 
         uint64_t at = 0;
         for (size_t k = 0; k < idx.size(); k++) { seq[k] = idx[k]; len[k] = lens[idx[k]]; off[k] = at; at += (uint64_t)lens[idx[k]]; }
         if (nonEmpty & 1) { seq[nonEmpty] = -1; len[nonEmpty] = 0; off[nonEmpty] = at; }
+    });
+}
+
+int opal_hip_order_cuts(const uint64_t* targets, int T, const uint64_t* off, int nonEmpty, uint64_t total, uint64_t* out, void* stream) {
+    return enqueue(stream, [=] {
+        for (int t = 0; t < T; t++) {
+            const int it = (int)(std::lower_bound(off, off + nonEmpty, targets[t]) - off);
+            out[2 * t] = (uint64_t)it;
+            out[2 * t + 1] = it < nonEmpty ? off[it] : total;
+        }
     });
 }
 

@@ -151,6 +151,27 @@ int main(int argc, char** argv) {
             api_round("chunks-other", q60, d2, 3, 1, m, st, mode);
         }
 
+    // ... and a call that finds a third of its results computed already (opal.h:118-122): those stay as they are, the look
+    // through the result structs -- which runs while the device orders the lengths -- drops that ordering and the rest is searched
+    {
+        const size_t nn = d.seqs.size();
+        std::vector<OpalSearchResult> store(nn);
+        std::vector<OpalSearchResult*> res(nn);
+        for (size_t i = 0; i < nn; i++) {
+            opalInitSearchResult(&store[i]); res[i] = &store[i];
+            if (i % 3 == 0) { opalSearchResultSetScore(&store[i], -5); store[i].endLocationQuery = 1; store[i].endLocationTarget = 1; }
+        }
+        const int rc = opalSearchDatabase(const_cast<unsigned char*>(q60.data()), (int)q60.size(), d.ptr.data(), (int)nn, d.len.data(), 3, 1, m.data(), A,
+                                          res.data(), OPAL_SEARCH_SCORE_END, OPAL_MODE_SW, OPAL_OVERFLOW_BUCKETS);
+        Want w = oracle(q60, d, 3, 1, m, 1, OPAL_MODE_SW);
+        size_t bad = rc != w.rc;
+        for (size_t i = 0; i < nn; i++) {
+            if (i % 3 == 0) bad += !(store[i].score == -5 && store[i].endLocationQuery == 1 && store[i].endLocationTarget == 1);
+            else bad += !(store[i].scoreSet && store[i].score == w.s[i] && (w.s[i] == 0 || (store[i].endLocationQuery == w.eq[i] && store[i].endLocationTarget == w.et[i])));
+        }
+        if (bad) { fprintf(stderr, "FAIL partial results: %zu wrong\n", bad); g_fail++; }
+    }
+
     // 2. two caller threads at once (cached contexts, the shared pool)
     {
         std::thread t1([&] { for (int r = 0; r < 3; r++) api_round("thread-1", q60, d, 3, 1, m, 1, OPAL_MODE_SW); });

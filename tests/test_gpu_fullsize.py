@@ -701,6 +701,61 @@ def test_multi_gpu_handle_device_side_gather(c2):
     multi.close()
 
 
+def test_multi_gpu_handle_rccl_gather(c2, opal_opt):
+    """The path's one collective THROUGH RCCL inside the library (ncclCommInitAll over the device list, one
+    ncclGather of the padded {score, endQ, endT} blocks per search, OPAL_HIP_MULTI_GATHER=rccl) -- with the one rank a one-GPU
+    box allows (RCCL refuses a device listed twice): communicator set-up, the gather on the shard's stream behind its kernels,
+    the root's block permutation, queued searches. Results against the single handle. What N > 1 ranks add can only run on a
+    multi-GPU node (unmeasured on hardware)."""
+    import ctypes as C
+    import torch
+    from opal_amd import _lib, synth
+    from opal_amd.api import PreparedDb, PreparedMultiDb
+    n = 30001
+    res, offs = c2["res"][: c2["offs"][n]], c2["offs"][: n + 1]
+    q, m = c2["q"], c2["m"]
+    opal_opt.set("OPAL_HIP_MULTI_GATHER", "rccl")
+    multi = PreparedMultiDb(res, offs, [0])
+    _lib.lib().opalx_multi_gather_kind.restype = C.c_int
+    _lib.lib().opalx_multi_gather_kind.argtypes = [C.c_void_p]
+    if _lib.lib().opalx_multi_gather_kind(multi._h) != 1:
+        multi.close()
+        pytest.skip("librccl.so could not be loaded here: the handle fell back to peer copies")
+    one = PreparedDb(res, offs)
+    out = torch.full((3 * n,), -12345, dtype=torch.int32, device="cuda")
+    for mode in ("SW", "OV"):
+        for st in (0, 1):
+            rc0, s0, eq0, et0 = one.search(q, 3, 1, m, st, oracle_lib.MODES[mode])
+            out.fill_(-12345)
+            torch.cuda.synchronize()
+            rc, kms = multi.search_device(q, 3, 1, m, st, oracle_lib.MODES[mode], out[:n].data_ptr(), out[n:2 * n].data_ptr() if st else 0,
+                                          out[2 * n:].data_ptr() if st else 0)
+            assert rc == rc0 == 0 and kms > 0
+            got = out.cpu().numpy().reshape(3, n)
+            np.testing.assert_array_equal(got[0], s0, err_msg=f"rccl gather {mode} st={st} score")
+            if st:
+                np.testing.assert_array_equal(got[1], eq0)
+                np.testing.assert_array_equal(got[2], et0)
+            else:
+                assert (got[1:] == -12345).all()
+    jobs = [(synth.query(250, seed=31), "SW", 0), (q, "HW", 1)]
+    outs = [torch.full((3 * n,), -12345, dtype=torch.int32, device="cuda") for _ in jobs]
+    torch.cuda.synchronize()
+    for (qq, mode, st), o in zip(jobs, outs):
+        assert multi.search_device_async(qq, 3, 1, m, st, oracle_lib.MODES[mode], o[:n].data_ptr(), o[n:2 * n].data_ptr() if st else 0,
+                                         o[2 * n:].data_ptr() if st else 0) == 0
+    for (qq, mode, st), o in zip(jobs, outs):
+        rc, kms = multi.wait()
+        assert rc == 0
+        rc0, s0, eq0, et0 = one.search(qq, 3, 1, m, st, oracle_lib.MODES[mode])
+        got = o.cpu().numpy().reshape(3, n)
+        np.testing.assert_array_equal(got[0], s0, err_msg=f"rccl gather, queued {mode}")
+        if st:
+            np.testing.assert_array_equal(got[1], eq0)
+            np.testing.assert_array_equal(got[2], et0)
+    multi.close()
+
+
 @pytest.mark.parametrize("mode", ["SW", "NW", "HW", "OV"])
 def test_one_launch_kernels_equal_separate_launches(mode, c2, oracle, opal_opt):
     """The one-launch ("uber") kernels -- all length classes of a search as ONE grid -- against the same search as
