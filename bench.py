@@ -126,7 +126,7 @@ def spawn_ranks(n):
     tmp = tempfile.mkdtemp(prefix="bench_ranks_")
     procs, files = [], []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         out = open(os.path.join(tmp, f"rank{r}.out"), "wb")
         err = open(os.path.join(tmp, f"rank{r}.err"), "wb")
@@ -662,7 +662,9 @@ def main():
             status = 3
         res_host = None
         if world == 1 and not args.no_e2e and total <= 1000000:
-            res_host = d_res.cpu().numpy()
+            # (a private copy made by THIS thread, the way an application holds the sequences it read: the pages of a tensor that
+            # .cpu() filled were first touched by the runtime's staging thread, wherever that ran)
+            res_host = d_res.cpu().numpy().copy()
             e2e_ms, same_ms, e2e_ok = e2e_call(query, res_host, offs, matrix, args.gap_open, args.gap_ext, args.search_type, mode, gscore,
                                                calls=6 if total <= 200000 else 3)
             res_line["e2e"] = {"ms": round(e2e_ms, 3), "gcups": round(cells / (e2e_ms * 1e-3) / 1e9, 1), "scores_match": e2e_ok,

@@ -109,6 +109,16 @@ typedef struct OpalHipLaunch {
     /* Timeline probe (NULL: off): every workgroup b of the launch writes the constant-rate ticks at its start and end to
        timeline[2b], timeline[2b+1] (capacity: 2 x the grid size). */
     unsigned long long* timeline;
+    /* opal_hip_launch_stream: leave this many CUs without a persistent workgroup -- for launches of the same search that run
+       BESIDE the stream on other streams (the 32-bit prefix, swapped targets): a persistent workgroup per CU would otherwise
+       keep them waiting for the whole stream whenever it reaches the dispatcher first (24 ms or 34 ms per search, from run to run) */
+    int reserve_blocks;
+    /* opal_hip_launch_stream: the waves working on the first prio_items sequences handed out (the longest of the range) run at
+       a raised issue priority (0: none) */
+    int prio_items;
+    /* opal_hip_launch_swap: NULL, or a zeroed device counter that every workgroup of the launch increments when it starts
+       (opal_hip_wait_started) */
+    int* started_counter;
 } OpalHipLaunch;
 
 /* ONE launch for up to three length classes of a search (plain 16-bit kernels): the bulk of the database on
@@ -148,6 +158,11 @@ int opal_hip_launch_stream(const OpalHipLaunch* args, int* next_counter);
 int opal_hip_swap_rows(int query_length, int alphabet_length);
 size_t opal_hip_swap_lds_bytes(int rows_per_lane, int query_length, int alphabet_length);  /* (> 160 KiB: not launchable) */
 int opal_hip_launch_swap(const OpalHipLaunch* args);
+/* Enqueue on `stream` a one-wave kernel that ends when *counter >= target (or after ~2 ms): what is launched behind it on
+   that stream reaches the dispatcher only after `target` workgroups of a launch on ANOTHER stream have taken their CUs. A grid
+   that fills every CU with workgroups of 39 KB of LDS otherwise starves a 55 KB workgroup arriving a moment later until
+   it drains: one retiring workgroup never frees enough (541 762 sequences, 300-aa query: 8.5 ms or 12.5 from run to run). */
+int opal_hip_wait_started(const int* counter, int target, void* stream);
 /* NW / HW / OV have role-swapped kernels too (int32 arithmetic, scores and end cells: out_end_* may be NULL): the same entry
    with args->mode; rows per lane from opal_hip_swap_gl_rows: 16 (2-byte profile entries: every matrix entry must fit 16
    bits) or 8 (4-byte entries). */

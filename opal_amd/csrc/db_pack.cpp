@@ -172,13 +172,27 @@ static int order_sequences_device(OpalxDb* db, int n, const int* lens, bool forc
     int maxLen = 0, nonEmpty = 0;
     int64_t total = 0;
     int* const keep = keepLens ? keepLens->data() : nullptr;  // (cached contexts: the lengths as handed over, for the next call's "same database?")
-    for (int i = 0; i < n; i++) {
-        const int len = lens[i] > 0 ? lens[i] : 0;
-        h[i] = len;
-        if (keep) keep[i] = lens[i];
-        maxLen = std::max(maxLen, len);
-        nonEmpty += len > 0;
-        total += len;
+    auto stage = [&](int i0, int i1, int* mx, int* ne, int64_t* tot) {
+        int m = 0, e = 0;
+        int64_t t = 0;
+        for (int i = i0; i < i1; i++) {
+            const int len = lens[i] > 0 ? lens[i] : 0;
+            h[i] = len;
+            if (keep) keep[i] = lens[i];
+            m = std::max(m, len);
+            e += len > 0;
+            t += len;
+        }
+        *mx = m; *ne = e; *tot = t;
+    };
+    if (n >= 400000) {  // (a pool job costs ~50 us: worth it from a few hundred thousand lengths on -- 625 000: 0.51 ms on one thread)
+        constexpr int PARTS = 8;
+        int mx[PARTS], ne[PARTS];
+        int64_t tot[PARTS];
+        HostPool::get().parallel_for(PARTS, [&](int t) { stage((int)((long long)n * t / PARTS), (int)((long long)n * (t + 1) / PARTS), &mx[t], &ne[t], &tot[t]); });
+        for (int t = 0; t < PARTS; t++) { maxLen = std::max(maxLen, mx[t]); nonEmpty += ne[t]; total += tot[t]; }
+    } else {
+        stage(0, n, &maxLen, &nonEmpty, &total);
     }
     if (maxLen > opal_hip_order_max_length()) return 1;
     const size_t items = ((size_t)nonEmpty + 1) / 2 * 2;

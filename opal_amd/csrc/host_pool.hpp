@@ -114,7 +114,13 @@ public:
         // hardware threads, quota 16 cores), cold opalSearchDatabase call on C2, best of 12, two rounds: 64 threads 2.46-2.60 ms,
         // 48 threads 2.43-2.45, 32 threads 2.33-2.48, 24 threads 2.31-2.33, 16 threads 2.37-2.52 (profiles/r05_e2e_variants.txt) --
         // 64 runnable threads on 16 cores' worth of time get throttled in the middle of a gather.
-        const double quota = cpu_quota_cores();
+        double quota = cpu_quota_cores();
+        // One process per GPU on one node (torchrun, bench.py --gpus N): the ranks share the quota. LOCAL_WORLD_SIZE is the
+        // launchers' name for how many they are.
+        if (const char* lw = getenv("LOCAL_WORLD_SIZE")) {
+            const int ranks = atoi(lw);
+            if (ranks > 1) quota = (quota > 0 ? quota : (double)nt) / ranks;
+        }
         if (quota > 0) {
             const unsigned cap = (unsigned)(1.5 * quota + 0.5);
             if (nt > cap) nt = cap < 4 ? 4 : cap;

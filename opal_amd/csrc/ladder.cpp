@@ -57,6 +57,8 @@ static int launch_chunked(const SearchCtx& c, int width, int swEndPass, int dete
     // (8 bytes per column of every item's -- width 16: every pair's -- residue stream)
     if (!db->boundary.ensure(8 * ((size_t)db->residues + 16)) || !db->scratch.ensure(2 * (size_t)std::max(db->numSeqs, 1)))
         return OPAL_ERR_NO_SIMD_SUPPORT;
+    if (c.stream && bestG == 64 && numItems <= 256 && wpb > 4) wpb = 4;  // (as launch_class: the few longest, one wave per SIMD)
+    if (c.sideBlocks && c.stream) *c.sideBlocks += (numItems + (64 / bestG) * wpb - 1) / ((64 / bestG) * wpb);
     const int cap = bestG * bestS;
     const int nchunks = (c.Q + cap - 1) / cap;
     const int firstRows = c.Q - (nchunks - 1) * cap;  // SW/HW/OV: the partial chunk is the first one
@@ -98,6 +100,10 @@ static int launch_class(const SearchCtx& c, int width, int swEndPass, int detect
     fill_launch(a, c, width, swEndPass, detectWrap, work, ovfCounter);
     a.lanes_per_seq = k.G; a.rows_per_lane = k.rows; a.waves_per_block = k.wpb; a.lds_bytes_min = k.ldsPad;
     a.first_item = k.first; a.num_items = k.count;
+    // A handful of sequences that each take a whole wave (64 lanes) and run beside the rest of the search are its critical path:
+    // one wave per SIMD (the lone-wave rate), not eight waves of one workgroup sharing a CU -- ten 35 000-residue targets of a
+    // 1000-aa HW search took 30 ms as two waves per SIMD, 15 as one.
+    if ((side || c.stream) && k.G == 64 && k.count <= 256 && a.waves_per_block > 4) a.waves_per_block = 4;
     a.skew = skew;
     a.stream = stream;
     a.priority = side ? 1 : 0;
@@ -106,6 +112,7 @@ static int launch_class(const SearchCtx& c, int width, int swEndPass, int detect
         fprintf(stderr, "[opal] launch width=%d mode=%d end=%d items=[%d,+%d) G=%d rows=%d waves/block=%d ldsPad=%d%s%s\n", width,
                 c.mode, swEndPass, k.first, k.count, k.G, k.rows, k.wpb, k.ldsPad, skew ? " skew" : "", side ? " (side)" : "");
     if (opal_hip_launch(&a)) return 1;
+    if (c.sideBlocks && c.stream) *c.sideBlocks += (k.count + (64 / k.G) * a.waves_per_block - 1) / ((64 / k.G) * a.waves_per_block);
     count(CNT_CLASS_LAUNCHES);
     if (width == 32) count(CNT_WIDTH32);
     return 0;
@@ -255,6 +262,16 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
             auxUsed |= stream != side && stream != db->main();
             const bool zcj = zc.zeroCopy && (int)j >= zcFrom;
             const SearchCtx& cx = zcj ? zc : c;
+            // Slices exist to start before the gather has finished. Once every remaining chunk HAS been gathered (a large database:
+            // the gather takes 2.5 ms of a 16 ms search) the rest goes out as one launch -- kernels that read the pinned buffer need
+            // nothing else, and one large grid runs better than three that take turns on two streams (C4 shard: slices 4-6 started
+            // only when 2 and 3 had ended, 18.7 ms for 15.5 ms of DP).
+            if (zcj && j >= 1 && j + 2 < cut.size()) {
+                const int c0 = (int)(std::upper_bound(g.cutItem.begin(), g.cutItem.end(), cut[j]) - g.cutItem.begin()) - 1;
+                bool gathered = true;
+                for (int cc = std::max(c0, 0); cc < g.chunks() && gathered; cc++) gathered = g.state[(size_t)cc].load(std::memory_order_acquire) != 0;
+                if (gathered) cut.erase(cut.begin() + (long)j + 1, cut.end() - 1);
+            }
             if (!gate_items(db, stream, cut[j], cut[j + 1] - cut[j], /*needDevice=*/!zcj)) { err = 1; break; }
             if (dbg) { void* ev = opal_hip_event_create(); marks.push_back(ev); if (ev) opal_hip_event_record(ev, stream); }
             if (oneGrid) err = launch_grid(cx, cut[j], cut[j + 1], stream);
@@ -335,6 +352,24 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
         if (recorded[i] && opal_hip_stream_wait_event(db->main(), db->event(1 + i))) err = 1;
     if (err) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }  // nothing of this call stays in flight
     return 0;
+}
+
+// Streaming launches: how many of the range's longest sequences (handed out first) get their wave a raised issue priority.
+// A slot works through residues / slots columns on average; a sequence that alone is a quarter of that or more decides when its
+// wave ends, and with it the search. Not more of them than an eighth of the slots: priority among many is none.
+static int stream_prio_items(const OpalxDb* db, int firstItem, int numItems, int G) {
+    if (opts().streamPrio == 0 || numItems <= 0) return 0;
+    const long long slots = 256LL * 16 * (64 / G);
+    long long res = 0;
+    const int step = std::max(1, numItems / 4096);
+    for (int i = 0; i < numItems; i += step) res += db->pairLen[(size_t)firstItem + (size_t)i];
+    res *= step;
+    const long long share = res / slots;  // columns per slot
+    const int* len = db->pairLen.data() + firstItem;
+    // lengths are sorted longest first: the number of items longer than share / 4
+    int lo = 0, hi = numItems;
+    while (lo < hi) { const int mid = (lo + hi) / 2; if ((long long)len[mid] * 4 > share) lo = mid + 1; else hi = mid; }
+    return (int)std::min<long long>(lo, slots / 8);
 }
 
 // reference opal.cpp:178-198 / :610-630 at 32 bits
@@ -552,6 +587,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                     fprintf(stderr, "[opal] streaming launch width=%d G=%d rows=%d end=%d items=[%d,+%d)\n", splan.width, splan.G, splan.rows, wantEnd,
                             a.first_item, a.num_items);
                 a.side_first_item = 0; a.side_num_items = headItems;  // (the long head: class body, first workgroups of the launch)
+                a.prio_items = stream_prio_items(db, a.first_item, a.num_items, splan.G);
                 if (!gate_items(db, st, 0, 2 * P)) return OPAL_ERR_NO_SIMD_SUPPORT;
                 if (splan.passes > 1) {
                     // a query beyond one wave: row chunks from the top, the first one partial (as launch_chunked cuts them), a
@@ -589,8 +625,11 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                     OpalHipLaunch a;
                     fill_launch(a, c, 18, wantEnd, 0, nullptr, db->ovfCount.p);
                     a.rows_per_lane = swapRows; a.first_item = 0; a.num_items = swapN; a.stream = side;
+                    a.started_counter = db->ovfCount.p + 3;  // (zeroed with the search header)
                     if (!fork || !side || opal_hip_event_record(fork, st) || opal_hip_stream_wait_event(side, fork) || !gate_items(db, side, 0, swapN) ||
-                        opal_hip_launch_swap(&a) || !(joinSwap = db->event(12)) || opal_hip_event_record(joinSwap, side)) {
+                        opal_hip_launch_swap(&a) || !(joinSwap = db->event(12)) || opal_hip_event_record(joinSwap, side) ||
+                        // the grids that follow on `main` reach the dispatcher when the swapped workgroups have their CUs
+                        (!opts().noStartedWait && opal_hip_wait_started(db->ovfCount.p + 3, swapN, st))) {
                         db->quiesce();
                         return OPAL_ERR_NO_SIMD_SUPPORT;
                     }
@@ -677,11 +716,14 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
             }
             if (!gplan.G) q32 = p32;
         }
+        int sideBlocks = 0;  // workgroups of the launches that run beside the main range on other streams
         auto launch_global_stream = [&]() -> int {
             OpalHipLaunch a;
             fill_launch(a, c, gplan.width, 0, 0, nullptr, db->ovfCount.p);
             a.lanes_per_seq = gplan.G; a.rows_per_lane = gplan.rows; a.skew = 1;
             a.first_item = 2 * q32; a.num_items = 2 * (P - q32);
+            a.reserve_blocks = std::min(sideBlocks, 64);
+            a.prio_items = stream_prio_items(db, a.first_item, a.num_items, gplan.G);
             if (gplan.passes > 1) {
                 // a query beyond one wave: row chunks from the top (NW: the last one partial, HW/OV: the first), a chunk's bottom
                 // row through the upper half of db->boundary (4 bytes per residue; the class-kernel chunks of the sequences that
@@ -751,13 +793,16 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                 OpalHipLaunch a;
                 fill_launch(a, c, 32, 0, 0, nullptr, db->ovfCount.p + 1);
                 a.rows_per_lane = rowsG; a.first_item = nBad; a.num_items = swapG; a.stream = side;
+                a.started_counter = db->ovfCount.p + 3;
                 if (debug_on()) fprintf(stderr, "[opal] swapped launch mode=%d: items [%d,+%d) (%d of them beyond the 16-bit bounds), %d rows per lane\n", mode, nBad, swapG, need32, rowsG);
                 if (!fork || !side || opal_hip_event_record(fork, st) || opal_hip_stream_wait_event(side, fork) || !gate_items(db, side, nBad, swapG) ||
-                    opal_hip_launch_swap(&a) || !(joinSwapG = db->event(12)) || opal_hip_event_record(joinSwapG, side)) {
+                    opal_hip_launch_swap(&a) || !(joinSwapG = db->event(12)) || opal_hip_event_record(joinSwapG, side) ||
+                    (!opts().noStartedWait && opal_hip_wait_started(db->ovfCount.p + 3, swapG, st))) {
                     db->quiesce();
                     return OPAL_ERR_NO_SIMD_SUPPORT;
                 }
                 count(CNT_SWAPPED, swapG);
+                sideBlocks += swapG;
             }
         }
         // (what the swapped launch took is gone from both rungs: the 32-bit range is empty, the 16-bit one starts behind it)
@@ -768,11 +813,15 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
         // high-priority side stream. The two ranges share nothing but the buffers they index by their own sequences.
         void* join32 = nullptr;
         SearchCtx c32 = c;
+        c32.sideBlocks = &sideBlocks;
         // (round 4: any query. On a database with a real length tail -- Swiss-Prot shape, 110-aa query -- the ten targets beyond
         // 32 000 residues need 8 ms on the 32-bit kernels, and everything else waited behind them on the main stream: 14 ms for a
         // search whose bulk takes 2.8. Unchunked queries use the stream of the swapped launches, which the global modes never
         // need: the side streams 0..2 belong to the long classes of the 16-bit range.)
-        if (P > q32 && (2 * p32 > nBad || (chunkedQuery && gplan.G && gplan.passes > 1 && q32 > p32)) && !opts().noSidePrefix) {
+        // (not beside row chunks at width 16: those index the boundary buffer by the PAIRS' token streams, the 32-bit prefix by
+        // its sequences' residues -- two index spaces in one buffer; only test hooks get there, a query in row chunks runs at width 17 / 18)
+        if (P > q32 && (2 * p32 > nBad || (chunkedQuery && gplan.G && gplan.passes > 1 && q32 > p32)) && !opts().noSidePrefix &&
+            !(chunkedQuery && narrow == 16)) {
             void* fork = db->event(8);
             void* side = chunkedQuery ? db->stream(0) : db->swap();
             if (fork && side && !opal_hip_event_record(fork, st) && !opal_hip_stream_wait_event(side, fork)) { c32.stream = side; join32 = db->event(9); }

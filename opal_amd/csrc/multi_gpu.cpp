@@ -37,6 +37,7 @@ struct SlotWorker {
     const std::function<void(size_t)>* fn = nullptr;  // the job at hand (nullptr: none)
     std::atomic<int> posted{0};                        // (polled for a while after a job before the worker blocks)
     size_t slot = 0;
+    std::atomic<bool> spin{true};
     std::atomic<int>* left = nullptr;
     std::mutex* doneM = nullptr;
     std::condition_variable* doneCv = nullptr;
@@ -44,8 +45,12 @@ struct SlotWorker {
         for (;;) {
             const std::function<void(size_t)>* job = nullptr;
             // a caller that sends search after search finds the worker still polling: no wake-up latency between two searches
-            const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
-            while (!posted.load(std::memory_order_acquire) && std::chrono::steady_clock::now() < until) __builtin_ia32_pause();
+            // (only while the workers of a device list fit the CPU quota: eight spinning workers on a quota of four cores take
+            // the time the gather needs)
+            if (spin) {
+                const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
+                while (!posted.load(std::memory_order_acquire) && std::chrono::steady_clock::now() < until) __builtin_ia32_pause();
+            }
             {
                 std::unique_lock<std::mutex> lk(m);
                 cv.wait(lk, [&] { return fn != nullptr; });
@@ -89,8 +94,12 @@ void run_on_device_workers(size_t slots, const std::function<void(size_t)>& fn) 
         std::thread([me] { me->loop(); }).detach();
     }
     std::atomic<int> left{(int)slots};
+    // (the workers poll for their next job only if all of them together stay within half the CPU quota)
+    static const double quota = HostPool::cpu_quota_cores();
+    const bool spin = quota <= 0 || (double)slots <= 0.5 * quota;
     for (size_t k = 0; k < slots; k++) {
         SlotWorker* me = sw.w[k].get();
+        me->spin.store(spin, std::memory_order_relaxed);
         {
             std::lock_guard<std::mutex> lk(me->m);
             me->left = &left;

@@ -356,6 +356,7 @@ struct SearchCtx {
     long long maxScore;    // largest matrix entry (>= 0)
     bool zeroCopy = false; // launches read the residues from the pinned staging buffer (db->hRaw) instead of the device copy
     void* stream = nullptr; // launch on this stream instead of the handle's main one (row chunks of a 32-bit prefix beside the 16-bit ones)
+    int* sideBlocks = nullptr;  // (launches on `stream`) counts their workgroups: a persistent streaming launch beside them leaves that many CUs free
 };
 
 // Lengths of the items of a launch range: item i has length lens[(idx ? idx[i] : i) * stride]

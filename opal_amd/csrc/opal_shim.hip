@@ -649,6 +649,7 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
     p.satLimit = a->sat_limit; p.negPad = a->neg_pad;
     p.clk = a->clock_probe; p.tl = a->timeline;
     sp.next = next_counter;
+    sp.prioItems = a->prio_items > 0 ? a->prio_items : 0;
     // persistent workgroups: one per CU (16 waves = 4 per SIMD), fewer when there are not enough sequences to go round
     const int perBlock = STREAM_WAVES * (64 / G);
     int blocks = (a->num_items + perBlock - 1) / perBlock;
@@ -670,11 +671,29 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
         sp.sideBlocks = (a->side_num_items + perSide - 1) / perSide;
         if (blocks + sp.sideBlocks > cus && blocks > 1) blocks = std::max(1, cus - sp.sideBlocks);  // every workgroup resident from the start
     }
+    if (a->reserve_blocks > 0 && blocks + sp.sideBlocks + a->reserve_blocks > cus)  // CUs for what runs beside this launch on other streams
+        blocks = std::max(std::min(blocks, cus / 2), cus - sp.sideBlocks - a->reserve_blocks);
     if (opal_host::opts().streamBlocks >= 1) blocks = opal_host::opts().streamBlocks;  // test hook
     if (ldsLaunch > 64 * 1024 && raise_lds_limit((const void*)fn)) return 1;
     hipLaunchKernelGGL(fn, dim3(blocks + sp.sideBlocks), dim3(STREAM_WAVES * 64), ldsLaunch, (hipStream_t)a->stream, sp);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("streaming kernel launch", e);
+}
+
+// One wave that ends when `target` workgroups of a launch on another stream have started (see include/opal_hip.h).
+__global__ void __launch_bounds__(64) opal_wait_started_kernel(const int* counter, int target) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (wall_clock64() - t0 > 200000ull) break;  // ~2 ms of the 100 MHz counter: never a deadlock, at worst the old order
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+extern "C" int opal_hip_wait_started(const int* counter, int target, void* stream) {
+    if (!counter || target <= 0) return 0;
+    hipLaunchKernelGGL(opal_wait_started_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, target);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("wait kernel launch", e);
 }
 
 // ------------------------------------------------------------------ role-swapped SW score search (swap_kernel.hpp)
@@ -723,6 +742,7 @@ extern "C" int opal_hip_launch_swap(const OpalHipLaunch* a) {
     p.ovfCount = a->overflow_count; p.ovfItems = a->overflow_items;
     p.satLimit = a->sat_limit; p.negPad = a->neg_pad;
     p.clk = a->clock_probe;
+    p.started = a->started_counter;
     if (lds > 64 * 1024 && raise_lds_limit((const void*)fn)) return 1;
     hipLaunchKernelGGL(fn, dim3(a->num_items), dim3(SWAP_WAVES * 64), lds, (hipStream_t)a->stream, p);
     hipError_t e = hipGetLastError();

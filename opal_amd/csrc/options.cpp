@@ -97,6 +97,7 @@ const std::vector<Desc>& table() {
         one_of("OPAL_HIP_STREAM", &Options::stream, {0, 1}),
         pair_of("OPAL_HIP_STREAM_CHUNKS", &Options::streamChunkG, &Options::streamChunkS),
         integer("OPAL_HIP_STREAM_BLOCKS", &Options::streamBlocks, 1, 1 << 20),
+        one_of("OPAL_HIP_STREAM_PRIO", &Options::streamPrio, {0, 1}),
         integer("OPAL_HIP_STREAM_HEAD_ITEMS", &Options::streamHeadItems, 1, 1 << 30),
         flag("OPAL_HIP_NO_STREAM_HEAD", &Options::noStreamHead),
         flag("OPAL_HIP_NO_STREAM_CHUNKS", &Options::noStreamChunks),
@@ -132,6 +133,7 @@ const std::vector<Desc>& table() {
              if (!strcmp(v, "pipe")) o.tailPipeModel = true; else if (!strcmp(v, "lone")) o.tailPipeModel = false; else return false;
              return true; }, back(&Options::tailPipeModel)},
         integer("OPAL_HIP_WAVES_PER_BLOCK", &Options::wavesPerBlock, 1, 16),
+        flag("OPAL_HIP_NO_STARTED_WAIT", &Options::noStartedWait),
         integer("OPAL_HIP_SWAP", &Options::swap, 0, 1 << 20),
         one_of("OPAL_HIP_SWAP_ROWS", &Options::swapRows, {8, 16, 24, 40}),
     };

@@ -48,6 +48,7 @@ struct Options {
     int stream = -1;                  // OPAL_HIP_STREAM: 0 never stream, 1 whenever a geometry exists (test hook), -1 automatic
     int streamChunkG = 0, streamChunkS = 0;  // OPAL_HIP_STREAM_CHUNKS "G,S" (test hook)
     int streamBlocks = 0;             // OPAL_HIP_STREAM_BLOCKS (test hook): persistent workgroups of a streaming launch
+    int streamPrio = 1;               // OPAL_HIP_STREAM_PRIO=0: no raised issue priority for the waves on a streaming launch's longest sequences
     int streamHeadItems = 0;          // OPAL_HIP_STREAM_HEAD_ITEMS (test hook)
     bool noStreamHead = false;        // OPAL_HIP_NO_STREAM_HEAD
     bool noStreamChunks = false;      // OPAL_HIP_NO_STREAM_CHUNKS
@@ -65,6 +66,7 @@ struct Options {
     double tailFraction = 0;          // OPAL_HIP_TAIL_FRACTION (0: 0.7)
     bool tailPipeModel = false;       // OPAL_HIP_TAIL_MODEL=pipe
     int wavesPerBlock = 0;            // OPAL_HIP_WAVES_PER_BLOCK (test hook)
+    bool noStartedWait = false;       // OPAL_HIP_NO_STARTED_WAIT: the grids of a search do not wait for its swapped workgroups to have started
     int swap = -1;                    // OPAL_HIP_SWAP: 0 never use the role-swapped kernel, N > 0 (test hook) the N longest targets, -1 automatic
     int swapRows = 0;                 // OPAL_HIP_SWAP_ROWS (test hook): 8 / 16 / 24 / 40
     // the values of the options that are part of a launch-plan cache key, as one string

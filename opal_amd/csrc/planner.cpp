@@ -323,6 +323,9 @@ StreamPlan plan_stream(int Q, int A, int mode, int wantEnd, long long residues, 
             const double total = (double)residues * G / 64.0 * stepInstr * 2.15 / 1024.0;
             const double crit = ((double)longest + G) * stepInstr * 3.5;
             if (!force && crit > (G >= 32 ? 1.5 : 0.5) * total) continue;
+            // (a persistent launch per row chunk: with ~2 sequences per slot it loses to the class kernels' chunks -- planner sweep,
+            // 20 000 sequences, 2600- / 4100-aa queries: 8.6 ms against 6.9; with 12 per slot, 100 000 sequences, it wins)
+            if (!force && (double)numSeqs < 6.0 * 4096.0 * (64 / G)) continue;
             if (cost < bestCost) { bestCost = cost; best.width = 17; best.G = G; best.rows = rows; best.passes = passes; }
         }
     }
@@ -343,7 +346,11 @@ StreamPlan plan_stream(int Q, int A, int mode, int wantEnd, long long residues, 
         const double stepInstr = (best.width == 18 ? 9.5 : 9.0) * best.rows + 30.0;
         const double total = (double)residues * best.G / 64.0 * stepInstr * 2.15 / 1024.0;  // (of one pass; so is crit)
         const double crit = ((double)longest + best.G) * stepInstr * 3.5;
-        if (best.G >= 32) {
+        if (best.G >= 64 && numSeqs >= 1000) {
+            // every lane of a wave on one sequence: the class kernels have nothing wider to give the longest sequence either, and
+            // pay fill and drain per sequence on top (planner sweep, 2 000 sequences, 1700- / 2000-aa queries: 1.13-1.45 ms
+            // streamed against 1.54-1.95 on the class kernels; Swiss-Prot-like tail, 20 000 sequences: 12.1 against 14.9)
+        } else if (best.G >= 32) {
             if (crit > 1.5 * total) best = StreamPlan();
         } else {
             // 16 lanes per sequence or fewer: the class kernels lose little to fill and drain, and streaming only wins

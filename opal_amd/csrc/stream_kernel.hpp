@@ -35,6 +35,10 @@ struct StreamParams {
     // arithmetic); SW, width 17: 4G lanes x S/4 rows (the longest sequences of a long-tailed database)
     KClass side;
     int sideBlocks;
+    // The first `prioItems` sequences handed out (the longest ones of the range) raise the issue priority of the wave that works
+    // on them: every wave of a persistent launch is equally old, so nothing else would let the wave holding a 20 000-residue
+    // sequence run ahead of its three SIMD neighbours -- and the search ends when that wave does.
+    int prioItems;
 };
 #define STREAM_SW_SIDE_MAX_ROWS 39  // SW streams instantiated with the class body for side items: rows 1..39 (40: one register short)
 #define STREAM_SIDE_WAVES 4  // one wave per SIMD: these few sequences are the critical path, they run at the lone-wave rate
@@ -66,6 +70,7 @@ struct SlotStream {
     int coveredEnd = 0;   // stream position where it ends (INT_MAX once the item range is exhausted)
     int lastEnd = 0;      // end of the last real entry
     bool done = false;
+    bool hot = false;      // the newest entry is one of the launch's longest sequences (StreamParams::prioItems)
     unsigned tokNext = 0;  // letter of the position fetched last
     unsigned bndNext = 0;  // row-chunked queries: the chunk boundary {H, F input} above that position (0: none)
 };
@@ -79,7 +84,7 @@ struct SlotStream {
 // Descriptor: {start, len, caller index, -, residue offset lo, hi, item, running maximum (SW with end locations)}.
 template <int SEPS, bool BND = false>
 __device__ __forceinline__ void stream_fetch(SlotStream& st, const KParams& p, int* next, int* ring, const int x, const int k,
-                                             const int G, const int slotLane0, const int PAD) {
+                                             const int G, const int slotLane0, const int PAD, const int prioItems = 0) {
     const int base = x - k;
     const bool need = !st.done && st.coveredEnd <= base + G - 1;  // slot-uniform
     if (__ballot(need) != 0ull) {  // (wave-uniform branch, every lane inside: the broadcast below reads lane 0 of the slot)
@@ -103,10 +108,16 @@ __device__ __forceinline__ void stream_fetch(SlotStream& st, const KParams& p, i
                 st.coveredEnd += span;
                 st.lastEnd = st.coveredEnd;
                 st.nEntries++;
+                st.hot = idx < prioItems;
             } else {
                 st.done = true;
                 st.coveredEnd = INT_MAX;
+                st.hot = false;
             }
+        }
+        if (prioItems > 0) {  // (wave-uniform: some slot of this wave is on one of the longest sequences, or none is any more)
+            if (__ballot(st.hot) != 0ull) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(0);
         }
         // ring writes by lane 0 of a slot are read by its other lanes below (same wave: LDS keeps program order)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -241,7 +252,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     int outCol = INT_MAX, outRow = -1;
     const int r0 = q0 + k * S - padTop;  // query row held in register 0
 
-    auto fetch = [&](const int x) { stream_fetch<2, CHUNK>(st, p, sp.next, ring, x, k, G, slotLane0, PAD); };
+    auto fetch = [&](const int x) { stream_fetch<2, CHUNK>(st, p, sp.next, ring, x, k, G, slotLane0, PAD, sp.prioItems); };
     fetch(k);
     unsigned bndq = 0;  // CHUNK: lane queue of the boundary words above the columns of this batch (lane 0 consumes)
     unsigned outq = 0;  // CHUNK: lane queue of the last lane's outputs, oldest towards lane 0
@@ -642,7 +653,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
     int bestCol = -1;              // its first column
     int outLcV = INT_MIN, outLcRow = -1;                    // OV: last-column maximum handed down the lanes
 
-    auto fetch = [&](const int x) { stream_fetch<0, CHUNK>(st, p, sp.next, ring, x, k, G, slotLane0, PAD); };
+    auto fetch = [&](const int x) { stream_fetch<0, CHUNK>(st, p, sp.next, ring, x, k, G, slotLane0, PAD, sp.prioItems); };
     fetch(k);
     unsigned bndq = 0;     // CHUNK: lane queue of the boundary words above the columns of this batch (lane 0 consumes)
     unsigned outq = 0;     // CHUNK: lane queue of the last lane's outputs (true values), oldest towards lane 0

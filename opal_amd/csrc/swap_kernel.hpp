@@ -42,6 +42,7 @@ struct SwapParams {
     int* ovfItems;
     int satLimit, negPad;
     unsigned long long* clk;  // clock probe (dp_kernel.hpp)
+    int* started;             // (may be null) every workgroup adds one when it starts: opal_hip_wait_started
 };
 typedef void (*SwapFn)(const SwapParams);
 
@@ -85,6 +86,7 @@ __global__ void __launch_bounds__(SWAP_WAVES * 64, 1) opal_swap_sw(const SwapPar
     unsigned short* const mat16 = reinterpret_cast<unsigned short*>(bnd + (Q + 66));
     unsigned char* const clkSlot = reinterpret_cast<unsigned char*>(mat16) + (((size_t)A * A * 2 + 15) & ~(size_t)15);
     clk_begin(p.clk, nullptr, clkSlot);
+    if (threadIdx.x == 0 && p.started) atomicAdd(p.started, 1);  // this workgroup has its CU
 
     const int item = p.firstItem + (int)blockIdx.x;
     const int seq = p.pairSeq[item];
@@ -292,6 +294,7 @@ __global__ void __launch_bounds__(SWAP_WAVES * 64, 1) opal_swap_gl(const SwapPar
     // (the probe's slot holds 64-bit words: bndF ends on a 4-byte boundary when Q is odd)
     unsigned char* const clkSlot = lds + ((((size_t)(A + 1) * stride + 4 * (size_t)(Q + 128) + 8 * (size_t)(Q + 66)) + 15) & ~(size_t)15);
     clk_begin(p.clk, nullptr, clkSlot);
+    if (threadIdx.x == 0 && p.started) atomicAdd(p.started, 1);  // this workgroup has its CU
 
     const int item = p.firstItem + (int)blockIdx.x;
     const int seq = p.pairSeq[item];

@@ -31,6 +31,15 @@ TOL = float(os.environ.get("TOL", "1.10"))
 # (name, options): every alternative the scheduler could have taken; an option that does not apply to a search changes nothing
 ALTS = [("natural", {}), ("stream=0", {"OPAL_HIP_STREAM": "0"}), ("stream=1", {"OPAL_HIP_STREAM": "1"}), ("narrow=16", {"OPAL_HIP_NARROW": "16"}),
         ("narrow=18", {"OPAL_HIP_NARROW": "18"}), ("swap=0", {"OPAL_HIP_SWAP": "0"}), ("no_uber", {"OPAL_HIP_NO_UBER": "1"})]
+import ctypes as C
+from opal_amd import _lib
+CNAMES = ["stream_sw", "stream_gl", "one_launch", "class", "chunk", "w32", "dtrace", "htrace", "reused", "swapped"]
+def counters():
+    buf = (C.c_longlong * 10)()
+    _lib.lib().opalx_counters(buf, 10)
+    return np.array([int(v) for v in buf])
+def path(delta):
+    return "+".join(f"{CNAMES[i]}{'' if delta[i] // (REPS + 1) <= 1 else '*' + str(int(delta[i] // (REPS + 1)))}" for i in range(10) if delta[i] > 0) or "-"
 dev = torch.device("cuda", 0)
 m = blosum50()[1]
 misses, mismatches, rows = [], [], 0
@@ -52,18 +61,19 @@ for shape in SHAPES:
                 for st in TYPES:
                     if cells1 * Q > 6e12:
                         continue
-                    times, ref = [], None
+                    times, ref, paths = [], None, []
                     for name, o in ALTS:
+                        c0 = counters()
                         for k, v in o.items():
                             opal_amd.set_option(k, v)
                         try:
                             ks = []
                             out = outs[0] if name == "natural" else outs[1]
                             out.fill_(-7)
-                            for _ in range(REPS):
+                            for rep in range(REPS + 1):  # (the first one untimed: launch plans, first use of a kernel shape)
                                 rc, k = pdb.search_device(q, 3 if shape == "sprot" else 11, 1, m, st, opal_amd.MODES[mode], out.data_ptr(),
                                                           out[n:].data_ptr() if st else 0, out[2 * n:].data_ptr() if st else 0)
-                                ks.append(k)
+                                if rep: ks.append(k)
                             if rc not in (0, 1):
                                 times.append(float("nan")); continue
                             times.append(float(np.median(ks)))
@@ -75,11 +85,12 @@ for shape in SHAPES:
                         finally:
                             for k in o:
                                 opal_amd.set_option(k, None)
+                            paths.append(path(counters() - c0))
                     best = np.nanmin(times)
                     ratio = times[0] / best
                     rows += 1
                     flag = "  MISS" if ratio > TOL else ""
-                    print(f"  {shape:5s} {n:7d} {Q:5d} {mode:4s} {st:3d} | " + " ".join(f"{t:10.3f}" for t in times) + f" | {ratio:6.3f}  {ALTS[int(np.nanargmin(times))][0]}{flag}", flush=True)
+                    print(f"  {shape:5s} {n:7d} {Q:5d} {mode:4s} {st:3d} | " + " ".join(f"{t:10.3f}" for t in times) + f" | {ratio:6.3f}  {ALTS[int(np.nanargmin(times))][0]}{flag}  [natural: {paths[0]}" + (f"; best: {paths[int(np.nanargmin(times))]}" if ratio > 1.03 else "") + "]", flush=True)
                     if ratio > TOL:
                         misses.append((shape, n, Q, mode, st, ratio, ALTS[int(np.nanargmin(times))][0]))
         del pdb, d_res, outs

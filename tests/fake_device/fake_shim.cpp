@@ -282,6 +282,7 @@ int opal_hip_launch_stream(const OpalHipLaunch* a, int*) {
         run_items(c, Range{c.first_item, c.num_items}, false);
     });
 }
+int opal_hip_wait_started(const int*, int, void*) { return 0; }  // (the fake streams have no dispatcher to race for)
 int opal_hip_launch_swap(const OpalHipLaunch* a) {
     OpalHipLaunch c = *a;
     if (c.mode == OPAL_MODE_SW) c.width = 17;  // (16-bit arithmetic with the re-run list, like the class kernels)

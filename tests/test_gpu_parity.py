@@ -983,3 +983,30 @@ def test_api_results_do_not_depend_on_where_the_ordering_runs(device_order, orac
             np.testing.assert_array_equal(s, os_, err_msg=mode_name)
             np.testing.assert_array_equal(eq[live], oq[live], err_msg=mode_name)
             np.testing.assert_array_equal(et[live], ot[live], err_msg=mode_name)
+
+
+@pytest.mark.parametrize("mode", ["NW", "HW", "OV"])
+def test_chunked_query_with_32bit_prefix_at_forced_width16(mode, oracle, opal_opt):
+    """Found by the planner sweep (round 5): a query in row chunks (2600 aa) whose longest targets need the 32-bit rung, with
+    the 16-bit range forced onto the packed pairs (OPAL_HIP_NARROW=16/17/18 all end there for such a query). The pairs' chunks
+    index the boundary buffer by token-stream offsets, the 32-bit prefix by residue offsets: run side by side on two streams
+    they overwrote each other's boundary rows (garbage scores for the first items). The prefix now runs on the same stream."""
+    from opal_amd import synth
+    from opal_amd.api import PreparedDb
+    from opal_amd.score_matrix import blosum50
+    n = 6000
+    res, offs, lens = synth.database(n, seed=42)
+    pdb = PreparedDb(res, offs)
+    q = synth.query(2600, seed=7)
+    m = blosum50()[1]
+    order = np.argsort(-lens.astype(np.int64), kind="stable")
+    pick = np.unique(np.concatenate([order[:30], np.random.RandomState(2).choice(n, 20, replace=False)]))
+    db = [res[offs[i]:offs[i + 1]] for i in pick]
+    want = oracle.search(q, db, 11, 1, m, 1, MODES[mode])
+    for narrow in ("16", "18"):
+        opal_opt.set("OPAL_HIP_NARROW", narrow)
+        rc, s, eq, et = pdb.search(q, 11, 1, m, 1, MODES[mode])
+        assert rc == want[0] == 0
+        np.testing.assert_array_equal(s[pick], want[1], err_msg=f"{mode} narrow={narrow}: score")
+        np.testing.assert_array_equal(eq[pick], want[2], err_msg=f"{mode} narrow={narrow}: endQ")
+        np.testing.assert_array_equal(et[pick], want[3], err_msg=f"{mode} narrow={narrow}: endT")

@@ -358,6 +358,11 @@ def test_streaming_plan_of_the_scheduler(opal_opt):
     # a small database: the longest sequence would outlast the whole search on its lanes -- class kernels
     assert plan(2000, nseq=300) == (0, 0, 0, 0)
     assert plan(3000, nseq=300) == (0, 0, 0, 0)
+    # ... but with every lane of a wave on one sequence (64 lanes) the class kernels have nothing wider to offer the longest
+    # sequence: a 2000-aa query streams from 1000 sequences on (planner sweep, profiles/r05_planner_sweep.txt)
+    assert plan(2000, nseq=2000) == (18, 64, 32, 1)
+    # a query in row chunks streams only with enough sequences per slot (20 000 on 8 192 slots: class-kernel chunks)
+    assert plan(3000, nseq=20000) == (0, 0, 0, 0)
     # a 35 000-residue sequence among 540 000 (the published shape), 513-aa query: not as a whole ...
     assert plan(513, nseq=541762, mean=356, longest=35213) == (0, 0, 0, 0)
     # ... but what is left behind its 128 longest sequences streams on 16 lanes
