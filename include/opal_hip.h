@@ -158,6 +158,14 @@ int opal_hip_launch_stream(const OpalHipLaunch* args, int* next_counter);
 int opal_hip_swap_rows(int query_length, int alphabet_length);
 size_t opal_hip_swap_lds_bytes(int rows_per_lane, int query_length, int alphabet_length);  /* (> 160 KiB: not launchable) */
 int opal_hip_launch_swap(const OpalHipLaunch* args);
+/* One query x target pair spread over several waves of one workgroup (pair_kernel.hpp: NW / HW / OV, int32, 2-byte profile
+   entries -- every matrix entry must fit 16 bits): the longest targets of a global-mode search, items [first_item, +num_items),
+   one workgroup each. opal_hip_pair_shape: rows per lane (2 / 4 / 8) and waves (1..16) for this query, 0 if none fits LDS.
+   opal_hip_launch_pair: rows_per_lane / waves_per_block from it; `boundary`: (waves - 1) x bnd_stride 8-byte words (the bottom
+   rows the waves hand each other), bnd_stride >= the residues of the items + 64, bnd_base = the residue offset of the first item.
+   Fields used as in opal_hip_launch_swap (started_counter included). */
+int opal_hip_pair_shape(int query_length, int alphabet_length, int* rows, int* waves);
+int opal_hip_launch_pair(const OpalHipLaunch* args, void* boundary, unsigned long long bnd_base, unsigned long long bnd_stride);
 /* Enqueue on `stream` a one-wave kernel that ends when *counter >= target (or after ~2 ms): what is launched behind it on
    that stream reaches the dispatcher only after `target` workgroups of a launch on ANOTHER stream have taken their CUs. A grid
    that fills every CU with workgroups of 39 KB of LDS otherwise starves a 55 KB workgroup arriving a moment later until

@@ -295,7 +295,7 @@ void db_release(OpalxDb* db) {
     db->hLens.release(); db->hEmpty.release(); db->dLens.release(); db->dEmpty.release(); db->dOrderScratch.release();
     db->tokens.release(); db->pairOff.release(); db->hPairOff.release();
     db->timeline.release();
-    db->header.release(); db->hHeader.release(); db->ovfItems.release(); db->boundary.release(); db->scratch.release();
+    db->header.release(); db->hHeader.release(); db->ovfItems.release(); db->boundary.release(); db->pairBnd.release(); db->scratch.release();
     db->results.release(); db->quads.release();
     db->ovfCount.p = nullptr; db->matrix.p = nullptr; db->query.p = nullptr;
     db->seqItem.release(); db->revFlags.release(); db->redo.release();

@@ -711,17 +711,21 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
             while (q32 < P && !skew_safe(db->pairLen[2 * (size_t)q32])) { moved += db->pairLen[2 * (size_t)q32] + db->pairLen[2 * (size_t)q32 + 1]; q32++; }
             // (a query in row chunks: the unskewable sequences run on the class kernels' chunks on a side stream BESIDE the
             // streamed ones, not inside the launch -- they may hold a sixth of the residues before they become the longer side)
-            if (q32 < P && (moved * (chunkedQuery ? 6 : 50) <= db->residues || opts().stream == 1) && !opts().noSkew) {
+            // (round 5: a sixth also for unchunked queries -- the longest of them now go to the pair kernel, and the alternative to
+            // a stream with a few hundred side workgroups ahead of it is the class kernels at 64 lanes for EVERYTHING: 81 ms
+            // against ~50 for a 2000-aa query on the Swiss-Prot shape, whose unskewable targets hold 2.7 % of the residues)
+            if (q32 < P && (moved * (chunkedQuery ? 6 : (opts().pair != 0 ? 16 : 50)) <= db->residues || opts().stream == 1) && !opts().noSkew) {
                 gplan = plan_stream(Q, A, mode, wantEnd, db->residues - moved, db->pairLen[2 * (size_t)q32], db->numSeqs - 2 * q32);
             }
             if (!gplan.G) q32 = p32;
         }
         int sideBlocks = 0;  // workgroups of the launches that run beside the main range on other streams
+        int taken = 0;       // items [.., taken) have been handed to a pair launch (pair_kernel.hpp): every range below starts behind them
         auto launch_global_stream = [&]() -> int {
             OpalHipLaunch a;
             fill_launch(a, c, gplan.width, 0, 0, nullptr, db->ovfCount.p);
             a.lanes_per_seq = gplan.G; a.rows_per_lane = gplan.rows; a.skew = 1;
-            a.first_item = 2 * q32; a.num_items = 2 * (P - q32);
+            a.first_item = std::max(2 * q32, taken); a.num_items = 2 * P - a.first_item;  // (taken: what a pair launch has, below)
             a.reserve_blocks = std::min(sideBlocks, 64);
             a.prio_items = stream_prio_items(db, a.first_item, a.num_items, gplan.G);
             if (gplan.passes > 1) {
@@ -749,7 +753,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                 return 0;
             }
             // the skew-unsafe sequences (the longest ones) ride along in the same launch on the unskewed class body
-            a.side_first_item = 2 * p32; a.side_num_items = 2 * (q32 - p32);
+            a.side_first_item = std::max(2 * p32, taken); a.side_num_items = std::max(0, std::max(2 * q32, taken) - a.side_first_item);
             if (debug_on())
                 fprintf(stderr, "[opal] streaming launch mode=%d width=%d G=%d rows=%d items=[%d,+%d)\n", mode, gplan.width, gplan.G, gplan.rows,
                         a.first_item, a.num_items);
@@ -774,9 +778,43 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
         // there, 8 ms against a 110-aa query on a search whose bulk takes 3 -- and the 16-bit ones behind them that would outlast
         // the search alone on the widest class. Items [nBad, nBad + swapG) on a high-priority stream of their own, submitted first;
         // the 32-bit rung then has nothing left, the 16-bit range starts behind them.
+        // ONE PAIR OVER SEVERAL WAVES (pair_kernel.hpp): the targets the bounds send to the 32-bit rung, and the long 16-bit ones
+        // behind them that would outlast the search on one wave, each on a workgroup of its own whose waves share the query's
+        // rows -- a 35 213-residue target against a 2000-aa query is 22 ms of one wave's 32-row steps, 6 ms of eight waves'
+        // 4-row steps. On the high-priority stream of the swapped launches (which then has nothing to do), submitted first.
+        int pairN = 0;
+        void* joinPair = nullptr;
+        // (not beside class kernels on packed pairs, width 16: their items are PAIRS of sequences; beside a stream it is fine)
+        if (!chunkedQuery && (narrow != 16 || gplan.G) && P > 0) {
+            int rowsP = 0, wavesP = 0;
+            pairN = plan_pair(Q, A, mode, seqLenOf, nBad, 2 * P - nBad, db->residues, 2 * p32 - nBad, fits16, &rowsP, &wavesP);
+            while (pairN > 0 && db->pairSeq[(size_t)nBad + pairN - 1] < 0) pairN--;  // (the absent last item of an odd count)
+            if (pairN > 0 && pairN < 2 * p32 - nBad) pairN = 0;
+            if (pairN > 0) {
+                unsigned long long base = 0, words = 64;
+                for (int i = 0; i < nBad; i++) base += (unsigned long long)db->pairLen[(size_t)i];
+                for (int i = 0; i < pairN; i++) words += (unsigned long long)db->pairLen[(size_t)nBad + i];
+                void* fork = db->event(11);
+                void* side = db->swap();
+                OpalHipLaunch a;
+                fill_launch(a, c, 32, 0, 0, nullptr, db->ovfCount.p + 1);
+                a.rows_per_lane = rowsP; a.waves_per_block = wavesP; a.first_item = nBad; a.num_items = pairN; a.stream = side;
+                a.started_counter = db->ovfCount.p + 3;
+                if (debug_on()) fprintf(stderr, "[opal] pair launch mode=%d: items [%d,+%d) on %d waves x %d rows per lane\n", mode, nBad, pairN, wavesP, rowsP);
+                if ((wavesP > 1 && !db->pairBnd.ensure((size_t)(wavesP - 1) * (size_t)words, 1.25)) || !fork || !side || opal_hip_event_record(fork, st) ||
+                    opal_hip_stream_wait_event(side, fork) || !gate_items(db, side, nBad, pairN) || opal_hip_launch_pair(&a, db->pairBnd.p, base, words) ||
+                    !(joinPair = db->event(12)) || opal_hip_event_record(joinPair, side) ||
+                    (!opts().noStartedWait && opal_hip_wait_started(db->ovfCount.p + 3, pairN, st))) {
+                    db->quiesce();
+                    return OPAL_ERR_NO_SIMD_SUPPORT;
+                }
+                count(CNT_PAIRED, pairN);
+                taken = nBad + pairN;  // (no CUs reserved for them: the stream behind waits until they have started, and takes their CUs when they end)
+            }
+        }
         int swapG = 0;
         void* joinSwapG = nullptr;
-        if (!chunkedQuery && !gplan.G && narrow != 16 && P > 0) {
+        if (!chunkedQuery && !gplan.G && narrow != 16 && P > 0 && pairN == 0) {
             int rowsG = 0;
             const int planned = plan_swap(Q, A, mode, seqLenOf, nBad, 2 * P - nBad, db->residues, &rowsG, fits16);
             const int need32 = 2 * p32 - nBad;
@@ -802,12 +840,12 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                     return OPAL_ERR_NO_SIMD_SUPPORT;
                 }
                 count(CNT_SWAPPED, swapG);
-                sideBlocks += swapG;
             }
         }
         // (what the swapped launch took is gone from both rungs: the 32-bit range is empty, the 16-bit one starts behind it)
-        const int first16 = swapG > 0 ? nBad + swapG : 2 * p32;
+        const int first16 = std::max(swapG > 0 ? nBad + swapG : 2 * p32, taken);
         if (swapG > 0) { p32 = 0; q32 = 0; nBad = 0; }
+        const int first32 = std::max(nBad, taken);  // the 32-bit prefix: what the pair launch has not taken (normally nothing then)
         // A query beyond one wave runs in row chunks, one launch after the other; its 32-bit prefix (a few long sequences: every
         // chunk is one long lone-wave tail, 2 x 2.4 ms of a 26 ms 3000-aa NW search) runs BESIDE the 16-bit chunks on a
         // high-priority side stream. The two ranges share nothing but the buffers they index by their own sequences.
@@ -820,13 +858,13 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
         // need: the side streams 0..2 belong to the long classes of the 16-bit range.)
         // (not beside row chunks at width 16: those index the boundary buffer by the PAIRS' token streams, the 32-bit prefix by
         // its sequences' residues -- two index spaces in one buffer; only test hooks get there, a query in row chunks runs at width 17 / 18)
-        if (P > q32 && (2 * p32 > nBad || (chunkedQuery && gplan.G && gplan.passes > 1 && q32 > p32)) && !opts().noSidePrefix &&
+        if (P > q32 && (2 * p32 > first32 || (chunkedQuery && gplan.G && gplan.passes > 1 && q32 > p32)) && !opts().noSidePrefix &&
             !(chunkedQuery && narrow == 16)) {
             void* fork = db->event(8);
             void* side = chunkedQuery ? db->stream(0) : db->swap();
             if (fork && side && !opal_hip_event_record(fork, st) && !opal_hip_stream_wait_event(side, fork)) { c32.stream = side; join32 = db->event(9); }
         }
-        if (2 * p32 > nBad && launch_range(c32, 32, 0, 0, nullptr, nBad, 2 * p32 - nBad, seqLenOf, db->ovfCount.p + 1)) {
+        if (2 * p32 > first32 && launch_range(c32, 32, 0, 0, nullptr, first32, 2 * p32 - first32, seqLenOf, db->ovfCount.p + 1)) {
             db->quiesce();
             return OPAL_ERR_NO_SIMD_SUPPORT;
         }
@@ -836,7 +874,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
             // stream, beside the 32-bit ones: each of these launches is one lone-wave tail, 3.5-4 ms next to a stream, and four
             // of them in a row took as long as the three streamed chunks, 15 ms)
             SearchCtx c16 = c32;
-            if (c32.stream && 2 * p32 > nBad) {
+            if (c32.stream && 2 * p32 > first32) {
                 void* side2 = db->stream(1);
                 if (side2 && !opal_hip_stream_wait_event(side2, db->event(8))) { c16.stream = side2; join16 = db->event(10); }
             }
@@ -845,14 +883,17 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
             if (e || (join16 && opal_hip_event_record(join16, c16.stream))) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
         }
         if (c32.stream && (!join32 || opal_hip_event_record(join32, c32.stream))) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
-        if (P > q32) {
+        if (P > q32 && 2 * P > taken) {
             const int e = gplan.G ? launch_global_stream()
                         : narrow == 16 ? launch_range(c, 16, 0, 0, nullptr, p32, P - p32, pairLenOf, db->ovfCount.p)
                                        : launch_range(c, narrow, 0, 0, nullptr, first16, 2 * P - first16, seqLenOf, db->ovfCount.p);
             if (e) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
         }
         if ((c32.stream && opal_hip_stream_wait_event(st, join32)) || (join16 && opal_hip_stream_wait_event(st, join16)) ||
-            (joinSwapG && opal_hip_stream_wait_event(st, joinSwapG))) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
+            (joinSwapG && opal_hip_stream_wait_event(st, joinSwapG)) || (joinPair && opal_hip_stream_wait_event(st, joinPair))) {
+            db->quiesce();
+            return OPAL_ERR_NO_SIMD_SUPPORT;
+        }
     }
     if (evStop) { opal_hip_event_record(evStop, st); db->asyncEvents = db->asyncTimed; }
     // (a caller that copies the results back on the same stream and waits for that copy needs no wait of its own here)

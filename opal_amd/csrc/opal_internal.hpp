@@ -50,6 +50,7 @@ enum Counter {
     CNT_HOST_TRACED,     // alignments traced (or started) by the host
     CNT_REUSED_FILLS,
     CNT_SWAPPED,         // targets searched on the role-swapped kernel (the longest ones of a search with a short query)    // opalSearchDatabase calls that found their database already on the device (same lengths; changed chunks re-uploaded)
+    CNT_PAIRED,          // targets searched with one pair spread over several waves (pair_kernel.hpp: the longest ones of a global-mode search)
     CNT_COUNT
 };
 extern std::atomic<long long> g_counters[CNT_COUNT];
@@ -203,6 +204,7 @@ struct OpalxDb {
     opal_host::DevBuf<int> ovfItems;  // [items]
     // device: per-search scratch
     opal_host::DevBuf<unsigned char> boundary;  // 8 B per residue: chunk-boundary rows of long queries (allocated on first use)
+    opal_host::DevBuf<unsigned long long> pairBnd;  // pair_kernel.hpp: the bottom rows the waves of a pair hand each other (allocated on first use)
     opal_host::DevBuf<int> scratch;             // [2N] per-sequence values carried across query chunks
     opal_host::DevBuf<int> results;             // [3N] device staging of host-array searches
     opal_host::DevBuf<int> quads;               // degenerate results on their way to the scatter kernel
@@ -375,6 +377,9 @@ bool plan_chunks(int width, int mode, int swEndPass, int Q, int A, long long nIt
 struct StreamPlan { int width = 0, G = 0, rows = 0, passes = 1; };  // passes > 1: the query runs in that many row chunks
 StreamPlan plan_stream(int Q, int A, int mode, int wantEnd, long long residues, int longest, int numSeqs);
 int plan_swap(int Q, int A, int mode, LenView lenOf, int first, int count, long long residues, int* rowsOut, bool fits16 = true);  // items for swap_kernel.hpp (0: none)
+// items for pair_kernel.hpp (0: none): the targets that need 32 bits (need32 of them, a prefix) and the ones behind them that would
+// outlast the search alone on a wave; rows / waves: the kernel's shape for this query
+int plan_pair(int Q, int A, int mode, LenView lenOf, int first, int count, long long residues, int need32, bool fits16, int* rowsOut, int* wavesOut);
 
 bool args_fit_int32(int Go, int Ge, const int* M, int A);
 int ensure_query_buffers(OpalxDb* db, const unsigned char* query, int Q, const int* M, int A);

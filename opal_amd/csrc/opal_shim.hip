@@ -17,6 +17,7 @@
 #include "dp_kernel.hpp"
 #include "stream_kernel.hpp"
 #include "swap_kernel.hpp"
+#include "pair_kernel.hpp"
 #include "opal_hip.h"
 #include "options.hpp"
 
@@ -666,10 +667,16 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
         if (ldsLaunch > 160 * 1024) { snprintf(g_err, sizeof g_err, "side items: profile needs %zu bytes of LDS", ldsLaunch); return 2; }
     }
     if (a->mode != MODE_SW && a->side_num_items > 0) {
-        const int perSide = STREAM_SIDE_WAVES * (64 / G);
+        // a handful of side sequences: one wave per SIMD (they are the critical path); hundreds of them (a long query on a database
+        // with a real length tail): every wave of their workgroups works, and the stream starts beside them on the other CUs
+        sp.sideWaves = a->side_num_items * G / 64 > cus ? STREAM_WAVES : STREAM_SIDE_WAVES;
+        const int perSide = sp.sideWaves * (64 / G);
         sp.side = KClass{log2G, a->side_first_item, a->side_num_items, 0};
         sp.sideBlocks = (a->side_num_items + perSide - 1) / perSide;
-        if (blocks + sp.sideBlocks > cus && blocks > 1) blocks = std::max(1, cus - sp.sideBlocks);  // every workgroup resident from the start
+        // (every workgroup resident from the start -- but never fewer than half the CUs for the stream: the side workgroups come
+        // first in the grid and leave, the persistent ones take their CUs as they do. max(1, ...) here once left a 2000-aa search of
+        // the Swiss-Prot shape with ONE streaming workgroup: 10.9 s)
+        if (blocks + sp.sideBlocks > cus && blocks > 1) blocks = std::max(std::min(blocks, cus / 2), cus - sp.sideBlocks);
     }
     if (a->reserve_blocks > 0 && blocks + sp.sideBlocks + a->reserve_blocks > cus)  // CUs for what runs beside this launch on other streams
         blocks = std::max(std::min(blocks, cus / 2), cus - sp.sideBlocks - a->reserve_blocks);
@@ -678,6 +685,51 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
     hipLaunchKernelGGL(fn, dim3(blocks + sp.sideBlocks), dim3(STREAM_WAVES * 64), ldsLaunch, (hipStream_t)a->stream, sp);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("streaming kernel launch", e);
+}
+
+// ------------------------------------------------------------------ one pair over several waves (pair_kernel.hpp)
+// Rows per lane and waves per workgroup for a query: the cheapest column step among the instantiated row counts whose profile
+// fits LDS (a step is ~9 instructions per row + ~30; up to two waves per SIMD run at the lone-wave rate, four share the pipe).
+extern "C" int opal_hip_pair_shape(int query_length, int alphabet_length, int* rows, int* waves) {
+    double bestCost = 0;
+    int bestS = 0, bestW = 0;
+    for (int S : {2, 4, 8}) {
+        const int W = (query_length + 64 * S - 1) / (64 * S);
+        if (W < 1 || W > PAIR_MAX_WAVES || opal_pair_lds_bytes(W, S, alphabet_length) > 160 * 1024) continue;
+        const double cost = (9.0 * S + 40.0) * (W <= 8 ? 5.2 : 8.6);
+        if (!bestS || cost < bestCost) { bestCost = cost; bestS = S; bestW = W; }
+    }
+    if (rows) *rows = bestS;
+    if (waves) *waves = bestW;
+    return bestS ? 1 : 0;
+}
+
+extern "C" int opal_hip_launch_pair(const OpalHipLaunch* a, void* boundary, unsigned long long bnd_base, unsigned long long bnd_stride) {
+    const int S = a->rows_per_lane, W = a->waves_per_block;
+    PairFn fn = (W >= 1 && W <= PAIR_MAX_WAVES && (long long)W * 64 * S >= a->query_length && a->query_length >= 1 && !a->work &&
+                 (W == 1 || boundary) && (!a->want_end || (a->out_end_query && a->out_end_target)))
+                    ? opal_pair_fn(a->mode, S) : nullptr;
+    if (!fn) {
+        snprintf(g_err, sizeof g_err, "unlaunchable pair shape: mode=%d rows=%d waves=%d Q=%d", a->mode, S, W, a->query_length);
+        fprintf(stderr, "[opal-hip] %s\n", g_err);
+        return 2;
+    }
+    if (a->num_items <= 0) return 0;
+    const size_t lds = opal_pair_lds_bytes(W, S, a->alphabet_length);
+    if (lds > 160 * 1024) { snprintf(g_err, sizeof g_err, "query profile needs %zu bytes of LDS (>160 KiB)", lds); return 2; }
+    PairParams p;
+    memset(&p, 0, sizeof p);
+    p.query = a->query; p.matrix = a->score_matrix; p.Q = a->query_length; p.A = a->alphabet_length; p.Go = a->gap_open; p.Ge = a->gap_ext;
+    p.res = a->residues; p.seqOff = a->seq_offset; p.pairLen = a->pair_len; p.pairSeq = a->pair_seq;
+    p.firstItem = a->first_item; p.numItems = a->num_items;
+    p.outScore = a->out_score; p.outEndQ = a->out_end_query; p.outEndT = a->out_end_target;
+    p.bnd = (unsigned long long*)boundary; p.bndBase = bnd_base; p.bndStride = bnd_stride;
+    p.started = a->started_counter;
+    p.clk = a->clock_probe;
+    if (lds > 64 * 1024 && raise_lds_limit((const void*)fn)) return 1;
+    hipLaunchKernelGGL(fn, dim3(a->num_items), dim3(W * 64), lds, (hipStream_t)a->stream, p);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("pair kernel launch", e);
 }
 
 // One wave that ends when `target` workgroups of a launch on another stream have started (see include/opal_hip.h).

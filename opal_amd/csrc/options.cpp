@@ -135,6 +135,7 @@ const std::vector<Desc>& table() {
         integer("OPAL_HIP_WAVES_PER_BLOCK", &Options::wavesPerBlock, 1, 16),
         flag("OPAL_HIP_NO_STARTED_WAIT", &Options::noStartedWait),
         integer("OPAL_HIP_SWAP", &Options::swap, 0, 1 << 20),
+        integer("OPAL_HIP_PAIR", &Options::pair, 0, 1 << 20),
         one_of("OPAL_HIP_SWAP_ROWS", &Options::swapRows, {8, 16, 24, 40}),
     };
     return t;

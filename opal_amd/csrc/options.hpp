@@ -68,6 +68,7 @@ struct Options {
     int wavesPerBlock = 0;            // OPAL_HIP_WAVES_PER_BLOCK (test hook)
     bool noStartedWait = false;       // OPAL_HIP_NO_STARTED_WAIT: the grids of a search do not wait for its swapped workgroups to have started
     int swap = -1;                    // OPAL_HIP_SWAP: 0 never use the role-swapped kernel, N > 0 (test hook) the N longest targets, -1 automatic
+    int pair = -1;                    // OPAL_HIP_PAIR: 0 never spread a pair over several waves, N > 0 (test hook) the N longest targets, -1 automatic
     int swapRows = 0;                 // OPAL_HIP_SWAP_ROWS (test hook): 8 / 16 / 24 / 40
     // the values of the options that are part of a launch-plan cache key, as one string
     std::string plan_key() const;

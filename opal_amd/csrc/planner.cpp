@@ -278,6 +278,61 @@ int plan_swap(int Q, int A, int mode, LenView lenOf, int first, int count, long 
     return n;
 }
 
+/*
+ * One pair over several waves (pair_kernel.hpp, NW / HW / OV): how many of the longest items of [first, first + count) go there.
+ * The need32 items the a-priori bounds send to the 32-bit rung always do (if the kernel has a shape for the query) -- on the
+ * 32-bit class kernels each is one wave's 32-row steps, 15-22 ms for a 35 213-residue target --, and behind them the targets
+ * that, alone on a wave of the 16-bit class body, would outlast half the search. Where the role-swapped kernels exist (queries
+ * to 1024 residues) and are the faster place for the longest target, nothing goes here.
+ */
+int plan_pair(int Q, int A, int mode, LenView lenOf, int first, int count, long long residues, int need32, bool fits16, int* rowsOut, int* wavesOut) {
+    *rowsOut = 0; *wavesOut = 0;
+    const int forced = opts().pair;
+    if (forced == 0 || mode == OPAL_MODE_SW || !fits16 || count <= 0) return 0;
+    int S = 0, W = 0;
+    if (!opal_hip_pair_shape(Q, A, &S, &W)) return 0;
+    *rowsOut = S; *wavesOut = W;
+    if (forced > 0) return std::min(forced, count);
+    if (opts().swap > 0) return 0;  // (test hook: the N longest targets are FORCED onto the swapped kernels)
+    if (need32 > 128) return 0;
+    // (per step: ~9 instructions per row + ~40 of lane hand-off, queues, result tracking and the barrier share, at the rate of
+    // one or two waves per SIMD. Measured, 100 000 sequences of the published shape: 513-aa HW 7.7 ms with four targets here against
+    // 9.9 without, 2000-aa HW 11.1 against 26; all 541 762, 300 aa: 8.4 ms with 34 targets here, 7.9 with 10 on the swapped kernel)
+    auto pairClocks = [&](int len) { return (double)(len + 63 + (W - 1) * 160) * (9.0 * S + 40.0) * (W <= 8 ? 5.2 : 8.6); };
+    int G0 = 1;
+    while (G0 < 64 && (Q + G0 - 1) / G0 > OPAL_HIP_MAX_ROWS) G0 *= 2;
+    const int S0 = (Q + G0 - 1) / G0;
+    const int Gw = std::min(64, 4 * G0);
+    const int Sw = (Q + Gw - 1) / Gw;
+    const int S64 = ((Q + 63) / 64 + 7) / 8 * 8;  // rows per lane of the 32-bit class kernels (64 lanes per sequence)
+    const double totalClocks = (double)residues / (64 / G0) * (2.15 * 6.5 * S0 + 90.0) / 1024.0;
+    // (a sixth of the search: what stays behind shares its CU with other long targets -- 16 waves per side workgroup of a stream,
+    // 8.6 clocks per instruction instead of a lone wave's 4.8 -- and a 30 000-residue target left on the class body of a
+    // 2000-aa search was 34 ms of a 66 ms search)
+    const double budget = std::max(0.15 * totalClocks, 20000.0);
+    auto classClocks = [&](int len, bool wide) { return wide ? (len + 63.0) * 4.8 * (11.0 * S64 + 14.0) : (len + Gw - 1.0) * 4.8 * (8.0 * Sw + 28.0); };
+    const int longest = lenOf(first);
+    // (the swapped kernels where they are the faster place: short queries)
+    const int swapRows = opal_hip_swap_gl_rows(Q, A, 1);
+    if (swapRows && opts().swap != 0) {
+        const double swapClocks = (double)((longest + 64 * swapRows - 1) / (64 * swapRows)) * (Q + 63) * 5.0 * (8.3 * swapRows + 80.0);
+        if (swapClocks <= pairClocks(longest)) return 0;
+    }
+    const double limit = std::max(budget, pairClocks(longest));  // the search cannot end before its longest target has
+    int n = 0;
+    while (n < count && n < 128) {
+        const int len = lenOf(first + n);
+        const bool wide = n < need32;
+        if (!wide && !(classClocks(len, false) > limit && pairClocks(len) < 0.7 * classClocks(len, false))) break;
+        n++;
+    }
+    if (n < need32) return 0;  // (all of the 32-bit ones or none: what is left of them would need the 32-bit class kernels anyway)
+    if (n > 0 && debug_on())
+        fprintf(stderr, "[opal] pair plan: Q=%d, %d waves x 64 lanes x %d rows: the %d longest targets (%d .. %d residues, %d of them beyond the 16-bit bounds); longest: %.0f clocks there, %.0f on the class kernels; budget %.0f\n",
+                Q, W, S, n, longest, lenOf(first + n - 1), need32, pairClocks(longest), classClocks(longest, need32 > 0), budget);
+    return n;
+}
+
 // Streaming SW score search (stream_kernel.hpp): which geometry, if any. Long queries need 32 or 64 lanes per sequence,
 // where the class kernels lose (G-1)/(L+G-1) of their steps to pipeline fill and drain; the streaming kernel has no
 // such loss, so it is chosen by the cost of a column step per useful query row alone.

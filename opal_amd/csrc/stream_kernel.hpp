@@ -39,6 +39,9 @@ struct StreamParams {
     // on them: every wave of a persistent launch is equally old, so nothing else would let the wave holding a 20 000-residue
     // sequence run ahead of its three SIMD neighbours -- and the search ends when that wave does.
     int prioItems;
+    // NW / HW / OV: waves of a side workgroup that take work (0 = STREAM_SIDE_WAVES, one per SIMD: a handful of sequences that
+    // are the critical path; 16 = all of them when the side range holds hundreds of sequences -- then it is throughput that counts)
+    int sideWaves;
 };
 #define STREAM_SW_SIDE_MAX_ROWS 39  // SW streams instantiated with the class body for side items: rows 1..39 (40: one register short)
 #define STREAM_SIDE_WAVES 4  // one wave per SIMD: these few sequences are the critical path, they run at the lone-wave rate
@@ -546,7 +549,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
         // arithmetic, in the same launch and ahead of the streaming workgroups in dispatch order. (As a separate launch on
         // another stream they overlapped with the stream only when HIP happened to give the two streams different hardware
         // queues: 9 ms or 13 ms per search from run to run.)
-        opal_dp_body<WIDTH, MODE, 0, S>(p, sp.side, (int)blockIdx.x, STREAM_SIDE_WAVES);
+        opal_dp_body<WIDTH, MODE, 0, S>(p, sp.side, (int)blockIdx.x, sp.sideWaves > 0 ? sp.sideWaves : STREAM_SIDE_WAVES);
         return;
     }
 

@@ -282,6 +282,18 @@ int opal_hip_launch_stream(const OpalHipLaunch* a, int*) {
         run_items(c, Range{c.first_item, c.num_items}, false);
     });
 }
+int opal_hip_pair_shape(int Q, int, int* rows, int* waves) {
+    for (int S : {2, 4, 8}) {
+        const int W = (Q + 64 * S - 1) / (64 * S);
+        if (W >= 1 && W <= 16) { if (rows) *rows = S; if (waves) *waves = W; return 1; }
+    }
+    return 0;
+}
+int opal_hip_launch_pair(const OpalHipLaunch* a, void*, unsigned long long, unsigned long long) {
+    OpalHipLaunch c = *a;
+    c.width = 32;
+    return enqueue(c.stream, [c] { run_items(c, Range{c.first_item, c.num_items}, false); });
+}
 int opal_hip_wait_started(const int*, int, void*) { return 0; }  // (the fake streams have no dispatcher to race for)
 int opal_hip_launch_swap(const OpalHipLaunch* a) {
     OpalHipLaunch c = *a;

@@ -23,13 +23,13 @@ pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(os.path.dirname(HERE), "opal_amd", "csrc", "libopal.so")
-NAMES = ["stream_sw", "stream_global", "one_launch", "class_launches", "chunk_launches", "width32", "device_traced", "host_traced", "reused_fills", "swapped"]
+NAMES = ["stream_sw", "stream_global", "one_launch", "class_launches", "chunk_launches", "width32", "device_traced", "host_traced", "reused_fills", "swapped", "paired"]
 
 
 def counters():
     from opal_amd import _lib
-    buf = (C.c_longlong * 10)()
-    _lib.lib().opalx_counters(buf, 10)
+    buf = (C.c_longlong * 11)()
+    _lib.lib().opalx_counters(buf, 11)
     return dict(zip(NAMES, [int(v) for v in buf]))
 
 
@@ -108,15 +108,17 @@ def test_longtail_search_score_and_end(qlen, base, gold, oracle):
         assert (eq >= 0).all() and (eq < qlen).all() and (et >= 0).all() and (et < lens).all()
     assert (out["SW"][0] > 0).all()
     # which path: NW targets of more than ~32 000 residues cannot stay in 16 bits (gap extension alone exceeds the range): the
-    # 32-bit class kernels, or -- queries up to 1024 residues -- the role-swapped int32 kernels (round 4)
-    assert paths["NW"]["width32"] + paths["NW"]["swapped"] >= 1
+    # role-swapped int32 kernels (short queries, round 4), one pair over several waves (pair_kernel.hpp, round 5), or -- with
+    # both switched off -- the 32-bit class kernels
+    assert paths["NW"]["width32"] + paths["NW"]["swapped"] + paths["NW"]["paired"] >= 1
     if qlen <= 1024:
-        assert paths["NW"]["swapped"] >= 8 and paths["HW"]["swapped"] >= 8 and paths["OV"]["swapped"] >= 8 and paths["NW"]["width32"] == 0
-    # a 2000-aa query on 100 000 sequences: the global modes stream their 16-bit part (the > 32 000-residue targets are on
-    # the 32-bit rung, in row chunks: a 2000-row int32 profile exceeds the LDS); SW does not -- eight 35 213-residue
-    # targets on 64 lanes each outlast the rest of this small database, so plan_stream leaves it to the class kernels
+        for mode in ("NW", "HW", "OV"):
+            assert paths[mode]["swapped"] + paths[mode]["paired"] >= 8 and paths[mode]["width32"] == 0, (mode, paths[mode])
+    # a 2000-aa query on 100 000 sequences: the global modes stream their 16-bit part, the targets beyond the 16-bit bounds (and
+    # the long ones behind them) each on a workgroup of eight waves; SW does not stream -- eight 35 213-residue targets on 64
+    # lanes each outlast the rest of this small database, so plan_stream leaves it to the class kernels
     if qlen == 2000:
-        assert paths["HW"]["stream_global"] == 1 and paths["HW"]["chunk_launches"] >= 2
+        assert paths["HW"]["stream_global"] == 1 and paths["HW"]["paired"] >= 8 and paths["HW"]["width32"] == 0
         assert paths["SW"]["stream_sw"] + paths["SW"]["class_launches"] + paths["SW"]["one_launch"] >= 1
 
 
