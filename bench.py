@@ -473,12 +473,22 @@ def main():
 
     # settle: the process has just generated and packed its database (host work, the GPU idle): the clock governor starts every
     # burst of launches at its low point and needs ~20 ms of sustained activity to reach what it holds under load
+    # (N > 1: every step carries a collective, so every rank must run the SAME number of them: one probing step, its time
+    # reduced over the ranks, decides how many follow)
     settle_steps = 0
     if args.settle_ms > 0:
+        fence()
         t_settle = time.perf_counter()
-        while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms and settle_steps < 1000:
+        step()
+        flush()
+        fence()
+        t_one = torch.tensor([time.perf_counter() - t_settle], dtype=torch.float64, device=dev if backend == "nccl" else torch.device("cpu"))
+        if multi:
+            dist.all_reduce(t_one, op=dist.ReduceOp.MAX)
+        more = int(min(1000, max(0, np.ceil(args.settle_ms * 1e-3 / max(float(t_one.item()), 1e-5)) - 1)))
+        for _ in range(more):
             step()
-            settle_steps += 1
+        settle_steps = 1 + more
     for _ in range(args.warmup):
         step()
     flush()
@@ -598,7 +608,7 @@ def main():
                     ("c5", 2000, 100000, "SW", 0): "c5", ("c5", 2000, 100000, "SW", 1): "c5end", ("c5", 2000, 100000, "NW", 1): "c5nw",
                     ("c5", 2000, 100000, "HW", 1): "c5hw", ("c5", 2000, 100000, "OV", 1): "c5ov"}
             tag = tags.get(key[:5]) if (key[5], key[6]) == (11, 1) else None
-            for rnd in ("r04", "r03", "r02"):
+            for rnd in ("r05", "r04", "r03", "r02"):
                 path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}.json")
                 if tag and os.path.exists(path):
                     with open(path) as fh:

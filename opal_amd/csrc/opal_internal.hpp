@@ -251,7 +251,7 @@ struct OpalxDb {
         return copyStream && copyStream2 ? copyStream : nullptr;
     }
     void* aux() {
-        if (!auxStream) auxStream = opal_hip_stream_create();
+        if (!auxStream) auxStream = opal_host::opts().auxHighPrio ? opal_hip_stream_create_high() : opal_hip_stream_create();
         return auxStream;
     }
     void* swap() {

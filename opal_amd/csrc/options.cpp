@@ -120,6 +120,7 @@ const std::vector<Desc>& table() {
         {"OPAL_HIP_SLICE_STREAMS", [](Options& o, const char* v) {
              if (!strcmp(v, "serial")) o.sliceStreams = 0; else if (!strcmp(v, "alternate")) o.sliceStreams = 1; else if (!strcmp(v, "separate")) o.sliceStreams = 2; else return false;
              return true; }, back(&Options::sliceStreams)},
+        flag("OPAL_HIP_AUX_HIGH_PRIO", &Options::auxHighPrio),
         flag("OPAL_HIP_NO_SIDE_PREFIX", &Options::noSidePrefix),
         one_of("OPAL_HIP_SIDE_STREAMS", &Options::sideStreams, {2, 3}),
         {"OPAL_HIP_SIDE_STREAM_PRIO", [](Options& o, const char* v) { long long x; if (!parse_ll(v, 0, 1, &x)) return false; o.sideStreamsNormalPrio = x == 0; return true; }, back(&Options::sideStreamsNormalPrio)},

@@ -12,6 +12,14 @@ qlen = int(os.environ.get("QLEN", "300"))
 res, offs, lens = synth.database(n, seed=42)
 q = synth.query(qlen, seed=7); m = np.ascontiguousarray(blosum50()[1], np.int32)
 L = _lib.lib()
+if os.environ.get("PRE"):  # a process that already holds a prepared database and has searched it (bench.py's situation): streams exist
+    import torch
+    from opal_amd.api import PreparedDb
+    _pdb = PreparedDb(res, offs)
+    _out = torch.zeros(3 * n, dtype=torch.int32, device="cuda")
+    for _mode in (3, 1):
+        for _ in range(int(os.environ["PRE"])):
+            _pdb.search_device(q, 11, 1, m, 1, _mode, _out.data_ptr(), _out[n:].data_ptr(), _out[2 * n:].data_ptr())
 ptrs = np.ascontiguousarray(res.ctypes.data + np.asarray(offs[:-1], dtype=np.uint64), dtype=np.uint64)
 ln = np.ascontiguousarray(lens, np.int32)
 arr = (OpalSearchResult * n)()
