@@ -40,6 +40,9 @@
 #define MODE_OV 2
 #define MODE_SW 3
 
+#ifndef OPAL_ABL
+#define OPAL_ABL 0  // (measurement only: 1 = no column store, 2 = no event at all, 3 = no end-cell code; results wrong)
+#endif
 #define FLAG_SWEND 1  // SW with end location: the lane also records where its running maximum was first reached
 #define FLAG_WRAP 2   // width 32 SW: detect 32-bit wrap of ulH + P (reference opal.cpp:302-303,339-351)
 #define FLAG_MULTI 4  // the query is processed in several row chunks; the boundary row travels through HBM
@@ -893,13 +896,13 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
                 // last column. Before: a row scan, 2 instructions per row, for every improvement of any lane's own maximum
                 // -- with cheap gaps (scores grow along the whole sequence) in every step.
                 const unsigned cv = (unsigned)cm & 0xffffu;  // (SW values are >= 0)
-                const bool cand = (int)cv > bestV || ((int)cv == bestV && c < bestC);
-                if (__builtin_amdgcn_ballot_w64(cand)) {
+                const bool cand = OPAL_ABL >= 3 ? false : ((int)cv > bestV || ((int)cv == bestV && c < bestC));
+                if (__builtin_amdgcn_ballot_w64(cand) && (OPAL_ABL < 2 || p.satLimit < 0)) {
                     const unsigned key = slot_max_u32(cand ? ((cv << 6) | (unsigned)k) + 1u : 0u, log2G);
                     if (key) {  // (the same in every lane of a slot)
                         const unsigned kw = (key - 1u) & 63u;
                         bestV = (int)((key - 1u) >> 6); bestC = s - (int)kw;
-                        if ((unsigned)k == kw) {
+                        if ((unsigned)k == kw && (OPAL_ABL < 1 || p.satLimit < 0)) {
                             // (two rows per word, four words per store: the LDS pipe is paid per instruction, whatever the
                             // number of lanes writing -- 20 two-word stores of unpacked rows per change made LDS the bound)
                             typedef unsigned ckpt_vec4 __attribute__((ext_vector_type(4)));

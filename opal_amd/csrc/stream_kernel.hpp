@@ -384,21 +384,21 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
             // can be the first cell holding the final score, and it is worth a row scan only if it also reaches the
             // maximum the lanes ABOVE me had reached when they finished this very column (a lower bound of the final
             // score that belongs to this sequence by construction: it travels down the lanes with the column).
-            reg pmIn = (reg)shr1((unsigned)pmOut);
+            reg pmIn = OPAL_ABL >= 3 ? V::splat(-1) : (reg)shr1((unsigned)pmOut);
             pmIn = (k == 0) ? V::splat(-1) : pmIn;
             // ... and (minus one: ties with it may still be mine) the maximum ALL lanes of my sequence had reached a few steps
             // ago: one LDS atomic per 8 steps on the sequence's descriptor (word 7), which also covers the lanes below me.
             // Both bounds are kept MINUS ONE: a value equal to them may still be the first cell of the final score, and a
             // lane that skipped a scan must end below the final score (its end cell is stale). Everything stays in 16-bit
             // values and full-rate instructions: max, max, compare.
-            if ((s & 7) == 0) {
+            if ((s & 7) == 0 && (OPAL_ABL < 2 || p.satLimit < 0)) {
                 const int mv = V::half(mx, 0);
                 const int old = atomicMax(ring + (flushCount & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4) + 7, mv);
                 seqM1 = V::splat((old > mv ? old : mv) - 1);
             }
             const reg cm = V::maxs(cq[0], cq[1]);
             const reg bar = V::maxs(V::maxs(mx, seqM1), pmIn);
-            if ((short)cm > (short)bar) {
+            if ((short)cm > (short)bar && (OPAL_ABL < 1 || p.satLimit < 0)) {
                 // the first half whose maximum is the column's, then the smallest row in it
                 const int qsel = V::same(cq[0], cm, 0) ? 0 : 1;
                 int r = 0;

@@ -446,6 +446,27 @@ def test_two_rank_bench_on_one_gpu():
     assert one["verify"]["score_crc32"] == two["verify"]["score_crc32"]
 
 
+def test_eight_rank_bench_on_one_gpu():
+    """The shape of the driver's 8-GPU run, rehearsed on the one GPU there is: `--gpus 8` starts eight ranks (all on GPU 0, gloo
+    instead of RCCL, which refuses several ranks on one device), each takes its deal of the C4 workload (P18080, a 1 M-sequence
+    cut of the 5 M database here), the gathered and re-ordered scores equal the one-rank run's, and the line carries what an N = 8
+    line must: eight kernel times, the deal's imbalance, the exchange. With end locations too (three gathered vectors)."""
+    common = ["--workload", "c4", "--total-seqs", "1000000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e"]
+    one = _run_bench(["--gpus", "1"] + common)
+    eight = _run_bench(["--gpus", "8"] + common, {"BENCH_SHARE_GPU": "1", "BENCH_BACKEND": "gloo"})
+    assert one["verified"] and eight["verified"] and eight["n_gpus"] == 8 and eight["scaling"] == "strong"
+    assert one["verify"]["score_crc32"] == eight["verify"]["score_crc32"]
+    r = eight["ranks"]
+    assert len(r["kernel_ms"]["per_rank"]) == 8 and min(r["kernel_ms"]["per_rank"]) > 0
+    assert 1.0 <= r["imbalance"] < 1.02 and r["exchange_ms"] > 0
+    assert eight["config"]["cells_per_step"] == one["config"]["cells_per_step"]
+    end = ["--workload", "c3", "--mode", "OV", "--total-seqs", "200000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e"]
+    one = _run_bench(["--gpus", "1"] + end)
+    eight = _run_bench(["--gpus", "8"] + end, {"BENCH_SHARE_GPU": "1", "BENCH_BACKEND": "gloo"})
+    assert one["verified"] and eight["verified"]
+    assert one["verify"] == eight["verify"] or one["verify"]["score_crc32"] == eight["verify"]["score_crc32"]
+
+
 def test_bench_rccl_branch_with_one_rank():
     """The RCCL side of bench.py on a one-GPU box (RCCL refuses two ranks on one GPU, so the two-rank test above runs on
     gloo): BENCH_FORCE_DIST=1 sends ONE rank through everything N ranks go through -- `nccl` process group bound to the
