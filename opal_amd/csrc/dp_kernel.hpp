@@ -419,7 +419,21 @@ template <typename V, int S, int J> struct OvColumnRow {
 };
 
 // Words of a slot's column buffer (CKPT): two rows per word, then the lane number, padded to whole 16-byte stores.
-__host__ __device__ constexpr int opal_swend_ckpt_words(int S) { return ((S + 1) / 2 + 1 + 3) / 4 * 4; }
+// SW with end locations, slot-exact (CKPT): a lane's rows fall into up to four GROUPS of 4-row blocks, each with a column-maximum
+// accumulator of its own (which accumulator a row block feeds costs nothing, and the group's first block starts it: ROWS_SWI).
+// When a lane holds its slot's new best cell it leaves the rows of ONE group -- the first that holds the column maximum -- in
+// the slot's LDS buffer: one word per row as the registers hold them, then {lane, first row of the group}.
+__host__ __device__ constexpr int opal_swend_groups(int S) { return S > 38 ? 1 : (S > 36 ? 2 : ((S + 3) / 4 < 4 ? (S + 3) / 4 : 4)); }  // (the tallest shapes have no registers for four accumulators)
+__host__ __device__ constexpr int opal_swend_group_of_block(int S, int b) { return b * opal_swend_groups(S) / ((S + 3) / 4); }
+__host__ __device__ constexpr int opal_swend_group_first_block(int S, int g) {  // (g == groups: one past the last block)
+    int b = 0;
+    while (b < (S + 3) / 4 && opal_swend_group_of_block(S, b) < g) b++;
+    return b;
+}
+__host__ __device__ constexpr int opal_swend_group_rows_max(int S) {
+    return 4 * (((S + 3) / 4 + opal_swend_groups(S) - 1) / opal_swend_groups(S));
+}
+__host__ __device__ constexpr int opal_swend_ckpt_words(int S) { return (opal_swend_group_rows_max(S) + 2 + 3) / 4 * 4; }
 
 // Maximum of an unsigned value over the 2^log2G lanes of a slot, left in every lane of it (all lanes of the wave active).
 // Lanes 1, 2, 4, 8 apart through DPP (quad permutes, then the two mirrors: once the quads agree, mirroring eight lanes
@@ -436,14 +450,75 @@ __device__ __forceinline__ unsigned slot_max_u32(unsigned x, const int log2G) {
                 if (log2G >= 4) {
                     asm("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(x));
                     if (log2G >= 5) {
-                        { const unsigned o = (unsigned)__shfl_xor((int)x, 16, 64); x = o > x ? o : x; }
-                        if (log2G >= 6) { const unsigned o = (unsigned)__shfl_xor((int)x, 32, 64); x = o > x ? o : x; }
+                        // every lane of a 16-lane row holds its row's maximum now; across rows through SGPRs (four v_readlane and
+                        // scalar maxima: no LDS round trip -- two ds_bpermute cost a 64-lane slot ~250 clocks of latency per settlement)
+                        const unsigned r0 = __builtin_amdgcn_readlane(x, 0), r1 = __builtin_amdgcn_readlane(x, 16);
+                        const unsigned r2 = __builtin_amdgcn_readlane(x, 32), r3 = __builtin_amdgcn_readlane(x, 48);
+                        const unsigned lo = r0 > r1 ? r0 : r1, hi = r2 > r3 ? r2 : r3;
+                        if (log2G >= 6) x = lo > hi ? lo : hi;
+                        else x = (__lane_id() & 32u) ? hi : lo;
                     }
                 }
             }
         }
     }
     return x;
+}
+
+// The winner's store (see opal_swend_groups): ds_write2_b32, two rows per store from whatever registers hold them (a 16-byte
+// store wants four consecutive registers, i.e. one v_mov per row; packing two rows per word cost a half-rate v_perm per pair).
+// Inline asm with a different text per group: identical stores in several branches would be sunk behind them, with a register
+// copy per row to feed them. The LDS pipe is paid per instruction whatever the number of lanes writing, so the fewer rows the
+// better: a quarter of the column, not all of it (round 4) or half of it.
+template <class V, int S, int GRP>
+__device__ __forceinline__ void swend_put_group(const unsigned ca, const typename V::reg* Hp, const int k) {
+    constexpr int first = 4 * opal_swend_group_first_block(S, GRP);
+    constexpr int end = 4 * opal_swend_group_first_block(S, GRP + 1) < S ? 4 * opal_swend_group_first_block(S, GRP + 1) : S;
+    constexpr int rows = end - first, RM = opal_swend_group_rows_max(S);
+    static_assert(rows >= 1 && rows <= RM, "group geometry");
+#define OPAL_PUT2(a, b, o0, o1)                                                                                                       \
+    do {                                                                                                                            \
+        if constexpr (GRP == 0) asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4 ; group 0" :: "v"(ca), "v"(a), "v"(b), "n"(o0), "n"(o1) : "memory"); \
+        else if constexpr (GRP == 1) asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4 ; group 1" :: "v"(ca), "v"(a), "v"(b), "n"(o0), "n"(o1) : "memory"); \
+        else if constexpr (GRP == 2) asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4 ; group 2" :: "v"(ca), "v"(a), "v"(b), "n"(o0), "n"(o1) : "memory"); \
+        else asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4 ; group 3" :: "v"(ca), "v"(a), "v"(b), "n"(o0), "n"(o1) : "memory"); \
+    } while (0)
+    static_for<rows / 2>([&](auto jc) {
+        constexpr int j = 2 * decltype(jc)::value;
+        OPAL_PUT2(Hp[first + j], Hp[first + j + 1], j, j + 1);
+    });
+    const unsigned kk = (unsigned)k, ff = (unsigned)first;
+    if constexpr (rows & 1) {  // the odd row shares its store with the lane number
+        OPAL_PUT2(Hp[first + rows - 1], ff, rows - 1, RM + 1);
+        asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(ca), "v"(kk), "n"(4 * RM) : "memory");
+    } else {
+        OPAL_PUT2(kk, ff, RM, RM + 1);
+    }
+#undef OPAL_PUT2
+}
+template <class V, int S>
+__device__ __forceinline__ void swend_keep_column(const unsigned ca, const typename V::reg* Hp, const typename V::reg* aq, const typename V::reg cm, const int k) {
+    constexpr int NQ = opal_swend_groups(S);
+    if (NQ == 1 || V::same(aq[0], cm, 0)) swend_put_group<V, S, 0>(ca, Hp, k);
+    else if (NQ == 2 || V::same(aq[NQ > 1 ? 1 : 0], cm, 0)) swend_put_group<V, S, (NQ > 1 ? 1 : 0)>(ca, Hp, k);
+    else if (NQ == 3 || V::same(aq[NQ > 2 ? 2 : 0], cm, 0)) swend_put_group<V, S, (NQ > 2 ? 2 : 0)>(ca, Hp, k);
+    else swend_put_group<V, S, (NQ > 3 ? 3 : 0)>(ca, Hp, k);
+}
+// ... and the look-up, once per sequence: the smallest row of the kept group that holds the score (a stale word behind a shorter
+// group's rows cannot win: the group's own maximum sits below it), and the lane that kept it
+template <int S>
+__device__ __forceinline__ int swend_kept_row(const unsigned ca, const int sc, int& lane) {
+    typedef __attribute__((address_space(3))) unsigned ckpt_word;
+    constexpr int RM = opal_swend_group_rows_max(S);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the rows were stored by inline asm)
+    const ckpt_word* ck = (const ckpt_word*)(uintptr_t)ca;
+    const int first = (int)ck[RM + 1];
+    lane = (int)ck[RM];
+    int r = 0;
+#pragma unroll
+    for (int j = RM - 1; j >= 0; j--)
+        if (first + j < S && (ck[j] & 0xffffu) == (unsigned)sc) r = first + j;
+    return r;
 }
 
 // ------------------------------------------------------------------ the DP kernel
@@ -625,18 +700,27 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
     };
     const int r0 = q0 + k * S - padTop;  // query row held in register 0 (negative: virtual rows)
     reg Hp[S], En[S];               // H[r][c-1] and E[r][c] for my rows
+    // (NW, HW: the boundary value runs down the rows, one 64-bit value alive -- computed per row from scratch, the compiler
+    // interleaved the 64-bit clamps of all rows: 128 registers and two to four spills in this prologue at 28-30 rows)
+    long long hbRun = -(long long)Go - (long long)r0 * Ge;
 #pragma unroll
-    for (int j = 0; j < S; j++) {
+    for (int j = 0; j < S; j++, hbRun -= Ge) {
         if (MODE == MODE_SW) { Hp[j] = 0; En[j] = 0; }
         else if (MODE == MODE_OV || r0 + j < 0) { Hp[j] = 0; En[j] = V::splat(V::clampv(-(long long)Go)); }
         else {  // NW, HW: H[r][-1] = -Go - r*Ge (opal.cpp:671-679), E[r][0] = H[r][-1] - Go
-            const long long hb = -(long long)Go - (long long)(r0 + j) * Ge;
+            const long long hb = hbRun;
             Hp[j] = V::splat(V::clampv(hb));
             En[j] = V::splat(V::clampv(hb - Go));
         }
         if (SKEW) {  // my first column runs at step k: H(j) is read as the diagonal of step k, E(j) at step k
             Hp[j] = V::adds(Hp[j], V::splat((j + k - 1) * Ge + kf));
             En[j] = V::adds(En[j], V::splat((j + k) * Ge + kf));
+        }
+        if constexpr ((MODE == MODE_NW || MODE == MODE_HW) && PLAIN) {
+            // (row j finished before row j+1's boundary value exists: otherwise all S 64-bit clamps are in flight at once)
+            unsigned lo = (unsigned)hbRun, hi = (unsigned)((unsigned long long)hbRun >> 32);
+            asm volatile("" : "+v"(lo), "+v"(hi), "+v"(Hp[j]), "+v"(En[j]));
+            hbRun = (long long)(((unsigned long long)hi << 32) | lo);
         }
     }
     // what the lane below reads: H and next-row F of my last row. Before my first column it must be
@@ -792,6 +876,8 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
             // costs nothing), so that a row scan only visits the first half that holds the column maximum
             constexpr int NBLK4H = (S + 3) / 4;
             reg ch[2] = {0, 0};
+            constexpr int NQ = opal_swend_groups(S);
+            reg aq[NQ];  // CKPT: the column maximum per group of row blocks (opal_swend_groups)
             if constexpr (PLAIN) {
                 // Plain 16-bit path: one asm statement per block of 4 rows (one ds_read_b128 of profile entries), the
                 // profile read of the next block issued before the current block's arithmetic. Inside a block the
@@ -822,15 +908,22 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
                             constexpr int n = (S - j0) < 4 ? (S - j0) : 4;
                             constexpr bool last = j0 + n == S;
                             const reg* Pn = &Pv[j0 - rb * RB + 1];  // profile of the row BELOW each row
-                            reg& acc = CKPT ? cm : (SWEND ? ch[(j0 / 4) * 2 / NBLK4H] : mx);
-                            V::template rows<KIND, n, last>(&Hp[j0], &En[j0], Pn, f, acc, d, t, SKEW ? GQs : Qs, Rs);
+                            constexpr int grp = opal_swend_group_of_block(S, j0 / 4);
+                            constexpr bool starts = CKPT && j0 / 4 == opal_swend_group_first_block(S, grp);
+                            reg& acc = CKPT ? aq[grp] : (SWEND ? ch[(j0 / 4) * 2 / NBLK4H] : mx);
+                            V::template rows<starts ? ROWS_SWI : KIND, n, last>(&Hp[j0], &En[j0], Pn, f, acc, d, t, SKEW ? GQs : Qs, Rs);
                         }
                     });
                     pc = pn;
                 });
                 if constexpr (LATE) pfirst = pc;
                 h = Hp[S - 1];
-                if constexpr (SWEND && !CKPT) cm = V::maxs(ch[0], ch[1]);
+                if constexpr (CKPT) {
+                    cm = aq[0];
+                    if constexpr (NQ == 2) cm = V::maxs(aq[0], aq[1]);
+                    if constexpr (NQ == 3) cm = V::maxs(V::maxs(aq[0], aq[1]), aq[2]);
+                    if constexpr (NQ == 4) cm = V::maxs(V::maxs(aq[0], aq[1]), V::maxs(aq[2], aq[NQ - 1]));
+                } else if constexpr (SWEND) cm = V::maxs(ch[0], ch[1]);
             } else {
 #pragma unroll
             for (int rb = 0; rb < SPAD / RB; rb++) {
@@ -903,21 +996,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
                         const unsigned kw = (key - 1u) & 63u;
                         bestV = (int)((key - 1u) >> 6); bestC = s - (int)kw;
                         if ((unsigned)k == kw && (OPAL_ABL < 1 || p.satLimit < 0)) {
-                            // (two rows per word, four words per store: the LDS pipe is paid per instruction, whatever the
-                            // number of lanes writing -- 20 two-word stores of unpacked rows per change made LDS the bound)
-                            typedef unsigned ckpt_vec4 __attribute__((ext_vector_type(4)));
-                            typedef __attribute__((address_space(3))) ckpt_vec4 ckpt_quad;
-                            constexpr int NW = (S + 1) / 2;  // packed words
-                            unsigned pk[(NW + 3) / 4 * 4];
-#pragma unroll
-                            for (int w = 0; w < (NW + 3) / 4 * 4; w++)
-                                pk[w] = w < NW ? __builtin_amdgcn_perm(2 * w + 1 < S ? Hp[2 * w + 1] : 0u, Hp[2 * w], 0x05040100u) : (unsigned)k;
-#pragma unroll
-                            for (int w = 0; w < (NW + 3) / 4 * 4; w += 4) {
-                                ckpt_vec4 q4; q4.x = pk[w]; q4.y = pk[w + 1]; q4.z = pk[w + 2]; q4.w = pk[w + 3];
-                                *(ckpt_quad*)(ckpt + w) = q4;
-                            }
-                            if constexpr (NW % 4 == 0) ckpt[NW] = (unsigned)k;  // (otherwise the lane number sits in the padding words)
+                            swend_keep_column<V, S>((unsigned)(uintptr_t)(opal_lds_u8*)ckpt, Hp, aq, cm, k);
                         }
                     }
                 }
@@ -1097,11 +1176,9 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
             int sc = V::half(mx, hh), col = endCol[hh], row = endRow[hh], src = k;
             if constexpr (CKPT) {  // the slot's best cell is known in every lane; its row: the smallest one of the kept column holding the score
                 sc = bestV; col = bestV > 0 ? bestC : INT_MAX;
-                int r = 0;
-#pragma unroll
-                for (int j = S - 1; j >= 0; j--)
-                    if (((ckpt[j / 2] >> (16 * (j & 1))) & 0xffffu) == (unsigned)sc) r = j;
-                row = q0 + (int)ckpt[(S + 1) / 2] * S - padTop + r;
+                int kw = 0;
+                const int r = swend_kept_row<S>((unsigned)(uintptr_t)(opal_lds_u8*)ckpt, sc, kw);
+                row = q0 + kw * S - padTop + r;
             } else
             for (int d = 1; d < G; d <<= 1) {
                 const int osc = __shfl_xor(sc, d, 64);
@@ -1207,7 +1284,9 @@ typedef void (*UberFn)(const UberParams);
 template <int MODE, int FLAGS, int S0>
 __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64, 4) opal_dp_uber(const UberParams u) {
     const int b = (int)blockIdx.x;
-    if (b >= u.firstBlock[2]) opal_dp_body<17, MODE, FLAGS, S0>(u.base, u.cls[2], b - u.firstBlock[2]);
+    // (SW with end locations at 40 rows: the slot-exact end cell is two registers over inside this three-body kernel; row scans there)
+    constexpr int FLAGS0 = (S0 >= 40 && MODE == MODE_SW && (FLAGS & FLAG_SWEND)) ? (FLAGS | FLAG_NOCKPT) : FLAGS;
+    if (b >= u.firstBlock[2]) opal_dp_body<17, MODE, FLAGS0, S0>(u.base, u.cls[2], b - u.firstBlock[2]);
     else if (b >= u.firstBlock[1]) opal_dp_body<17, MODE, FLAGS, (S0 + 1) / 2>(u.base, u.cls[1], b - u.firstBlock[1]);
     else opal_dp_body<17, MODE, FLAGS, (S0 + 3) / 4>(u.base, u.cls[0], b - u.firstBlock[0]);
 }

@@ -5,6 +5,7 @@
 // (shapes that do not fit 128 registers are left out -- `make check-scratch`; the scheduler takes the next larger rows value
 // or another geometry)
 template <int MODE, int ROWS> struct GlFn { static constexpr StreamFn fn = opal_gl_stream<17, MODE, ROWS, true>; };
+template <> struct GlFn<MODE_OV, 38> { static constexpr StreamFn fn = nullptr; };
 template <> struct GlFn<MODE_OV, 39> { static constexpr StreamFn fn = nullptr; };
 template <> struct GlFn<MODE_OV, 40> { static constexpr StreamFn fn = nullptr; };
 

@@ -351,7 +351,7 @@ StreamPlan plan_stream(int Q, int A, int mode, int wantEnd, long long residues, 
             if (need > OPAL_HIP_MAX_ROWS) continue;
             const int rows = opal_hip_stream_rows_supported(width, mode, wantEnd, need);
             if (!rows || opal_hip_stream_lds_bytes(width, mode, G, rows, A) > 160 * 1024) continue;
-            const double perRow = (mode == OPAL_MODE_SW ? 9.0 + (wantEnd ? 1.5 : 0.0) : 6.0) + (width == 18 ? 0.5 : 0.0);
+            const double perRow = (mode == OPAL_MODE_SW ? 9.0 + (wantEnd ? 0.6 : 0.0) : 6.0) + (width == 18 ? 0.5 : 0.0);
             const double cost = (perRow * rows + 30.0) * G / Q;
             if (cost < bestCost) { bestCost = cost; best.width = width; best.G = G; best.rows = rows; }
         }
@@ -391,7 +391,7 @@ StreamPlan plan_stream(int Q, int A, int mode, int wantEnd, long long residues, 
             return best;
         }
     }
-    if (best.G && !force && (wantEnd || mode != OPAL_MODE_SW) && best.G < 32) best = StreamPlan();  // (end locations, NW/HW/OV at 16 lanes or fewer: class kernels, unmeasured otherwise)
+    if (best.G && !force && mode != OPAL_MODE_SW && best.G < 32) best = StreamPlan();  // (NW/HW/OV at 16 lanes or fewer: class kernels, unmeasured otherwise)
     if (best.G && !force && best.passes == 1) {
         // A sequence stays on its G lanes from its first column to its last: the longest one (handed out first) sets a
         // floor of (longest + G) steps at the rate of a wave that ends up alone on its SIMD (~3.5 clk per instruction).

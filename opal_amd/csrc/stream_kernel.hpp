@@ -62,7 +62,8 @@ __host__ __device__ inline int opal_stream_stride(int G, int S) {
 }
 template <int WIDTH>
 __host__ __device__ inline size_t opal_stream_lds_bytes(int G, int S, int A) {
-    return (size_t)(A + 3) * (size_t)opal_stream_stride<WIDTH>(G, S) + (size_t)STREAM_WAVES * (64 / G) * STREAM_RING * STREAM_DESC_BYTES + 48;  // (+48: probe slot)
+    return (size_t)(A + 3) * (size_t)opal_stream_stride<WIDTH>(G, S) + (size_t)STREAM_WAVES * (64 / G) * STREAM_RING * STREAM_DESC_BYTES + 48  // (+48: probe slot)
+           + (size_t)STREAM_WAVES * (64 / G) * 2 * opal_swend_ckpt_words(S) * 4;  // end locations: the kept half column of a slot's two sequences in flight
 }
 
 
@@ -247,13 +248,17 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
 
     SlotStream st;  // the stream of this slot
     int flushCount = 0;        // entries this lane has seen the end of (the last lane: whose score has been written)
-    // SWEND: where my running maximum was first reached (column within the sequence, query row), the stream position at
-    // which my current sequence starts, and what the lane below reads: the maximum over the lanes above and me for the
-    // column I just finished (scan filter), and at the second separator the best cell so far (score, column, row)
-    int endCol = INT_MAX, endRow = -1, myStart = 0;
-    reg pmOut = V::splat(-1), seqM1 = V::splat(-1);
-    int outCol = INT_MAX, outRow = -1;
-    const int r0 = q0 + k * S - padTop;  // query row held in register 0
+    // SWEND: the best cell of my sequence so far over ALL lanes of the slot, exactly (dp_kernel.hpp, CKPT): its score and the
+    // step at which I am (was, would be) on its column -- and the same for the sequence behind mine in the stream, which the
+    // lanes above me have entered already (a slot has at most two sequences in flight: an entry spans at least 2G positions).
+    // The column that holds the best cell waits in LDS, one buffer per sequence in flight (by the parity of its number).
+    int curV = 0, curS = INT_MIN, nxtV = 0, nxtS = INT_MIN;  // (INT_MIN: a tie at score 0 replaces nothing)
+    // The two sequences a slot may have in flight settle separately, GROUPED by the parity of (sequences finished by the lane -
+    // those lane 0 of the slot had finished at the last refill): in the middle of a sequence every lane of every slot is in group
+    // 0 and one all-reduce serves the wave (by the parity alone, four slots would need both groups almost every time).
+    int refCount = 0;
+    constexpr int CKW = opal_swend_ckpt_words(S);
+    auto ckpt_base = [&]() { return (unsigned)(uintptr_t)(opal_lds_u8*)(clkSlot + 48) + (unsigned)((wave * slots + slot) * 2 * CKW * 4); };  // (made when needed: no register across the loop)
 
     auto fetch = [&](const int x) { stream_fetch<2, CHUNK>(st, p, sp.next, ring, x, k, G, slotLane0, PAD, sp.prioItems); };
     fetch(k);
@@ -267,7 +272,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     // read inside the last row block of the current step -- behind the batch refill when the next step starts a batch --, so
     // a step no longer begins by waiting out an LDS round trip (dp_kernel.hpp, PF_LATE: the registers that carry the three
     // reads are live across the step's tail only).
-    constexpr bool LATE = !CHUNK && !(SIDE && SWEND) && S <= (SWEND ? 34 : 38) && OPAL_STREAM_PF_LATE != 0;  // (the tallest shapes are two registers short)
+    constexpr bool LATE = !CHUNK && S <= (SWEND ? 33 : (SIDE ? 37 : 38)) && OPAL_STREAM_PF_LATE != 0;  // (the tallest shapes are two registers short)
     bool finished = false;
     int4 infoNext = make_int4(0, 0, 0, 0), pfirst = make_int4(0, 0, 0, 0);
     // start of a batch of G steps (wave-uniform): refill the queue with columns s .. s+G-1, fetch those of the next batch
@@ -293,6 +298,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
                 }
             }
             fetch(s + G + k);
+            if constexpr (SWEND) refCount = __shfl(flushCount, slotLane0, 64);
             tokq = ldsBase + letter * (unsigned)stride;
             bndq = above;
             // every slot has run dry and its last separator has left the last lane (CHUNK: the store above covered the positions
@@ -336,11 +342,8 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
         const reg Qv = (reg)info.x, Rv = (reg)info.y;
 
         reg f = inF;
-        // SWEND: this column's maximum over my rows, kept per HALF of the rows during the row blocks (which accumulator a
-        // row block uses costs nothing), so that a row scan only visits the first half that holds the column maximum
-        constexpr int NBLK4Q = (S + 3) / 4;
-        constexpr int NQ = 2;  // (halves measured better than quarters: fewer accumulators to combine)
-        reg cq[NQ] = {0, 0};
+        constexpr int NQ = opal_swend_groups(S);
+        reg aq[NQ];  // SWEND: the column maximum per group of row blocks (dp_kernel.hpp, opal_swend_groups), each started by its first block
         {
             constexpr int NBLK = SPAD / RB;
             int4 pc = LATE ? pfirst : lds_ld16(offv);
@@ -368,7 +371,9 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
                     if constexpr (j0 < S) {
                         constexpr int n = (S - j0) < 4 ? (S - j0) : 4;
                         constexpr bool last = j0 + n == S;
-                        V::template rows<ROWS_SWV, n, last>(&Hp[j0], &En[j0], &Pv[j0 - rb * RB + 1], f, SWEND ? cq[(j0 / 4) * NQ / NBLK4Q] : mx, d, t, Qv, Rv);
+                        constexpr int grp = opal_swend_group_of_block(S, j0 / 4);
+                        constexpr bool starts = SWEND && j0 / 4 == opal_swend_group_first_block(S, grp);
+                        V::template rows<starts ? ROWS_SWVI : ROWS_SWV, n, last>(&Hp[j0], &En[j0], &Pv[j0 - rb * RB + 1], f, SWEND ? aq[grp] : mx, d, t, Qv, Rv);
                     }
                 });
                 pc = pn;
@@ -380,76 +385,73 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
         diagIn = inH;
 
         if constexpr (SWEND) {
-            // End location in the same pass, as in the class kernels: only a STRICT improvement of my running maximum
-            // can be the first cell holding the final score, and it is worth a row scan only if it also reaches the
-            // maximum the lanes ABOVE me had reached when they finished this very column (a lower bound of the final
-            // score that belongs to this sequence by construction: it travels down the lanes with the column).
-            reg pmIn = OPAL_ABL >= 3 ? V::splat(-1) : (reg)shr1((unsigned)pmOut);
-            pmIn = (k == 0) ? V::splat(-1) : pmIn;
-            // ... and (minus one: ties with it may still be mine) the maximum ALL lanes of my sequence had reached a few steps
-            // ago: one LDS atomic per 8 steps on the sequence's descriptor (word 7), which also covers the lanes below me.
-            // Both bounds are kept MINUS ONE: a value equal to them may still be the first cell of the final score, and a
-            // lane that skipped a scan must end below the final score (its end cell is stale). Everything stays in 16-bit
-            // values and full-rate instructions: max, max, compare.
-            if ((s & 7) == 0 && (OPAL_ABL < 2 || p.satLimit < 0)) {
-                const int mv = V::half(mx, 0);
-                const int old = atomicMax(ring + (flushCount & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4) + 7, mv);
-                seqM1 = V::splat((old > mv ? old : mv) - 1);
-            }
-            const reg cm = V::maxs(cq[0], cq[1]);
-            const reg bar = V::maxs(V::maxs(mx, seqM1), pmIn);
-            if ((short)cm > (short)bar && (OPAL_ABL < 1 || p.satLimit < 0)) {
-                // the first half whose maximum is the column's, then the smallest row in it
-                const int qsel = V::same(cq[0], cm, 0) ? 0 : 1;
-                int r = 0;
-                static_for<NQ>([&](auto qc) {
-                    constexpr int qi = decltype(qc)::value;
-                    if (qsel == qi) {
-                        static_for<NBLK4Q>([&](auto bc) {  // highest block first: the smallest row holding it wins
-                            constexpr int b = NBLK4Q - 1 - decltype(bc)::value;
-                            if constexpr (b * NQ / NBLK4Q == qi) {
-                                constexpr int n = (S - 4 * b) < 4 ? (S - 4 * b) : 4;
-                                V::template scan_rows<n, 4 * b>(&Hp[4 * b], cm, r);
+            // End location in the same pass, exactly and per SLOT, as in the single-launch class kernels (dp_kernel.hpp, CKPT): a
+            // lane's column maximum matters only if it beats the best cell of its sequence so far -- a higher value, or the same
+            // value in a smaller column. Only when some lane of the WAVE has such a column do the slots settle who holds their
+            // best (one all-reduce of (value, lane) keys per sequence in flight); the winner leaves the group of its rows that
+            // holds the maximum in LDS, where the last lane looks the row up when the sequence has passed it. Lanes of the
+            // winner's sequence take the new best as theirs, lanes still on the sequence before it as their next one's.
+            // (Before: per-lane row scans filtered by two running bounds, one LDS atomic per 8 steps; 14 % over the score-only
+            // stream at a 2000-aa query, 26 % with cheap gaps.)
+            reg cm = aq[0];
+            if constexpr (NQ == 2) cm = V::maxs(aq[0], aq[1]);
+            if constexpr (NQ == 3) cm = V::maxs(V::maxs(aq[0], aq[1]), aq[2]);
+            if constexpr (NQ == 4) cm = V::maxs(V::maxs(aq[0], aq[1]), V::maxs(aq[2], aq[NQ - 1]));
+            const int cv = (int)((unsigned)cm & 0xffffu);  // (SW values are >= 0)
+            const bool cand = OPAL_ABL >= 3 ? false : (cv > curV || (cv == curV && s < curS));
+            if (__ballot(cand) != 0ull && (OPAL_ABL < 2 || p.satLimit < 0)) {
+                const int par = flushCount & 1, grp = (flushCount - refCount) & 1;
+                static_for<2>([&](auto pgc) {
+                    constexpr int pg = decltype(pgc)::value;
+                    const bool mine = cand && grp == pg;
+                    if (__ballot(mine) != 0ull) {
+                        const unsigned key = slot_max_u32(mine ? ((unsigned)(cv << 6) | (unsigned)k) + 1u : 0u, log2G);
+                        if (key) {  // (the same in every lane of a slot)
+                            const int kw = (int)((key - 1u) & 63u);
+                            const int v = (int)((key - 1u) >> 6), at = s - kw + k;
+                            if (grp == pg) {
+                                curV = v; curS = at;
+                                if (k == kw && (OPAL_ABL < 1 || p.satLimit < 0))
+                                    swend_keep_column<V, S>(ckpt_base() + (unsigned)(par * CKW * 4), Hp, aq, cm, k);
+                            } else if (kw < k) {  // (a winner BELOW me is on the sequence I have left)
+                                nxtV = v; nxtS = at;
                             }
-                        });
+                        }
                     }
                 });
-                endRow = r0 + r;
-                endCol = s - k - myStart;
             }
-            mx = V::maxs(mx, cm);
-            pmOut = V::maxs(pmIn, V::subs(mx, V::splat(1)));
         }
 
         // ---- second separator column: hand the slot's maximum down the lanes, the last lane writes it
+        // (SWEND: nothing to hand down -- every lane knows its sequence's best cell; the last lane looks its row up)
         if (__ballot(info.z != 0) != 0ull) {
-            int inM = (int)shr1((unsigned)outM);
-            inM = (k == 0) ? 0 : inM;
-            int inCol = INT_MAX, inRow = -1;
+            int inM = 0;
+            if constexpr (!SWEND) {
+                inM = (int)shr1((unsigned)outM);
+                inM = (k == 0) ? 0 : inM;
+            }
+            int outCol = INT_MAX, outRow = -1;
             if constexpr (SWEND) {
-                inCol = (int)shr1((unsigned)outCol);
-                inRow = (int)shr1((unsigned)outRow);
-                if (k == 0) { inCol = INT_MAX; inRow = -1; }
+                if (__ballot(info.z != 0 && k == G - 1) != 0ull) {  // (wave-uniform: once per sequence and slot)
+                    if (info.z != 0 && k == G - 1 && curV > 0) {
+                        int kw = 0;
+                        const int r = swend_kept_row<S>(ckpt_base() + (unsigned)((flushCount & 1) * CKW * 4), curV, kw);
+                        outRow = q0 + kw * S - padTop + r;
+                    }
+                }
             }
             if (info.z != 0) {
-                const int mine = V::half(mx, 0);
+                const int* d = ring + (flushCount & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4);
                 if constexpr (SWEND) {
-                    // best cell: highest score, then smallest column, then smallest row (= the lanes above me)
-                    const bool take = mine > inM || (mine == inM && endCol < inCol);
-                    outM = take ? mine : inM;
-                    outCol = take ? endCol : inCol;
-                    outRow = take ? endRow : inRow;
-                    endCol = INT_MAX; endRow = -1; seqM1 = V::splat(-1);
+                    outM = curV;
+                    if (k == G - 1 && curV > 0) outCol = (curS - k) - d[0];  // (the entry's first stream position)
+                    curV = nxtV; curS = nxtS; nxtV = 0; nxtS = INT_MIN;
+                    flushCount++;
                 } else {
+                    const int mine = V::half(mx, 0);
                     outM = mine > inM ? mine : inM;
                 }
                 mx = 0;
-                const int* d = ring + (flushCount & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4);
-                if constexpr (SWEND) {  // my next sequence starts where this entry's span ends
-                    const int4 d0 = *reinterpret_cast<const int4*>(d);
-                    myStart = d0.x + max(d0.y + 2, 2 * G);
-                    flushCount++;
-                }
                 if (k == G - 1) {
                     const int seq = d[2];
                     if constexpr (!SWEND) flushCount++;
@@ -472,7 +474,9 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
                                 const int at = atomicAdd(p.ovfCount, 1);
                                 p.ovfItems[at] = d[6];
                             }
-                            p.outScore[seq] = p.satLimit;
+                            int lim = p.satLimit;
+                            asm volatile("" : "+s"(lim));  // (made here: as a lane value kept across the column loop it was spilled)
+                            p.outScore[seq] = lim;
                         } else {
                             p.outScore[seq] = sc;
                             if constexpr (SWEND) {

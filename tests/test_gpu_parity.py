@@ -99,6 +99,40 @@ def test_sw_end_cells_with_ties_in_every_wave_geometry(lanes, ours, oracle, opal
         _check(got, want, "SW", f"ties G={lanes} gaps {go}/{ge}")
 
 
+@pytest.mark.parametrize("lanes,qlen,narrow", [(4, 97, "17"), (8, 200, "17"), (16, 300, "17"), (16, 520, "17"), (32, 513, "17"),
+                                               (64, 700, "17"), (64, 1300, "18"), (64, 1500, "18"), (64, 2300, "18")])
+def test_sw_end_cells_with_ties_in_the_streaming_kernels(lanes, qlen, narrow, ours, oracle, opal_opt):
+    """The same where sequences follow each other through a slot's lanes (stream_kernel.hpp): the slot's best cell is kept per
+    SEQUENCE IN FLIGHT -- the lanes above a separator already work on the next one, whose best the lanes below must learn before
+    they get there, and the two kept columns sit in two LDS buffers by the parity of the sequence number. Ties in every column,
+    sequences shorter than the lane pipeline (pad columns between entries), one workgroup so that every slot sees many."""
+    rng = np.random.RandomState(1000 + lanes)
+    A = 4
+    m = np.full((A, A), -1, np.int32)
+    np.fill_diagonal(m, 1)
+    q = rng.randint(0, 2, qlen).astype(np.uint8)
+    n = max(200, 4 * 16 * 64 // lanes)
+    db = [rng.randint(0, 2, int(L)).astype(np.uint8) for L in rng.randint(1, 2 * max(lanes, 100) + 40, n)]
+    db += [np.tile(q[:7], 60)[: 250 + 3 * i].copy() for i in range(6)]   # periodic: the same score over and over
+    db += [q.copy(), q[::-1].copy(), np.zeros(300, np.uint8), np.ones(2, np.uint8), np.ones(1, np.uint8)]
+    order = rng.permutation(len(db))
+    db = [db[i] for i in order]
+    opal_opt.set("OPAL_HIP_STREAM", "1")
+    opal_opt.set("OPAL_HIP_LANES_PER_SEQ", str(lanes))
+    opal_opt.set("OPAL_HIP_NARROW", narrow)
+    cnt = (C.c_longlong * 11)()
+    for blocks in ("1", "3"):
+        opal_opt.set("OPAL_HIP_STREAM_BLOCKS", blocks)
+        for go, ge in ((0, 0), (1, 0), (0, 1), (2, 1)):
+            ours.lib.opalx_counters(cnt, 11)
+            before = cnt[0]
+            got = ours.search(q, db, go, ge, m, 1, MODES["SW"])[:4]
+            ours.lib.opalx_counters(cnt, 11)
+            assert cnt[0] - before >= 1, "not on the streaming kernels"
+            want = oracle.search(q, db, go, ge, m, 1, MODES["SW"])
+            _check(got, want, "SW", f"stream ties G={lanes} Q={qlen} w{narrow} gaps {go}/{ge} blocks={blocks}")
+
+
 def test_api_rules(ours, oracle):
     q, db, m = cases.materialise(cases.CASES["readme_example"])
     # score-only search: end locations -1; alignment fields post-filled (opal.cpp:1508-1515)
