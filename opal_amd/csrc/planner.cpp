@@ -415,6 +415,13 @@ StreamPlan plan_stream(int Q, int A, int mode, int wantEnd, long long residues, 
             // slot works through many sequences; with ~3 per slot (300-aa x 100 000) it is 14 % slower.
             const double perSlot = (double)numSeqs / (4096.0 * (64 / best.G));
             if (crit > 0.5 * total || perSlot < 20.0) best = StreamPlan();  // (300-aa query: break-even at ~18 sequences per slot, 600 000 sequences)
+            // With end locations the streaming kernels stop at 36 rows per lane, the class kernels at 40: a query that streams at
+            // twice the lanes and half the rows only because of that (300 aa: 16 x 19 instead of 8 x 38) pays the per-step work
+            // twice and loses to the class kernels (Swiss-Prot shape, gaps 3/1: 13.2 ms against 10.0).
+            if (best.G && wantEnd && mode == OPAL_MODE_SW) {
+                const int needHalf = (Q + best.G / 2 - 1) / (best.G / 2);
+                if (best.G >= 2 && needHalf <= OPAL_HIP_MAX_ROWS && opal_hip_rows_supported(17, mode, 1, needHalf)) best = StreamPlan();
+            }
         }
     }
     return best;

@@ -18,7 +18,9 @@ def counters():
 dev = torch.device("cuda", 0)
 m = blosum50()[1]
 tag = os.environ.get("TAG", "base")
-CASES = [("sprot", 541762, 513, 3, {"OPAL_HIP_STREAM": "0"}), ("sprot", 541762, 513, 3, {"OPAL_HIP_STREAM": "1"}), ("sprot", 541762, 513, 3, {}),
+CASES = [("c2", 625000, 513, 11, {}), ("c2", 625000, 513, 11, {"OPAL_HIP_STREAM": "0"}), ("c2", 625000, 513, 3, {}), ("c2", 625000, 513, 3, {"OPAL_HIP_STREAM": "0"}),
+         ("sprot", 541762, 513, 11, {}), ("sprot", 541762, 513, 11, {"OPAL_HIP_STREAM": "0"}), ("sprot", 541762, 300, 3, {}), ("sprot", 541762, 300, 3, {"OPAL_HIP_STREAM": "0"}),
+         ("sprot", 541762, 513, 3, {"OPAL_HIP_STREAM": "0"}), ("sprot", 541762, 513, 3, {"OPAL_HIP_STREAM": "1"}), ("sprot", 541762, 513, 3, {}),
          ("c2", 100000, 2000, 11, {}), ("c2", 100000, 300, 11, {}), ("c2", 100000, 300, 3, {}), ("c2", 100000, 2000, 3, {})]
 if os.environ.get("CASES"):
     CASES = [CASES[int(os.environ["CASES"])]]
