@@ -553,6 +553,14 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
     if (splan.G && splan.G <= 16 && db->gate.active && db->gate.chunks() >= 4 && narrow == 17 && !opts().noSlices) {
         if (opts().stream != 1) { splan = StreamPlan(); headItems = 0; }
     }
+    // End locations with CHEAP gaps (scores grow along the whole sequence: the best cell changes in every step, and every step pays
+    // a settlement and a store, stream_kernel.hpp): at 16 lanes per sequence or fewer the class kernels are as fast or faster there
+    // (published shape, gaps 3/1: 390 aa 14.8 ms against 15.7 streamed, 513 aa 18.6 either way; with gaps 11/1 the stream wins
+    // 5 %: P18080 x 625 000 16.9 ms against 17.8). "Cheap" by a rule of thumb on the inputs: opening + 3 extensions below 0.6 of
+    // the best match.
+    if (splan.G && splan.G <= 16 && wantEnd && mode == OPAL_MODE_SW && opts().stream != 1 && 5 * ((long long)Go + 3LL * Ge) < 3 * maxS) {
+        splan = StreamPlan(); headItems = 0;
+    }
     const bool plain = narrow != 16 || splan.G;
     const int satLimit = plain ? (int)(32767 - maxS) : 32767;
     SearchCtx c{db, Q, A, Go, Ge, mode, wantEnd, dScore, dEndQ, dEndT, satLimit, mode == OPAL_MODE_SW ? -satLimit : 0, maxS};
