@@ -401,12 +401,20 @@ StreamPlan plan_stream(int Q, int A, int mode, int wantEnd, long long residues, 
         const double stepInstr = (best.width == 18 ? 9.5 : 9.0) * best.rows + 30.0;
         const double total = (double)residues * best.G / 64.0 * stepInstr * 2.15 / 1024.0;  // (of one pass; so is crit)
         const double crit = ((double)longest + best.G) * stepInstr * 3.5;
-        if (best.G >= 64 && best.width == 18 && numSeqs >= 1000) {
+        // (do the class kernels still hold the query at full rate -- 4-byte profile entries, 64 lanes?)
+        bool class17 = false;
+        {
+            const int need = (Q + 63) / 64;
+            const int rows = need <= OPAL_HIP_MAX_ROWS ? opal_hip_rows_supported(17, mode, 0, need) : 0;
+            class17 = rows && opal_hip_lds_bytes(17, 64, rows, A) <= 160 * 1024;
+        }
+        if (best.G >= 64 && best.width == 18 && !class17 && numSeqs >= 1000) {
             // every lane of a wave on one sequence and a query whose 4-byte profile exceeds LDS: the class kernels have nothing wider
             // to give the longest sequence, run on packed pairs or 2-byte entries themselves, and pay fill and drain per sequence on
             // top (planner sweep, 2 000 sequences, 1700- / 2000-aa queries: 1.13-1.45 ms streamed against 1.54-1.95; Swiss-Prot-like
-            // tail, 20 000 sequences: 12.1 against 14.9). A 1400-aa query (4-byte profile, width 17) stays with the rule below:
-            // 0.97 ms streamed against 0.69 on the class kernels for 2 000 sequences.
+            // tail, 20 000 sequences: 12.1 against 14.9). A 1400-aa query, whose 4-byte profile fits the class kernels' workgroups
+            // but not a persistent one of 16 waves, stays with the rule below: 0.96 ms streamed against 0.69 on the class kernels
+            // for 2 000 sequences.
         } else if (best.G >= 32) {
             if (crit > 1.5 * total) best = StreamPlan();
         } else {

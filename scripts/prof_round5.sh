@@ -7,7 +7,7 @@ CFGS=${@:-"c2 c2end c3nw c3hw c3ov c4 c5 c5end c5nw c5hw c5ov w32"}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B=$GRAFT_REPO_ROOT/bench.py
-COMMON="--no-cpu-baseline --no-e2e --steps 5 --warmup 2"
+COMMON="--no-cpu-baseline --no-e2e --steps 5 --warmup 2 --settle-ms 0"  # (no settle phase: summarize_prof.py counts 12 launches per run)
 SQ1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY"
 SQ2="SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
 for c in $CFGS; do
