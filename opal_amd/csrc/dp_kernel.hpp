@@ -423,7 +423,11 @@ template <typename V, int S, int J> struct OvColumnRow {
 // accumulator of its own (which accumulator a row block feeds costs nothing, and the group's first block starts it: ROWS_SWI).
 // When a lane holds its slot's new best cell it leaves the rows of ONE group -- the first that holds the column maximum -- in
 // the slot's LDS buffer: one word per row as the registers hold them, then {lane, first row of the group}.
-__host__ __device__ constexpr int opal_swend_groups(int S) { return S > 38 ? 1 : (S > 36 ? 2 : ((S + 3) / 4 < 4 ? (S + 3) / 4 : 4)); }  // (the tallest shapes have no registers for four accumulators)
+__host__ __device__ constexpr int opal_swend_groups(int S) {
+    // (fewer where four accumulators cost a class kernel a wave per SIMD: the tallest shapes, and 15 / 16 / 22 / 23 / 24 rows, which sit
+    // just below a register boundary -- `make check-scratch` and the occupancy remarks of inst_s16swend.hip)
+    return (S > 38 || S == 24) ? 1 : ((S > 36 || S == 15 || S == 16 || S == 22 || S == 23) ? 2 : ((S + 3) / 4 < 4 ? (S + 3) / 4 : 4));
+}
 __host__ __device__ constexpr int opal_swend_group_of_block(int S, int b) { return b * opal_swend_groups(S) / ((S + 3) / 4); }
 __host__ __device__ constexpr int opal_swend_group_first_block(int S, int g) {  // (g == groups: one past the last block)
     int b = 0;
@@ -812,8 +816,13 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
     // probe slot: two rows per word + the lane number, a multiple of four words per slot (opal_shim.hip adds them to the
     // launch's LDS request)
     int bestV = 0, bestC = INT_MIN;  // (INT_MIN: a tie at score 0 replaces nothing)
-    typedef __attribute__((address_space(3))) unsigned ckpt_word;
-    ckpt_word* const ckpt = (ckpt_word*)(opal_lds_u8*)(clkSlot + 48) + (size_t)((threadIdx.x >> 6) * (64 >> log2G) + ((threadIdx.x & 63) >> log2G)) * opal_swend_ckpt_words(S);
+    // (the buffer's address is made where it is used: as a lane value kept across the column loop it cost the 23- to 25-row
+    // shapes their fifth wave per SIMD)
+    auto ckpt_addr = [&]() -> unsigned {
+        unsigned t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        return (unsigned)(uintptr_t)(opal_lds_u8*)(clkSlot + 48) + (unsigned)(((t >> 6) * (64u >> log2G) + ((t & 63u) >> log2G)) * (unsigned)(opal_swend_ckpt_words(S) * 4));
+    };
     int topHv = V::clampv(-(long long)Go);  // NW: H[-1][0]
     reg sRv = 0;                             // SKEW: s*Ge as a 16-bit value
     // One column step. MASKED: lanes before their first column sit the step out (NW/HW/OV; SW needs no test: its state is
@@ -878,6 +887,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
             reg ch[2] = {0, 0};
             constexpr int NQ = opal_swend_groups(S);
             reg aq[NQ];  // CKPT: the column maximum per group of row blocks (opal_swend_groups)
+            if constexpr (NQ == 1) aq[0] = 0;  // (one group: zeroed and accumulated as in round 4 -- one register less at 24 rows)
             if constexpr (PLAIN) {
                 // Plain 16-bit path: one asm statement per block of 4 rows (one ds_read_b128 of profile entries), the
                 // profile read of the next block issued before the current block's arithmetic. Inside a block the
@@ -909,7 +919,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
                             constexpr bool last = j0 + n == S;
                             const reg* Pn = &Pv[j0 - rb * RB + 1];  // profile of the row BELOW each row
                             constexpr int grp = opal_swend_group_of_block(S, j0 / 4);
-                            constexpr bool starts = CKPT && j0 / 4 == opal_swend_group_first_block(S, grp);
+                            constexpr bool starts = CKPT && NQ > 1 && j0 / 4 == opal_swend_group_first_block(S, grp);
                             reg& acc = CKPT ? aq[grp] : (SWEND ? ch[(j0 / 4) * 2 / NBLK4H] : mx);
                             V::template rows<starts ? ROWS_SWI : KIND, n, last>(&Hp[j0], &En[j0], Pn, f, acc, d, t, SKEW ? GQs : Qs, Rs);
                         }
@@ -996,7 +1006,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
                         const unsigned kw = (key - 1u) & 63u;
                         bestV = (int)((key - 1u) >> 6); bestC = s - (int)kw;
                         if ((unsigned)k == kw && (OPAL_ABL < 1 || p.satLimit < 0)) {
-                            swend_keep_column<V, S>((unsigned)(uintptr_t)(opal_lds_u8*)ckpt, Hp, aq, cm, k);
+                            swend_keep_column<V, S>(ckpt_addr(), Hp, aq, cm, k);
                         }
                     }
                 }
@@ -1177,7 +1187,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
             if constexpr (CKPT) {  // the slot's best cell is known in every lane; its row: the smallest one of the kept column holding the score
                 sc = bestV; col = bestV > 0 ? bestC : INT_MAX;
                 int kw = 0;
-                const int r = swend_kept_row<S>((unsigned)(uintptr_t)(opal_lds_u8*)ckpt, sc, kw);
+                const int r = swend_kept_row<S>(ckpt_addr(), sc, kw);
                 row = q0 + kw * S - padTop + r;
             } else
             for (int d = 1; d < G; d <<= 1) {
