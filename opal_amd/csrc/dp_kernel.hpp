@@ -816,12 +816,13 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
     // probe slot: two rows per word + the lane number, a multiple of four words per slot (opal_shim.hip adds them to the
     // launch's LDS request)
     int bestV = 0, bestC = INT_MIN;  // (INT_MIN: a tie at score 0 replaces nothing)
-    // (the buffer's address is made where it is used: as a lane value kept across the column loop it cost the 23- to 25-row
-    // shapes their fifth wave per SIMD)
+    // (slot index = thread index >> log2G. The 14-, 17- and 23- to 25-row shapes make the address where it is used: as a lane value kept
+    // across the column loop it cost them their fifth wave per SIMD; everywhere else it stays in its register -- with cheap gaps
+    // it is used in every step)
     auto ckpt_addr = [&]() -> unsigned {
         unsigned t = threadIdx.x;
-        asm volatile("" : "+v"(t));
-        return (unsigned)(uintptr_t)(opal_lds_u8*)(clkSlot + 48) + (unsigned)(((t >> 6) * (64u >> log2G) + ((t & 63u) >> log2G)) * (unsigned)(opal_swend_ckpt_words(S) * 4));
+        if constexpr ((S >= 23 && S <= 25) || S == 14 || S == 17) asm volatile("" : "+v"(t));
+        return (unsigned)(uintptr_t)(opal_lds_u8*)(clkSlot + 48) + (t >> log2G) * (unsigned)(opal_swend_ckpt_words(S) * 4);
     };
     int topHv = V::clampv(-(long long)Go);  // NW: H[-1][0]
     reg sRv = 0;                             // SKEW: s*Ge as a 16-bit value
