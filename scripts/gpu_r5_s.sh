@@ -13,10 +13,12 @@ for round in 1 2; do
     CASES=12 TAG=$v timeout 200 python3 scripts/gpu_r5_abl.py 2>&1 | grep "^$v"
     CASES=13 TAG=$v timeout 200 python3 scripts/gpu_r5_abl.py 2>&1 | grep "^$v"
   done
-done > $OUT/ab_sprot_end2.txt 2>&1
+done > $OUT/ab_sprot_end3.txt 2>&1
 unset OPAL_LIB_PATH
-cat $OUT/ab_sprot_end2.txt | cut -c1-200
+cat $OUT/ab_sprot_end3.txt | cut -c1-200
 timeout 1500 python3 -m pytest tests -q -m gpu --timeout 600 > $OUT/pytest_gpu.log 2>&1
 tail -3 $OUT/pytest_gpu.log
-OPAL_TEST_SEEDS=300 timeout 1200 python3 -m pytest tests/test_gpu_parity.py -q -x -m gpu -k "randomized_differential" > $OUT/stress_seeds300.log 2>&1
-tail -3 $OUT/stress_seeds300.log
+
+
+for m in SW; do ST=1 MODE=$m timeout 300 python3 scripts/gpu_sprot_queries.py; done > $OUT/sprot_queries_end_sw_final.txt 2>&1
+grep "^SW" $OUT/sprot_queries_end_sw_final.txt
