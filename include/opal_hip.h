@@ -248,8 +248,11 @@ int opal_hip_max_waves_per_block(int width);
 int opal_hip_kernel_vgprs(const OpalHipLaunch* args);
 /* Bytes of LDS the launch would need (query profile), for the scheduler's shape choice. */
 size_t opal_hip_lds_bytes(int width, int lanes_per_seq, int rows_per_lane, int alphabet_length);
-/* ... and what a single-launch width-17 SW search WITH end locations adds to it: the column buffer of every slot of a
-   workgroup (two rows per word + the lane number, in whole 16-byte stores), where the column holding a slot's best cell waits for its one row scan. */
+/* ... and what a single-launch width-17 SW search WITH end locations adds to it: the buffer of every slot of a workgroup
+   in which the rows holding the slot's best cell wait for their one look-up (one group of row blocks -- a quarter of a
+   lane's rows where the kernel keeps four accumulators --, one word per row, then the lane and the group's first row;
+   a multiple of 16 bytes). The streaming SW kernels keep two such buffers per slot (two sequences in flight);
+   opal_hip_stream_lds_bytes includes them. */
 size_t opal_hip_swend_ckpt_bytes(int lanes_per_seq, int rows_per_lane, int waves_per_block);
 const char* opal_hip_last_error(void);
 /* Timing helpers for bench.py: HIP events on the stream the kernels run on. */

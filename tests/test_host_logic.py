@@ -370,3 +370,24 @@ def test_streaming_plan_of_the_scheduler(opal_opt):
     assert (w, g, passes) == (17, 16, 1) and rows == 33
     # an alphabet whose profile leaves no room for a streaming geometry
     assert plan(3000, a=250) == (0, 0, 0, 0)
+
+
+def test_swend_slot_buffer_geometry():
+    """The LDS buffer in which the rows of a slot's best SW cell wait (dp_kernel.hpp, opal_swend_groups): a multiple of 16 bytes
+    per slot, room for the largest group of row blocks plus two header words, never more than the whole column, and the same
+    number the launch asks for per slot whatever the workgroup shape."""
+    import ctypes as C
+    from opal_amd import _lib
+    L = _lib.lib()
+    L.opal_hip_swend_ckpt_bytes.restype = C.c_size_t
+    L.opal_hip_swend_ckpt_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+    for S in range(1, 41):
+        per_slot = L.opal_hip_swend_ckpt_bytes(64, S, 1)
+        assert per_slot % 16 == 0 and per_slot >= 4 * (min(S, 4) + 2), (S, per_slot)
+        blocks = (S + 3) // 4
+        assert per_slot <= 4 * (4 * blocks + 2 + 3), (S, per_slot)           # at most the whole column
+        if 25 <= S <= 36:
+            assert per_slot <= 4 * (4 * ((blocks + 3) // 4) + 2 + 3), (S, per_slot)   # a quarter where four accumulators fit
+        for G, wpb in ((16, 4), (8, 8), (1, 2)):
+            assert L.opal_hip_swend_ckpt_bytes(G, S, wpb) == per_slot * (wpb * 64 // G)
+    assert L.opal_hip_swend_ckpt_bytes(0, 8, 4) == 0 and L.opal_hip_swend_ckpt_bytes(16, 0, 4) == 0
