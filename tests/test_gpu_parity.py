@@ -412,7 +412,7 @@ def test_large_alphabet_profile_exceeds_lds(ours, oracle):
         _check(got, oracle.search(q, db, 4, 1, m, 1, MODES[mode]), mode, f"A=200 {mode}")
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OPAL_TEST_SEEDS", "12"))))
 def test_randomized_differential(seed, ours, oracle):
     """Seeded random shapes: alphabet size, matrix, gap penalties, query/target lengths, mode, search type;
     each drawn configuration is compared with the oracle (bit-exact)."""
@@ -803,7 +803,7 @@ def test_device_traceback_equals_host_traceback(mode, qlen, go, ge, ours, oracle
         assert oracle.check_alignment(q, db[i], go, ge, m, int(s[i]), int(sq[i]), int(st[i]), int(eq[i]), int(et[i]), o) == 0
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("OPAL_TEST_SEEDS", "8"))))  # (OPAL_TEST_SEEDS=600: a one-off stress run)
 def test_randomized_differential_streaming(seed, ours, oracle, opal_opt):
     """The randomized shapes once more with the streaming kernels forced wherever a geometry exists (other alphabets and
     matrices than BLOSUM50, gap extension 0 or larger than the opening, queries from 1 to 2400 residues, every mode and
