@@ -99,6 +99,35 @@ def test_sw_end_cells_with_ties_in_every_wave_geometry(lanes, ours, oracle, opal
         _check(got, want, "SW", f"ties G={lanes} gaps {go}/{ge}")
 
 
+@pytest.mark.parametrize("rows", [15, 16, 22, 23, 24, 25, 33, 36, 37, 38, 39, 40])
+@pytest.mark.parametrize("stream", [False, True])
+def test_sw_end_cells_with_ties_in_every_row_grouping(rows, stream, ours, oracle, opal_opt):
+    """The kept rows of a slot's best cell are ONE group of a lane's row blocks, and the number of groups depends on the rows
+    per lane (four; two or one where four accumulators would cost a wave per SIMD: dp_kernel.hpp, opal_swend_groups): every
+    grouping, in the class kernels and -- up to the 36 rows they exist for -- in the streaming ones, on the tie-ridden inputs."""
+    if stream and rows > 36:
+        pytest.skip("streaming kernels with end locations stop at 36 rows per lane")
+    rng = np.random.RandomState(500 + rows)
+    lanes = 8
+    qlen = lanes * rows - 3
+    A = 4
+    m = np.full((A, A), -1, np.int32)
+    np.fill_diagonal(m, 1)
+    q = rng.randint(0, 2, qlen).astype(np.uint8)
+    db = [rng.randint(0, 2, int(L)).astype(np.uint8) for L in rng.randint(1, 500, 260)]
+    db += [np.tile(q[:7], 60)[: 250 + 3 * i].copy() for i in range(6)]
+    db += [q.copy(), q[::-1].copy(), np.zeros(300, np.uint8), np.ones(2, np.uint8)]
+    opal_opt.set("OPAL_HIP_LANES_PER_SEQ", str(lanes))
+    opal_opt.set("OPAL_HIP_NARROW", "17")
+    opal_opt.set("OPAL_HIP_STREAM", "1" if stream else "0")
+    if stream:
+        opal_opt.set("OPAL_HIP_STREAM_BLOCKS", "1")
+    for go, ge in ((0, 0), (1, 0), (2, 1), (11, 1)):
+        got = ours.search(q, db, go, ge, m, 1, MODES["SW"])[:4]
+        want = oracle.search(q, db, go, ge, m, 1, MODES["SW"])
+        _check(got, want, "SW", f"ties rows={rows} stream={stream} gaps {go}/{ge}")
+
+
 @pytest.mark.parametrize("lanes,qlen,narrow", [(4, 97, "17"), (8, 200, "17"), (16, 300, "17"), (16, 520, "17"), (32, 513, "17"),
                                                (64, 700, "17"), (64, 1300, "18"), (64, 1500, "18"), (64, 2300, "18")])
 def test_sw_end_cells_with_ties_in_the_streaming_kernels(lanes, qlen, narrow, ours, oracle, opal_opt):
