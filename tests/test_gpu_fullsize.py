@@ -111,6 +111,34 @@ def _sample(lens, n_random, seed=1, n_edge=40):
     return np.unique(np.concatenate([order[:n_edge], order[-n_edge:], rng.choice(len(lens), n_random, replace=False)]))
 
 
+def _every_sequence_vs_reference(label, q, host_res, offs, m, go, ge, got, search_type=1):
+    """Every sequence of a full-size search against the reference's own AVX2 library on all host cores (oracle/_ref,
+    ref_search_run; the reference entry point is opal.cpp:1435-1519). `got` = {mode: (score, endQ, endT)} from the HIP path.
+    SW with score 0 has no defined end cell in the reference: masked. A global mode whose reference call
+    returns non-zero (its 32-bit NW / HW / OV rung is undefined behaviour) is compared on the sequences the
+    reference did set and the rest is reported. Returns False where oracle/_ref is not there (the sampled scalar-oracle
+    checks of the callers stay as the fallback)."""
+    ref = oracle_lib.RefThreads() if oracle_lib.have_ref() else None
+    if ref is None or not ref.ok:
+        print(f"\n{label}: oracle/_ref absent -- sampled oracle comparison only")
+        return False
+    n = len(offs) - 1
+    for mode, (s, eq, et) in got.items():
+        rrc, rs, rq, rt, sec = ref.search(q, host_res, offs, m, go, ge, search_type, oracle_lib.MODES[mode])
+        have = rs != np.iinfo(np.int32).min
+        if mode == "SW":
+            assert rrc == 0 and have.all(), (label, mode, rrc)
+        elif rrc != 0:
+            print(f"\n{label} {mode}: the reference returned {rrc} (its undefined 32-bit rung); comparing the {int(have.sum())} of {n} it set")
+        np.testing.assert_array_equal(s[have], rs[have], err_msg=f"{label} {mode}: scores of every sequence vs the reference library")
+        if search_type:
+            live = have & (rs != 0) if mode == "SW" else have
+            np.testing.assert_array_equal(eq[live], rq[live], err_msg=f"{label} {mode}: endQ")
+            np.testing.assert_array_equal(et[live], rt[live], err_msg=f"{label} {mode}: endT")
+        print(f"\n{label} {mode}{' + end' if search_type else ' score'}: all {int(have.sum())} sequences equal the reference library's ({sec:.1f} s on the host)")
+    return True
+
+
 def test_c2_score_only_is_the_kernel_the_bench_times(c2, oracle):
     """BASELINE.json configs[1] exactly as stated: SW SCORE-ONLY on 100 000 sequences (the instantiation bench.py
     times, opal_dp_kernel<17,SW,0,S>), both gap settings of SURVEY.md 8d. Every score must equal the score of the
@@ -188,6 +216,10 @@ def test_c4_shard_all_modes(c4shard, oracle):
         np.testing.assert_array_equal(out[mode][0][pick], s, err_msg=mode)
         np.testing.assert_array_equal(out[mode][1][pick], eq, err_msg=mode)
         np.testing.assert_array_equal(out[mode][2][pick], et, err_msg=mode)
+    # SURVEY.md 8d, C4 as written: EVERY sequence of the shard against the reference itself
+    host_res = c4shard["keep"].cpu().numpy()
+    if _every_sequence_vs_reference("C4 shard (P18080 x 625 000)", q, host_res, c4shard["offs"], m, 3, 1, out):
+        _every_sequence_vs_reference("C4 shard (P18080 x 625 000)", q, host_res, c4shard["offs"], m, 3, 1, {"SW": (s0, None, None)}, search_type=0)
 
 
 def test_c5_long_query_buckets(c4shard, oracle):
@@ -206,11 +238,12 @@ def test_c5_long_query_buckets(c4shard, oracle):
     pick = _sample(lens, 60, seed=5, n_edge=10)
     sres, soffs, _ = synth.database_subset(owned[pick], 42, lens=lens[pick])
     db = [sres[soffs[i]:soffs[i + 1]] for i in range(len(pick))]
-    out = {}
+    out, full = {}, {}
     for mode in ("SW", "OV", "HW", "NW"):
         rc, s, eq, et = pdb.search(q, 3, 1, m, 1, oracle_lib.MODES[mode], overflow_method=1)
         assert rc == 0, mode
         out[mode] = s
+        full[mode] = (s, eq, et)
         orc, so, oq, ot = oracle.search(q, db, 3, 1, m, 1, oracle_lib.MODES[mode])
         np.testing.assert_array_equal(s[pick], so, err_msg=mode)
         np.testing.assert_array_equal(eq[pick], oq, err_msg=mode)
@@ -225,6 +258,11 @@ def test_c5_long_query_buckets(c4shard, oracle):
     rc, s0, _, _ = pdb.search(q, 3, 1, m, 0, oracle_lib.MODE_SW, overflow_method=1)
     assert rc == 0
     np.testing.assert_array_equal(s0, out["SW"])
+    # SURVEY.md 8d, C5 as written: EVERY sequence of the shard against the reference itself (streaming kernels, two
+    # sequences in flight per slot: where a rare interleaving would show)
+    host_res = c4shard["keep"].cpu().numpy()
+    _every_sequence_vs_reference("C5 shard (2000 aa x 625 000)", q, host_res, c4shard["offs"], m, 3, 1, full)
+    del host_res
     from opal_amd.api import PreparedDb
     res, offs, _ = synth.database(3000, seed=42)
     # forced 16 -> 32 bit: x3 matrix, the query itself (and two mutilated copies) planted among 3000 sequences
@@ -297,6 +335,9 @@ def test_c4_eight_way_equals_unsharded(opal_opt, oracle):
     res_host = d_res.cpu().numpy()
     del d_res, out
     torch.cuda.empty_cache()
+    # SURVEY.md 8d, C4 whole: all 5 000 000 sequences against the reference itself
+    if _every_sequence_vs_reference("C4 whole (P18080 x 5 000 000)", q, res_host, offs, m, 3, 1, {"SW": (want["SW"][0], None, None)}, search_type=0):
+        _every_sequence_vs_reference("C4 whole (P18080 x 5 000 000)", q, res_host, offs, m, 3, 1, {"HW": tuple(want["HW"])})
     L = _lib.lib()
     lens32 = np.ascontiguousarray(lens, np.int32)
     ptrs = np.ascontiguousarray(res_host.ctypes.data + np.asarray(offs[:-1], dtype=np.uint64), dtype=np.uint64)
