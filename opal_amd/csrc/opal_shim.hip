@@ -378,7 +378,7 @@ static int raise_lds_limit(const void* fn) {
 
 static size_t lds_bytes(int width, int G, int rows, int A) {
     const int es = (width == 16 || width == 18) ? 2 : 4;  // widths 17 and 32 keep 4-byte profile entries
-    return (size_t)(A + 1) * (size_t)opal_profile_stride(es, G, rows, width == 18) + 48;  // (+48: probe / zero-copy slot, dp_kernel.hpp)
+    return (size_t)(A + 1) * (size_t)opal_profile_stride(es, G, rows) + 48;  // (+48: probe / zero-copy slot, dp_kernel.hpp)
 }
 
 // SW with end location on the single-launch width-17 kernels: a column buffer per slot of the workgroup behind the profile

@@ -52,13 +52,14 @@ typedef void (*StreamFn)(const StreamParams);
                                  // last lane may still be flushing the one before)
 #define STREAM_DESC_BYTES 32
 
-// one letter's profile row: G lane segments, then the 16-byte info block {Go, Ge, flush flag, 0}
+// one letter's profile row: G lane segments, then the 16-byte info block {Go, Ge, flush flag, 0} sixteen times over -- lane l
+// reads copy l & 15, so that the sixteen lanes the LDS serves together, each on the block of ITS letter, fall on sixteen
+// different bank slots (the letter stride is a multiple of 256 bytes from 8 lanes per sequence on: dp_kernel.hpp, LDS geometry)
+#define STREAM_INFO_BYTES 256
 template <int WIDTH>
 __host__ __device__ inline int opal_stream_stride(int G, int S) {
     constexpr int ES = WIDTH == 18 ? 2 : 4;
-    int stride = G * opal_lane_bytes(ES, S, WIDTH == 18) + 16;
-    if (((stride / 16) & 1) == 0) stride += 16;
-    return stride;
+    return opal_letter_stride(G * opal_lane_bytes(ES, S, 1) + STREAM_INFO_BYTES, G);
 }
 template <int WIDTH>
 __host__ __device__ inline size_t opal_stream_lds_bytes(int G, int S, int A) {
@@ -162,7 +163,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     constexpr int ES = (int)sizeof(elem);
     constexpr int RB = 16 / ES;
     constexpr int SPAD = (S + RB - 1) / RB * RB;
-    constexpr int LANE_BYTES = opal_lane_bytes(ES, S, WIDTH == 18);
+    constexpr int LANE_BYTES = opal_lane_bytes(ES, S, 1);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const KParams& p = sp.base;
     if constexpr (SIDE) {  // (instantiations of their own, inst_stream17head.hip: inside the plain kernels the extra body cost C4 1.1 %)
@@ -221,7 +222,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
             info.y = sep ? 0xffff : (p.Ge & 0xffff);
             info.z = letter == SEP2 ? 1 : 0;
             info.w = 0;
-            *reinterpret_cast<int4*>(lds + letter * stride + G * LANE_BYTES) = info;
+            for (int c = 0; c < STREAM_INFO_BYTES / 16; c++) *reinterpret_cast<int4*>(lds + letter * stride + G * LANE_BYTES + 16 * c) = info;
         }
     }
     __syncthreads();
@@ -242,7 +243,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     int outM = 0;
     const unsigned ldsBase = (unsigned)(uintptr_t)(opal_lds_u8*)lds;
     const unsigned padOff = ldsBase + (unsigned)(PAD * stride);
-    const unsigned infoOff = (unsigned)((G - k) * LANE_BYTES);  // from my profile address to my letter's info block
+    const unsigned infoOff = (unsigned)((G - k) * LANE_BYTES + 16 * (lane & 15));  // from my profile address to my copy of my letter's info block
     unsigned offv = padOff + (unsigned)(k * LANE_BYTES);
     unsigned tokq = padOff;
 
@@ -519,9 +520,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
 template <int WIDTH>
 __host__ __device__ inline int opal_gl_stream_stride(int G, int S) {
     constexpr int ES = WIDTH == 18 ? 2 : 4;
-    int stride = G * opal_lane_bytes(ES, S, WIDTH == 18);
-    if (((stride / 16) & 1) == 0) stride += 16;
-    return stride;
+    return opal_letter_stride(G * opal_lane_bytes(ES, S, 1), G);
 }
 __host__ __device__ inline int opal_gl_init_entries(int S) { return 2 * ((S + 3) / 4 * 4) + 4; }  // Hp[], En[], diagonal input
 template <int WIDTH>
@@ -545,7 +544,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
     constexpr int SPAD = (S + RB - 1) / RB * RB;
     constexpr int SP4 = (S + 3) / 4 * 4;
     constexpr int INIT = 2 * SP4 + 4;  // entries of one lane's boundary block
-    constexpr int LANE_BYTES = opal_lane_bytes(ES, S, WIDTH == 18);
+    constexpr int LANE_BYTES = opal_lane_bytes(ES, S, 1);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const KParams& p = sp.base;
     if ((int)blockIdx.x < sp.sideBlocks) {
