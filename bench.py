@@ -397,6 +397,7 @@ def main():
     plan = shard.GatherPlan(owned_lists, nres, dev if backend == "nccl" else "cpu", root=rank == 0) if multi else None
     torch.cuda.synchronize()  # (the zero fills above run on torch's stream, the searches on the library's)
     kernel_ms = []
+    period_ms = []  # (N = 1) device time from the end of the search before to the end of this one: queued searches overlap
     step_no = [0]
 
     pending = [None]  # (N > 1) the result buffer whose exchange is still to be issued
@@ -433,13 +434,14 @@ def main():
                                          endq.data_ptr() if want_end else 0, endt.data_ptr() if want_end else 0)
             kms = None
             if rc == 0 and (inflight[0] == 1 or args.in_flight == 1):
-                rc, kms = pdb.wait()
+                rc, kms, per = pdb.wait2()
             elif rc == 0:
                 inflight[0] = 1
             if rc != 0:
                 raise SystemExit(f"search failed rc={rc}")
             if kms is not None:
                 kernel_ms.append(kms)
+                period_ms.append(per)
             return
         else:
             # the search is only ENQUEUED; while the GPU works on it the host issues the previous step's exchange (its
@@ -460,11 +462,12 @@ def main():
             exchange(pending[0])
             pending[0] = None
         if not multi and inflight[0] == 1:  # the last step's search
-            rc, kms = pdb.wait()
+            rc, kms, per = pdb.wait2()
             inflight[0] = 0
             if rc != 0:
                 raise SystemExit(f"search failed rc={rc}")
             kernel_ms.append(kms)
+            period_ms.append(per)
 
     def fence():
         if multi:
@@ -493,6 +496,7 @@ def main():
         step()
     flush()
     kernel_ms.clear()
+    period_ms.clear()
     # Every result buffer is POISONED before the timed region (outside it): the warm-up steps have already written the right
     # answers, so a timed step that did nothing would otherwise still verify. The check below reads what the LAST timed steps
     # wrote (one buffer per search in flight) and fails on any value the timed region left untouched.
@@ -545,7 +549,14 @@ def main():
 
     # what an N > 1 line needs to be READ: every rank's mean kernel time (all-reduced one-hot vector), the share of cells
     # the deal gave every rank, the time of the exchange on rank 0's stream
-    my_kms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    # N = 1: queued searches take turns on two streams of the handle and OVERLAP (the grid of search i+1 is released when search i
+    # has started its last workgroup and fills the CUs it leaves as it drains), so the time a search costs is the device time
+    # between two consecutive ends -- the period --, not the life of its own launch (which shares the chip at both ends). The
+    # first timed search's period starts at the last warm-up search's end, across the untimed poisoning of the buffers: left out.
+    launch_kms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    my_kms = launch_kms
+    if not multi and len(period_ms) >= 3 and all(v > 0 for v in period_ms[1:]):
+        my_kms = float(np.mean(period_ms[1:]))
     rank_kms = torch.zeros(world, dtype=torch.float64, device=rdev)
     rank_kms[rank] = my_kms
     if multi:
@@ -638,7 +649,8 @@ def main():
                        "cells_per_step": total_cells, "cells_per_step_rank0": cells,
                        "parallelism": f"db-shard x{world} (64-seq groups dealt by residue count), 1 gather" if world > 1 else
                                       ("one GPU, results written at their database index; " +
-                                       ("two searches queued on the handle: step i enqueued behind step i-1, then step i-1 waited for" if args.in_flight == 2
+                                       ("two searches queued on the handle (step i enqueued behind step i-1, then step i-1 waited for), on two streams in turn: the grid of "
+                                        "search i is released when search i-1 has started its last workgroup and fills the CUs it leaves (OPAL_HIP_PIPELINE=0: one stream)" if args.in_flight == 2
                                         else "one search at a time: enqueued, waited for"))},
             "in_flight": 1 if multi else args.in_flight,
             "settle": {"ms": args.settle_ms, "steps": settle_steps,
@@ -659,10 +671,16 @@ def main():
             "roofline": {"bound": "valu-issue", "achieved": round(kernel_gcups, 1), "peak": round(peak, 0), "unit": "GCUPS",
                          "frac": round(kernel_gcups / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": round(kms, 4),
+                         "launch_ms": round(launch_kms, 4),
+                         "frac_per_launch": round(cells / (launch_kms * 1e-3) / 1e9 / peak, 4),
                          "clock_ghz": round(clock_ghz, 3) if clock_ghz else None,
                          "frac_at_measured_clock": round(kernel_gcups / valu_peak_gcups(instr_per_cell, clock_ghz * 1e9), 4) if clock_ghz else None,
                          "model": f"1024 SIMDs x 2.4 GHz x 64 lanes / ({instr_per_cell:.0f} full-rate 16-bit instr x 2 clk per cell); "
-                                  "kernel_ms = HIP events around all DP launches of a step on the launch stream (rank 0); clock_ghz = "
+                                  "kernel_ms (N = 1) = device time per search in the queue: HIP events, from the end of the search before to the end of "
+                                  "this one, mean over the timed steps but the first -- consecutive searches overlap on two streams (a search's grid is "
+                                  "released when the one before has started its last workgroup), so launch_ms, the life of one search's launches from "
+                                  "their release to their end (what rocprofv3 --kernel-trace calls its duration), is longer than what the search costs and "
+                                  "frac_per_launch prices that; N > 1: kernel_ms = HIP events around all DP launches of a step on rank 0; clock_ghz = "
                                   "shader cycles / constant-rate ticks over one wave's lifetime per workgroup, measured in the DP kernels "
                                   "themselves on the last of >= 30 ms of searches queued two deep after the timed region (as the timed steps are); "
                                   "frac_at_measured_clock prices the bound at it",

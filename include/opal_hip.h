@@ -116,8 +116,10 @@ typedef struct OpalHipLaunch {
     /* opal_hip_launch_stream: the waves working on the first prio_items sequences handed out (the longest of the range) run at
        a raised issue priority (0: none) */
     int prio_items;
-    /* opal_hip_launch_swap: NULL, or a zeroed device counter that every workgroup of the launch increments when it starts
-       (opal_hip_wait_started) */
+    /* NULL, or a device counter that every workgroup of the launch increments when it starts. opal_hip_launch_swap /
+       opal_hip_launch_pair: zeroed by the caller, waited for with opal_hip_wait_started. opal_hip_launch /
+       opal_hip_launch_uber / opal_hip_launch_stream: a cumulative counter that is never zeroed, waited for with
+       opal_hip_wait_count (queued searches that take turns on two streams) */
     int* started_counter;
 } OpalHipLaunch;
 
@@ -171,6 +173,11 @@ int opal_hip_launch_pair(const OpalHipLaunch* args, void* boundary, unsigned lon
    that fills every CU with workgroups of 39 KB of LDS otherwise starves a 55 KB workgroup arriving a moment later until
    it drains: one retiring workgroup never frees enough (541 762 sequences, 300-aa query: 8.5 ms or 12.5 from run to run). */
 int opal_hip_wait_started(const int* counter, int target, void* stream);
+/* The same for a CUMULATIVE counter (OpalHipLaunch::started_counter of the class / one-launch / streaming launches: never
+   zeroed, may wrap): ends when (int)(*counter - target) >= 0, or after half a second. opal_hip_last_launch_blocks: the grid size
+   of the last such launch made by the calling thread -- what it will have added to the counter once all of it has started. */
+int opal_hip_wait_count(const int* counter, int target, void* stream);
+int opal_hip_last_launch_blocks(void);
 /* NW / HW / OV have role-swapped kernels too (int32 arithmetic, scores and end cells: out_end_* may be NULL): the same entry
    with args->mode; rows per lane from opal_hip_swap_gl_rows: 16 (2-byte profile entries: every matrix entry must fit 16
    bits) or 8 (4-byte entries). */
@@ -402,6 +409,15 @@ int opalx_search_device_async(OpalxDb* db, const unsigned char* query, int query
                               int gap_open, int gap_ext, const int* score_matrix, int alphabet_length,
                               int search_type, int mode, int* d_score, int* d_end_query, int* d_end_target);
 int opalx_db_wait(OpalxDb* db, float* kernel_ms);
+/* Round 6: queued searches take turns on TWO streams of the handle. A search that is one grid (a one-launch class search, a
+   single streaming launch; no re-run list possible) lets the grid of the search queued behind it reach the dispatcher as soon as
+   its own last workgroup has started, so that the second fills the CUs the first leaves while it drains; anything else waits for
+   the whole search before it. Results, return codes and the first-in-first-out order of opalx_db_wait are unchanged; what
+   changes is what the times mean: `kernel_ms` of a search is the device time from the release of its first launch to its end --
+   and consecutive searches overlap, so these do not add up to the elapsed time. `period_ms` (opalx_db_wait2) is the device time
+   between the end of the search waited for before this one and the end of this one: the time the search cost the queue (0 for
+   the first search ever waited for on the handle). Option OPAL_HIP_PIPELINE=0: one stream, one search after the other. */
+int opalx_db_wait2(OpalxDb* db, float* kernel_ms, float* period_ms);
 
 /* As above with HOST result buffers (copied back after the kernels). */
 int opalx_search_host(OpalxDb* db, const unsigned char* query, int query_length,

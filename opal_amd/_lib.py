@@ -51,6 +51,8 @@ def lib():
                                                 C.c_void_p, C.c_void_p, C.c_void_p]
         L.opalx_db_wait.restype = C.c_int
         L.opalx_db_wait.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.opalx_db_wait2.restype = C.c_int
+        L.opalx_db_wait2.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.opalx_search_starts.restype = C.c_int
         L.opalx_search_starts.argtypes = [C.c_void_p, u8p, C.c_int, C.c_int, C.c_int, i32p, C.c_int, C.c_int, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, i32p, i32p]

@@ -164,6 +164,13 @@ class PreparedDb:
         rc = _lib.lib().opalx_db_wait(self._h, C.byref(ms))
         return rc, ms.value
 
+    def wait2(self):
+        """opalx_db_wait2: as wait(), plus the device time between the end of the search waited for before this one and the end
+        of this one (queued searches overlap on two streams: what a search cost the queue). Returns (rc, kernel_ms, period_ms)."""
+        ms = C.c_float(0); per = C.c_float(0)
+        rc = _lib.lib().opalx_db_wait2(self._h, C.byref(ms), C.byref(per))
+        return rc, ms.value, per.value
+
     def search_starts_device(self, query, gap_open, gap_ext, score_matrix, mode, d_score, d_end_q, d_end_t, d_start_q, d_start_t):
         """opalx_search_starts: start cells on the device from the score / end-cell arrays a SCORE_END search of the
         same query left in device memory (raw pointers). Returns (rc, redo) -- `redo` = indices the host must redo."""

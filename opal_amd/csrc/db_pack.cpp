@@ -303,6 +303,9 @@ void db_release(OpalxDb* db) {
     db->raw.release(); db->rawOff.release(); db->hRawOff.release(); db->hRaw.release(); db->hResults.release();
     for (void*& st : db->streams) { opal_hip_stream_destroy(st); st = nullptr; }
     opal_hip_stream_destroy(db->mainStream); db->mainStream = nullptr;
+    opal_hip_stream_destroy(db->pipeStream); db->pipeStream = nullptr;
+    for (void*& ev : db->pipe.done) { opal_hip_event_destroy(ev); ev = nullptr; }
+    db->pipe = OpalxDb::Pipe(); db->startedCtr.release(); db->startedTotal = 0; db->hdrDev = nullptr; db->curStream = nullptr;
     opal_hip_stream_destroy(db->copyStream); db->copyStream = nullptr;
     opal_hip_stream_destroy(db->copyStream2); db->copyStream2 = nullptr;
     opal_hip_stream_destroy(db->auxStream); db->auxStream = nullptr;
@@ -310,7 +313,7 @@ void db_release(OpalxDb* db) {
     for (void*& ev : db->events) { opal_hip_event_destroy(ev); ev = nullptr; }
     for (void*& ev : db->asyncEv) { opal_hip_event_destroy(ev); ev = nullptr; }
     for (int i = 0; i < OPALX_ASYNC_DEPTH; i++) { opal_hip_event_destroy(db->hdrEv[i]); db->hdrEv[i] = nullptr; db->hdrEvSet[i] = false; }
-    db->asyncHead = db->asyncTail = 0;
+    db->asyncHead = db->asyncTail = 0; db->asyncWaited = 0;
     for (void*& ev : db->gate.events) { opal_hip_event_destroy(ev); ev = nullptr; }
     db->gate.events.clear();
 }
@@ -769,10 +772,10 @@ extern "C" int opalx_db_last_timeline_cycles(OpalxDb* db, unsigned long long* ou
 extern "C" double opalx_db_last_clock_ghz(const OpalxDb* dbc) {
     OpalxDb* db = const_cast<OpalxDb*>(dbc);
     if (!db) return 0.0;
-    if (db->clockProbe && db->header.p) {  // (the counters of the last search enqueued on the handle: waits for it)
+    if (db->clockProbe && db->hdrDev) {  // (the counters of the last search enqueued on the handle: waits for it)
         unsigned long long v[2] = {0, 0};
         void* st = db->main();
-        if (st && !opal_hip_memcpy_d2h(v, db->header.p + 16, sizeof v, st) && !opal_hip_stream_sync(st) && v[1])
+        if (st && !opal_hip_memcpy_d2h(v, db->hdrDev + 16, sizeof v, st) && !opal_hip_stream_sync(st) && v[1])
             db->lastClockGhz = (double)v[0] / (double)v[1] * opal_hip_wall_clock_hz() * 1e-9;
     }
     return db->lastClockGhz;

@@ -92,7 +92,14 @@ struct KParams {
     // tl[2 * blockIdx.x], tl[2 * blockIdx.x + 1] (scripts/gpu_timeline.py: where the time of a launch goes), and the shader
     // cycles at the same moments to tl[2 * 65536 + ...] (scripts/gpu_clock_timeline.py: the clock over the life of a launch).
     unsigned long long* tl;
+    // (may be null) every workgroup of the launch adds one when it starts, before anything else: a cumulative counter that is
+    // never zeroed. The next search queued on the handle waits -- on its own stream, opal_hip_wait_count -- until the last
+    // workgroup of this grid has been dispatched, then fills the CUs this one leaves as it drains (ladder.cpp, SearchPipe).
+    int* started;
 };
+__device__ __forceinline__ void count_started(int* started) {
+    if (threadIdx.x == 0 && started) atomicAdd(started, 1);
+}
 
 // The two start stamps -- and the pointer itself -- wait in 48 bytes behind the workgroup's LDS data, so that nothing of
 // the probe is live in a register across the column loop (the 40-row kernels sit at 128 VGPRs).
@@ -576,9 +583,10 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
     // pure latency) do it in every mode: with so few rows the LDS round trip is most of a step.
 #ifndef OPAL_PF_LATE_MASK
 // bit MODE = that mode's tall shapes prefetch late. SW: C2 6 940 -> 7 010 GCUPS, SW + end 6 160 -> 6 280 (same box, interleaved:
-// profiles/r04_ab_prefetch_split.txt); NW / HW / OV (which need SPLIT for it) gain nothing: their row blocks are too short to
-// cover the round trip either way, and they are bound by instruction count and clock, not by LDS latency.
-#define OPAL_PF_LATE_MASK 9
+// profiles/r04_ab_prefetch_split.txt). NW had it in rounds 4 and 5 (+3 % then); with the letter-independent LDS layout of round 6
+// (a read is 7.8 LDS cycles at 8 lanes per sequence instead of 11.2) NW measures 1.6-2 % FASTER without, HW and OV 2-3 % slower with
+// (profiles/r06_ab_prefetch_mask.txt): SW only.
+#define OPAL_PF_LATE_MASK 8
 #endif
 #ifndef OPAL_SPLIT_FILL
 #define OPAL_SPLIT_FILL 1    // NW/HW/OV run their first G-1 steps in a loop of their own (with the round-4 frame: HW +3 %, OV +4 %, NW +3 % with the late prefetch)
@@ -1295,6 +1303,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
 
 template <int WIDTH, int MODE, int FLAGS, int S>
 __global__ void __launch_bounds__(opal_max_waves_per_block(WIDTH) * 64, (WIDTH == 17 && !(FLAGS & FLAG_MULTI)) ? 4 : 1) opal_dp_kernel(const KParams p) {
+    count_started(p.started);
     opal_dp_body<WIDTH, MODE, FLAGS, S>(p, KClass{p.log2G, p.firstItem, p.numItems, p.prio}, (int)blockIdx.x);
 }
 
@@ -1315,6 +1324,7 @@ typedef void (*UberFn)(const UberParams);
 template <int MODE, int FLAGS, int S0>
 __global__ void __launch_bounds__(WAVES_PER_BLOCK * 64, 4) opal_dp_uber(const UberParams u) {
     const int b = (int)blockIdx.x;
+    count_started(u.base.started);
     // (SW with end locations at 40 rows: the slot-exact end cell is two registers over inside this three-body kernel; row scans there)
     constexpr int FLAGS0 = (S0 >= 40 && MODE == MODE_SW && (FLAGS & FLAG_SWEND)) ? (FLAGS | FLAG_NOCKPT) : FLAGS;
     if (b >= u.firstBlock[2]) opal_dp_body<17, MODE, FLAGS0, S0>(u.base, u.cls[2], b - u.firstBlock[2]);

@@ -6,6 +6,37 @@
 
 namespace opal_host {
 
+// ---- queued searches in turn on two streams (OpalxDb::Pipe)
+// What the search in hand must wait for before its first launch: if the search before it is ONE tracked grid and this launch is
+// one too (`grid`), a one-wave kernel that ends when that grid's last workgroup has started; anything else, the whole search.
+// Every launch site of search_core comes through here first (once per search: the first call decides).
+static int pipe_resolve(OpalxDb* db, void* stream, bool grid) {
+    OpalxDb::Pipe& pp = db->pipe;
+    if (!pp.active) return 0;
+    if (!grid || pp.launched) pp.untracked = true;  // (a second launch of any kind: the search is no longer one grid)
+    if (pp.resolved) return 0;
+    pp.resolved = true;
+    int e = 0;
+    if (pp.prevKind == 1 && grid && opts().pipeline == 1) {
+        e = opal_hip_wait_count(db->startedCtr.p, (int)(pp.prevTarget - (unsigned)opts().pipeSlack), stream);
+        if (debug_on()) fprintf(stderr, "[opal] queued search: grid behind a wait for %u started workgroups of the search before it\n", pp.prevTarget);
+    } else if (pp.prevKind != 0) {
+        void* done = pp.done[pp.lastIdx];
+        if (done) e = opal_hip_stream_wait_event(stream, done);
+    }
+    // the search's own time starts here: behind the wait, in front of its first launch
+    if (!e && pp.startEv) e = opal_hip_event_record(pp.startEv, stream);
+    pp.startEv = nullptr;
+    return e;
+}
+// ... and after a tracked grid has been launched: its workgroups count themselves in (fill_launch sets started_counter)
+static void pipe_launched_grid(OpalxDb* db) {
+    OpalxDb::Pipe& pp = db->pipe;
+    if (!pp.active) return;
+    pp.launched = true;
+    db->startedTotal += (unsigned)opal_hip_last_launch_blocks();
+}
+
 static void fill_launch(OpalHipLaunch& a, const SearchCtx& c, int width, int swEndPass, int detectWrap, const int* work,
                         int* ovfCounter) {
     memset(&a, 0, sizeof a);
@@ -22,8 +53,9 @@ static void fill_launch(OpalHipLaunch& a, const SearchCtx& c, int width, int swE
     a.overflow_count = ovfCounter; a.overflow_items = db->ovfItems.p;
     a.sat_limit = c.satLimit; a.neg_pad = c.negPad;
     a.stream = c.stream ? c.stream : db->main();
-    a.clock_probe = db->clockProbe ? (unsigned long long*)(db->header.p + 16) : nullptr;
+    a.clock_probe = db->clockProbe ? (unsigned long long*)(db->hdrDev + 16) : nullptr;
     a.timeline = (db->clockProbe && db->timelineProbe) ? db->timeline.p : nullptr;
+    a.started_counter = nullptr;  // (the tracked launch sites set it: one-grid searches queued on the handle)
 }
 
 // Queries that no single wave geometry can hold (more than 64 lanes x 40 rows, or a query profile
@@ -32,6 +64,7 @@ static void fill_launch(OpalHipLaunch& a, const SearchCtx& c, int width, int swE
 static int launch_chunked(const SearchCtx& c, int width, int swEndPass, int detectWrap, const int* work, int firstItem,
                           int numItems, LenView lenOf, int* ovfCounter) {
     OpalxDb* db = c.db;
+    if (pipe_resolve(db, c.stream ? c.stream : db->main(), false)) return OPAL_ERR_NO_SIMD_SUPPORT;  // (row chunks share db->boundary)
     int bestG = 0, bestS = 0, wpb = 4;
     // the items of THIS range (a re-run list, the 32-bit prefix of a global-mode search: a handful of long sequences, which
     // want every lane on one sequence; the whole database: the bulk decides): longest first, mean from a sample
@@ -86,7 +119,7 @@ static int launch_chunked(const SearchCtx& c, int width, int swEndPass, int dete
 // One class of a launch range on `stream` (a plain class launch). `side`: the launch belongs to a long-sequence class
 // beside the bulk (issue priority).
 static int launch_class(const SearchCtx& c, int width, int swEndPass, int detectWrap, const int* work, LaunchClass k, int skew,
-                        int* ovfCounter, void* stream, bool side) {
+                        int* ovfCounter, void* stream, bool side, bool grid = false) {  // (grid: the range's only launch -- see pipe_resolve)
     {   // the plan assumed the skewed kernels (every rows-per-lane value exists); a class that cannot use them
         // takes the plain kernel's next instantiated value
         const int rows = opal_hip_rows_supported(width, c.mode, swEndPass | (skew ? 4 : 0), k.rows);  // k.rows if it exists
@@ -111,7 +144,10 @@ static int launch_class(const SearchCtx& c, int width, int swEndPass, int detect
     if (debug_on())
         fprintf(stderr, "[opal] launch width=%d mode=%d end=%d items=[%d,+%d) G=%d rows=%d waves/block=%d ldsPad=%d%s%s\n", width,
                 c.mode, swEndPass, k.first, k.count, k.G, k.rows, k.wpb, k.ldsPad, skew ? " skew" : "", side ? " (side)" : "");
+    if (pipe_resolve(c.db, stream, grid)) return 1;
+    if (grid && c.db->pipe.active) a.started_counter = c.db->startedCtr.p;
     if (opal_hip_launch(&a)) return 1;
+    if (grid) pipe_launched_grid(c.db);
     if (c.sideBlocks && c.stream) *c.sideBlocks += (k.count + (64 / k.G) * a.waves_per_block - 1) / ((64 / k.G) * a.waves_per_block);
     count(CNT_CLASS_LAUNCHES);
     if (width == 32) count(CNT_WIDTH32);
@@ -170,7 +206,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
         else if (k.G != 2 * bulk.G && k.G != 4 * bulk.G) oneGrid = false;
     }
     // items [i0, i1) of the classes as ONE grid on `stream` (any class may be empty there)
-    auto launch_grid = [&](const SearchCtx& cx, int i0, int i1, void* stream) -> int {
+    auto launch_grid = [&](const SearchCtx& cx, int i0, int i1, void* stream, bool tracked = false) -> int {
         OpalHipUberLaunch u;
         memset(&u, 0, sizeof u);
         fill_launch(u.base, cx, width, swEndPass, detectWrap, nullptr, ovfCounter);
@@ -188,7 +224,10 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
             fprintf(stderr, "[opal] one launch width=%d mode=%d end=%d G0=%d rows=%d%s: bulk [%d,+%d) long [%d,+%d) longest [%d,+%d)\n", width,
                     c.mode, swEndPass, bulk.G, bulk.rows, skewBulk ? " skew" : "", u.base.first_item, u.base.num_items, u.long_first_item,
                     u.long_num_items, u.longest_first_item, u.longest_num_items);
+        if (pipe_resolve(db, stream, tracked)) return 1;
+        if (tracked && db->pipe.active) u.base.started_counter = db->startedCtr.p;
         if (opal_hip_launch_uber(&u)) return 1;
+        if (tracked) pipe_launched_grid(db);
         count(CNT_ONE_LAUNCH);
         return 0;
     };
@@ -320,8 +359,10 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
     // everything this range reads must have landed (no-op unless a fill is still in flight)
     if (!gate_items(db, db->main(), 0, 2 * db->numPairs)) return OPAL_ERR_NO_SIMD_SUPPORT;
 
+    // (one grid, or one class, of a plain 16-bit range that is not a re-run list: what a queued search may overlap with its neighbours)
+    const bool trackable = !work && (width == 17 || width == 18);
     if (oneGrid && classes.size() >= 2) {
-        if (launch_grid(c, firstItem, firstItem + numItems, db->main())) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
+        if (launch_grid(c, firstItem, firstItem + numItems, db->main(), trackable)) { db->quiesce(); return OPAL_ERR_NO_SIMD_SUPPORT; }
         return 0;
     }
     // The last class (the bulk of the database) runs on the main stream; the classes of long
@@ -329,6 +370,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
     // joined back into the main stream with events, longest sequences enqueued first.
     const int nside = std::min<int>((int)classes.size() - 1, 3);
     void* fork = nullptr;
+    if (!(trackable && classes.size() == 1) && pipe_resolve(db, db->main(), false)) return OPAL_ERR_NO_SIMD_SUPPORT;  // (before the fork)
     if (nside > 0) {
         fork = db->event(0);
         if (!fork || opal_hip_event_record(fork, db->main())) return OPAL_ERR_NO_SIMD_SUPPORT;
@@ -341,7 +383,8 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
         const bool side = (int)ki < nside;
         void* stream = side ? db->stream((int)ki) : db->main();
         if (side && (!stream || opal_hip_stream_wait_event(stream, fork))) { err = 1; break; }
-        if (launch_class(c, width, swEndPass, detectWrap, work, classes[ki], maySkew && skew_ok(classes[ki].first), ovfCounter, stream, side)) { err = 1; break; }
+        if (launch_class(c, width, swEndPass, detectWrap, work, classes[ki], maySkew && skew_ok(classes[ki].first), ovfCounter, stream, side,
+                         trackable && classes.size() == 1)) { err = 1; break; }
         if (side) {
             void* done = db->event(1 + (int)ki);
             if (!done || opal_hip_event_record(done, stream)) { err = 1; break; }
@@ -386,24 +429,32 @@ bool args_fit_int32(int Go, int Ge, const int* M, int A) {
 int ensure_query_buffers(OpalxDb* db, const unsigned char* query, int Q, const int* M, int A) {
     const size_t mb = (size_t)A * A * sizeof(int);
     const size_t head = 32;  // {counters[4], clock probe[2 x u64]}
-    const size_t bytes = (head + mb + (size_t)std::max(Q, 1) + 15) / 16 * 16;
+    const size_t bytes = (head + mb + (size_t)std::max(Q, 1) + 255) / 256 * 256;
+    // One DEVICE slot per search in flight as well (round 6): queued searches overlap on two streams, and a search must not find its
+    // query, matrix or counters overwritten by the upload of the next one.
     // (searches may be queued behind each other, opalx_search_device_async: a buffer that has to grow waits for them first)
-    if ((db->header.cap < bytes || db->hHeader.cap < OPALX_ASYNC_DEPTH * bytes) && (db->header.p || db->hHeader.p) && opal_hip_stream_sync(db->main())) return 1;
-    if (!db->header.ensure(bytes, 1.5) || !db->hHeader.ensure(OPALX_ASYNC_DEPTH * bytes, 1.5)) return 1;
+    if ((db->header.cap < OPALX_ASYNC_DEPTH * bytes || db->hHeader.cap < OPALX_ASYNC_DEPTH * bytes) && (db->header.p || db->hHeader.p)) {
+        if (opal_hip_stream_sync(db->main())) return 1;
+        if (db->pipeStream && opal_hip_stream_sync(db->pipeStream)) return 1;
+        if (db->mainStream && opal_hip_stream_sync(db->mainStream)) return 1;
+    }
+    if (!db->header.ensure(OPALX_ASYNC_DEPTH * bytes, 1.5) || !db->hHeader.ensure(OPALX_ASYNC_DEPTH * bytes, 1.5)) return 1;
     // the pinned staging slot of this search: free once the upload recorded behind its last use has run
     const int slot = (int)(db->hdrSeq++ % OPALX_ASYNC_DEPTH);
     if (db->hdrEvSet[slot] && opal_hip_event_sync(db->hdrEv[slot])) return 1;
-    unsigned char* h = db->hHeader.p + (size_t)slot * (db->hHeader.cap / OPALX_ASYNC_DEPTH / 16 * 16);
+    unsigned char* h = db->hHeader.p + (size_t)slot * (db->hHeader.cap / OPALX_ASYNC_DEPTH / 256 * 256);
+    unsigned char* d = db->header.p + (size_t)slot * (db->header.cap / OPALX_ASYNC_DEPTH / 256 * 256);
     memset(h, 0, head);
     memcpy(h + head, M, mb);
     if (Q) memcpy(h + head + mb, query, (size_t)Q);
-    if (opal_hip_memcpy_h2d(db->header.p, h, head + mb + (size_t)Q, db->main())) return 1;
+    if (opal_hip_memcpy_h2d(d, h, head + mb + (size_t)Q, db->main())) return 1;
     if (!db->hdrEv[slot]) db->hdrEv[slot] = opal_hip_event_create_untimed();
     db->hdrEvSet[slot] = db->hdrEv[slot] && !opal_hip_event_record(db->hdrEv[slot], db->main());
     if (!db->hdrEvSet[slot] && opal_hip_stream_sync(db->main())) return 1;  // (no event: the slot is free once the stream is idle)
-    db->ovfCount.p = (int*)db->header.p;
-    db->matrix.p = (int*)(db->header.p + head);
-    db->query.p = db->header.p + head + mb;
+    db->hdrDev = d;
+    db->ovfCount.p = (int*)d;
+    db->matrix.p = (int*)(d + head);
+    db->query.p = d + head + mb;
     return 0;
 }
 
@@ -451,6 +502,55 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
     if (!device_ok()) return OPAL_ERR_NO_SIMD_SUPPORT;
     const int wantEnd = searchType != OPAL_SEARCH_SCORE;
     const int P = db->numPairs;
+    // A QUEUED search (opalx_search_device_async) takes the stream the one before it did not: its grid is released when that one
+    // has started its last workgroup and fills the CUs it leaves (OpalxDb::Pipe). Everything below asks db->main() for "the"
+    // stream and gets this one.
+    struct PipeScope {
+        OpalxDb* db; bool piped = false; bool ok = false; int idx = 0;
+        ~PipeScope() {
+            OpalxDb::Pipe& pp = db->pipe;
+            if (piped) {
+                void* st = db->curStream;
+                if (ok && st) {
+                    if (!pp.resolved) pipe_resolve(db, st, false);  // (a search that launched nothing still keeps the order)
+                    if (!pp.done[idx]) pp.done[idx] = opal_hip_event_create_untimed();
+                    if (pp.done[idx] && !opal_hip_event_record(pp.done[idx], st)) {
+                        pp.prevKind = (pp.launched && !pp.untracked) ? 1 : 2;
+                        pp.prevTarget = db->startedTotal;
+                        pp.lastIdx = idx;
+                        if (idx == 1) pp.unjoined = true;
+                    } else ok = false;
+                }
+                pp.active = false; pp.resolved = true; pp.startEv = nullptr;
+                db->curStream = nullptr;
+                if (!ok) db->quiesce();  // (an error: nothing of this search stays in flight, and nothing waits for it)
+            }
+            // (a search outside the queue runs on mainStream behind everything -- main() has joined the second stream -- and has
+            // marked it `foreign`: the next queued search waits for all of it)
+        }
+    } scope{db};
+    if (db->asyncTimed && opts().pipeline != 0 && !db->gate.active) {
+        OpalxDb::Pipe& pp = db->pipe;
+        if (db->asyncHead == db->asyncTail) pp.prevKind = 0;  // (every queued search has been waited for: nothing of theirs is in flight)
+        if (!db->mainStream) db->main();
+        if (!db->pipeStream) db->pipeStream = opal_hip_stream_create();
+        if (!db->startedCtr.p && (!db->startedCtr.ensure(4) || opal_hip_memset32(db->startedCtr.p, 0, 4, db->main()) || opal_hip_stream_sync(db->main())))
+            return OPAL_ERR_NO_SIMD_SUPPORT;
+        if (db->mainStream && db->pipeStream) {
+            if (pp.foreign) {
+                // something else has been enqueued on mainStream since the last queued search (main() was handed out, and it made
+                // mainStream wait for the second stream first): an event behind all of it stands for "the search before"
+                if (!pp.done[0]) pp.done[0] = opal_hip_event_create_untimed();
+                if (!pp.done[0] || opal_hip_event_record(pp.done[0], db->mainStream)) return OPAL_ERR_NO_SIMD_SUPPORT;
+                pp.foreign = false; pp.unjoined = false;
+                pp.prevKind = 2; pp.lastIdx = 0;
+            }
+            scope.piped = true;
+            scope.idx = pp.prevKind != 0 ? (pp.lastIdx ^ 1) : 0;
+            db->curStream = scope.idx ? db->pipeStream : db->mainStream;
+            pp.active = true; pp.resolved = false; pp.untracked = false; pp.launched = false; pp.startEv = nullptr;
+        }
+    }
     void* const st = db->main();
     if (!st) return OPAL_ERR_NO_SIMD_SUPPORT;
     int rc = 0;
@@ -468,9 +568,14 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
         if (Q == 0)
             for (int i = 0; i < 2 * P; i++)
                 if (db->pairSeq[i] >= 0) add(db->pairSeq[i], db->pairLen[i]);
+        if (!quads.empty() && pipe_resolve(db, st, false)) return OPAL_ERR_NO_SIMD_SUPPORT;
         if (write_degenerate(db, quads, dScore, dEndQ, dEndT)) return OPAL_ERR_NO_SIMD_SUPPORT;
     }
-    if (Q == 0 || P == 0) return opal_hip_stream_sync(st) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
+    if (Q == 0 || P == 0) {
+        if (opal_hip_stream_sync(st)) return OPAL_ERR_NO_SIMD_SUPPORT;
+        scope.ok = true;
+        return 0;
+    }
 
     if (ensure_query_buffers(db, query, Q, M, A)) return OPAL_ERR_NO_SIMD_SUPPORT;  // (also zeroes the counters)
     if (db->clockProbe && db->timelineProbe && (!db->timeline.ensure(4 * 65536) || opal_hip_memset(db->timeline.p, 0, 4 * 65536 * sizeof(unsigned long long), st)))
@@ -576,7 +681,12 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
             if (!db->asyncEv[2 * slot + i]) db->asyncEv[2 * slot + i] = opal_hip_event_create();
         evStart = db->asyncEv[2 * slot]; evStop = db->asyncEv[2 * slot + 1];
     } else if (timed) { evStart = db->event(4); evStop = db->event(5); }
-    if (evStart) opal_hip_event_record(evStart, st);
+    if (scope.piped && evStart) db->pipe.startEv = evStart;  // (recorded behind the wait for the search before it: pipe_resolve)
+    else if (evStart) opal_hip_event_record(evStart, st);
+    // A 16-bit rung whose scores can reach its limit may leave a re-run list (db->ovfItems, one per handle) and reads its length
+    // back: such a search waits for the one before it and is waited for as a whole.
+    const bool canSaturate = (long long)std::min<long long>(Q, db->pairLen[0]) * maxS >= (long long)satLimit;
+    if (mode == OPAL_MODE_SW && (canSaturate || !fits16) && pipe_resolve(db, st, false)) return OPAL_ERR_NO_SIMD_SUPPORT;
 
     if (mode == OPAL_MODE_SW) {
         // rung 1: everything at 16 bits (if the inputs fit), saturated scores go to the re-run list.
@@ -597,6 +707,8 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                 a.side_first_item = 0; a.side_num_items = headItems;  // (the long head: class body, first workgroups of the launch)
                 a.prio_items = stream_prio_items(db, a.first_item, a.num_items, splan.G);
                 if (!gate_items(db, st, 0, 2 * P)) return OPAL_ERR_NO_SIMD_SUPPORT;
+                if (pipe_resolve(db, st, splan.passes == 1)) return OPAL_ERR_NO_SIMD_SUPPORT;  // (row chunks share db->boundary)
+                if (splan.passes == 1 && db->pipe.active) a.started_counter = db->startedCtr.p;
                 if (splan.passes > 1) {
                     // a query beyond one wave: row chunks from the top, the first one partial (as launch_chunked cuts them), a
                     // chunk's bottom row through db->boundary (4 bytes per residue), the hand-out counter zeroed in between
@@ -613,8 +725,10 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                         rc = opal_hip_launch_stream(&a, db->ovfCount.p + 2) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
                         count(CNT_CHUNK_LAUNCHES);
                     }
-                } else
-                rc = opal_hip_launch_stream(&a, db->ovfCount.p + 2) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
+                } else {
+                    rc = opal_hip_launch_stream(&a, db->ovfCount.p + 2) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
+                    if (!rc) pipe_launched_grid(db);
+                }
                 count(CNT_STREAM_SW);
             }
             else if (narrow == 16) rc = launch_range(c, 16, wantEnd, 0, nullptr, 0, nNarrow, pairLenOf, db->ovfCount.p);
@@ -627,6 +741,10 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                 if (wantEnd && swapRows > 16) swapRows = 16;  // (end cells: the 8- and 16-row shapes)
                 if (wantEnd && swapN > 0 && opal_hip_swap_lds_bytes(swapRows, Q, A) > 160 * 1024) swapN = 0;
                 void* joinSwap = nullptr;
+                // (before the fork: the side stream inherits the wait. A swapped launch shares nothing with the search before this one --
+                // its counters live in this search's header slot -- and its workgroups have started before the grid's do: the search
+                // stays "one grid" for the search queued behind it)
+                if (swapN > 0 && pipe_resolve(db, st, true)) return OPAL_ERR_NO_SIMD_SUPPORT;
                 if (swapN > 0) {
                     void* fork = db->event(11);
                     void* side = db->swap();
@@ -652,7 +770,6 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
             // The re-run list can only be non-empty if some score can reach the rung's limit at all: with
             // min(Q, longest sequence) * max(matrix) below it (a 300-aa query on BLOSUM50: 4 500 against 32 752) the
             // count need not be read back, and the search has no host round trip between its launches and its end.
-            const bool canSaturate = (long long)std::min<long long>(Q, db->pairLen[0]) * maxS >= (long long)satLimit;
             if (canSaturate && (opal_hip_memcpy_d2h(&cnt, db->ovfCount.p, sizeof(int), st) || opal_hip_stream_sync(st)))
                 return OPAL_ERR_NO_SIMD_SUPPORT;
             if (cnt > 0) {
@@ -740,7 +857,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                 // a query beyond one wave: row chunks from the top (NW: the last one partial, HW/OV: the first), a chunk's bottom
                 // row through the upper half of db->boundary (4 bytes per residue; the class-kernel chunks of the sequences that
                 // need 32 bits or cannot be skewed run beside this on a side stream and index the lower half by THEIR residues)
-                if (!gate_items(db, st, 0, 2 * P)) return 1;
+                if (!gate_items(db, st, 0, 2 * P) || pipe_resolve(db, st, false)) return 1;
                 if (!db->boundary.ensure(8 * ((size_t)db->residues + 16)) || !db->scratch.ensure(2 * (size_t)std::max(db->numSeqs, 1))) return 1;
                 const int cap = gplan.G * gplan.rows;
                 const int firstRows = Q - (gplan.passes - 1) * cap;
@@ -766,7 +883,11 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                 fprintf(stderr, "[opal] streaming launch mode=%d width=%d G=%d rows=%d items=[%d,+%d)\n", mode, gplan.width, gplan.G, gplan.rows,
                         a.first_item, a.num_items);
             count(CNT_STREAM_GLOBAL);
-            return (!gate_items(db, st, 0, 2 * P) || opal_hip_launch_stream(&a, db->ovfCount.p + 2)) ? 1 : 0;
+            if (!gate_items(db, st, 0, 2 * P) || pipe_resolve(db, st, true)) return 1;
+            if (db->pipe.active) a.started_counter = db->startedCtr.p;
+            if (opal_hip_launch_stream(&a, db->ovfCount.p + 2)) return 1;
+            pipe_launched_grid(db);
+            return 0;
         };
         // 32-bit safety (our definition where the reference is undefined, see oracle/opal_oracle.c):
         // sequences whose bound leaves [-2^30, 2^30] are not computed and the call returns OVERFLOW.
@@ -798,6 +919,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
             pairN = plan_pair(Q, A, mode, seqLenOf, nBad, 2 * P - nBad, db->residues, 2 * p32 - nBad, fits16, &rowsP, &wavesP);
             while (pairN > 0 && db->pairSeq[(size_t)nBad + pairN - 1] < 0) pairN--;  // (the absent last item of an odd count)
             if (pairN > 0 && pairN < 2 * p32 - nBad) pairN = 0;
+            if (pairN > 0 && pipe_resolve(db, st, true)) return OPAL_ERR_NO_SIMD_SUPPORT;  // (before the fork; as for the swapped launches of SW)
             if (pairN > 0) {
                 unsigned long long base = 0, words = 64;
                 for (int i = 0; i < nBad; i++) base += (unsigned long long)db->pairLen[(size_t)i];
@@ -809,8 +931,16 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                 a.rows_per_lane = rowsP; a.waves_per_block = wavesP; a.first_item = nBad; a.num_items = pairN; a.stream = side;
                 a.started_counter = db->ovfCount.p + 3;
                 if (debug_on()) fprintf(stderr, "[opal] pair launch mode=%d: items [%d,+%d) on %d waves x %d rows per lane\n", mode, nBad, pairN, wavesP, rowsP);
-                if ((wavesP > 1 && !db->pairBnd.ensure((size_t)(wavesP - 1) * (size_t)words, 1.25)) || !fork || !side || opal_hip_event_record(fork, st) ||
-                    opal_hip_stream_wait_event(side, fork) || !gate_items(db, side, nBad, pairN) || opal_hip_launch_pair(&a, db->pairBnd.p, base, words) ||
+                // (the rows the waves of a pair hand each other: one half of the buffer per stream of queued searches, which may overlap)
+                const size_t bndWords = (size_t)(wavesP > 1 ? wavesP - 1 : 0) * (size_t)words;
+                if (wavesP > 1 && db->pairBnd.would_realloc(2 * bndWords)) {
+                    // (growing frees the old buffer: nothing of the search before may still be using it)
+                    if (db->pipe.active && !db->pipe.resolved && pipe_resolve(db, st, false)) return OPAL_ERR_NO_SIMD_SUPPORT;
+                    if (db->pipe.active) { db->pipe.untracked = true; if (db->pipeStream) opal_hip_stream_sync(db->pipeStream); if (db->mainStream) opal_hip_stream_sync(db->mainStream); }
+                }
+                if ((wavesP > 1 && !db->pairBnd.ensure(2 * bndWords, 1.25)) || !fork || !side || opal_hip_event_record(fork, st) ||
+                    opal_hip_stream_wait_event(side, fork) || !gate_items(db, side, nBad, pairN) ||
+                    opal_hip_launch_pair(&a, db->pairBnd.p + ((db->pipe.active && db->curStream == db->pipeStream) ? db->pairBnd.cap / 2 : 0), base, words) ||
                     !(joinPair = db->event(12)) || opal_hip_event_record(joinPair, side) ||
                     (!opts().noStartedWait && opal_hip_wait_started(db->ovfCount.p + 3, pairN, st))) {
                     db->quiesce();
@@ -833,6 +963,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
             // (16 rows per lane -- half the steps -- measured for a handful of targets: 195-aa HW 6.5 -> 5.4 ms at best, but 9 ms in
             // every other run: a 103 KB workgroup finds room only on a CU with at most one bulk workgroup, i.e. only if it gets
             // there first; 54 KB fit beside three. 8 rows stay.)
+            if (swapG > 0 && pipe_resolve(db, st, true)) return OPAL_ERR_NO_SIMD_SUPPORT;  // (before the fork; as above)
             if (swapG > 0) {
                 void* fork = db->event(11);
                 void* side = db->swap();
@@ -868,6 +999,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
         // its sequences' residues -- two index spaces in one buffer; only test hooks get there, a query in row chunks runs at width 17 / 18)
         if (P > q32 && (2 * p32 > first32 || (chunkedQuery && gplan.G && gplan.passes > 1 && q32 > p32)) && !opts().noSidePrefix &&
             !(chunkedQuery && narrow == 16)) {
+            if (pipe_resolve(db, st, false)) return OPAL_ERR_NO_SIMD_SUPPORT;  // (before the fork)
             void* fork = db->event(8);
             void* side = chunkedQuery ? db->stream(0) : db->swap();
             if (fork && side && !opal_hip_event_record(fork, st) && !opal_hip_stream_wait_event(side, fork)) { c32.stream = side; join32 = db->event(9); }
@@ -903,15 +1035,17 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
             return OPAL_ERR_NO_SIMD_SUPPORT;
         }
     }
+    if (scope.piped && !db->pipe.resolved && pipe_resolve(db, st, false)) return OPAL_ERR_NO_SIMD_SUPPORT;  // (nothing launched: the start event still wants recording)
     if (evStop) { opal_hip_event_record(evStop, st); db->asyncEvents = db->asyncTimed; }
     // (a caller that copies the results back on the same stream and waits for that copy needs no wait of its own here)
     if ((finalSync || kernelMs) && opal_hip_stream_sync(st)) return OPAL_ERR_NO_SIMD_SUPPORT;
     if (kernelMs && evStart && evStop) *kernelMs = opal_hip_event_elapsed_ms(evStart, evStop);
     if (db->clockProbe && !db->asyncTimed) {  // (measurement runs only: one more small copy and wait; queued searches: opalx_db_last_clock_ghz reads it)
         unsigned long long v[2] = {0, 0};
-        if (!opal_hip_memcpy_d2h(v, db->header.p + 16, sizeof v, st) && !opal_hip_stream_sync(st) && v[1])
+        if (!opal_hip_memcpy_d2h(v, db->hdrDev + 16, sizeof v, st) && !opal_hip_stream_sync(st) && v[1])
             db->lastClockGhz = (double)v[0] / (double)v[1] * opal_hip_wall_clock_hz() * 1e-9;
     }
+    scope.ok = true;
     return rc;
 }
 

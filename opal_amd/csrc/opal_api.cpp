@@ -156,18 +156,29 @@ extern "C" int opalx_search_device_async(OpalxDb* db, const unsigned char* query
     return rc;
 }
 
-extern "C" int opalx_db_wait(OpalxDb* db, float* kernel_ms) {
+extern "C" int opalx_db_wait2(OpalxDb* db, float* kernel_ms, float* period_ms) {
     if (kernel_ms) *kernel_ms = 0.f;
+    if (period_ms) *period_ms = 0.f;
     if (!db) return OPAL_ERR_NO_SIMD_SUPPORT;
-    void* st = db->main();
-    if (!st) return OPAL_ERR_NO_SIMD_SUPPORT;
-    if (db->asyncTail == db->asyncHead) return opal_hip_stream_sync(st) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;  // nothing queued: the stream
+    if (db->asyncTail == db->asyncHead) {  // nothing queued: the streams
+        void* st = db->main();
+        if (!st) return OPAL_ERR_NO_SIMD_SUPPORT;
+        return opal_hip_stream_sync(st) ? OPAL_ERR_NO_SIMD_SUPPORT : 0;
+    }
     const int slot = (int)(db->asyncTail % OPALX_ASYNC_DEPTH);
+    const int before = (int)((db->asyncTail + OPALX_ASYNC_DEPTH - 1) % OPALX_ASYNC_DEPTH);  // (its events are not reused while fewer than DEPTH - 1 searches are queued)
+    const bool havePrev = db->asyncWaited > 0;
     db->asyncTail++;
     if (opal_hip_event_sync(db->asyncEv[2 * slot + 1])) return OPAL_ERR_NO_SIMD_SUPPORT;
+    db->asyncWaited++;
     if (kernel_ms) *kernel_ms = opal_hip_event_elapsed_ms(db->asyncEv[2 * slot], db->asyncEv[2 * slot + 1]);
+    if (period_ms && havePrev && db->asyncEv[2 * before + 1]) {
+        const float p = opal_hip_event_elapsed_ms(db->asyncEv[2 * before + 1], db->asyncEv[2 * slot + 1]);
+        *period_ms = p > 0.f ? p : 0.f;
+    }
     return 0;
 }
+extern "C" int opalx_db_wait(OpalxDb* db, float* kernel_ms) { return opalx_db_wait2(db, kernel_ms, nullptr); }
 
 extern "C" int opalx_search_host(OpalxDb* db, const unsigned char* query, int query_length, int gap_open, int gap_ext,
                                  const int* score_matrix, int alphabet_length, int search_type, int mode,

@@ -72,6 +72,9 @@ template <typename T> struct DevBuf {
         cap = p ? want : 0;
         return p != nullptr;
     }
+    bool would_realloc(size_t n) const {  // ensure(n) would free the buffer (nothing on the device may still be using it)
+        return !p || n > cap || (cap > 4 * std::max<size_t>(n, 1) && cap * sizeof(T) > (256u << 20));
+    }
     void release() { opal_hip_free(p); p = nullptr; cap = 0; }
 };
 template <typename T> struct PinBuf {
@@ -185,12 +188,38 @@ struct OpalxDb {
     bool asyncEvents = false;  // ... and recorded them
     // searches queued by opalx_search_device_async and not yet waited for: [asyncTail, asyncHead), slot = index % OPALX_ASYNC_DEPTH
     unsigned asyncHead = 0, asyncTail = 0;
+    unsigned asyncWaited = 0;  // searches waited for so far (opalx_db_wait2: the one before has a stop event to measure from)
     void* asyncEv[2 * OPALX_ASYNC_DEPTH] = {};   // their start / stop events (timed)
     // the pinned staging copies of the search header (query, matrix, zeroed counters): one slot per search in flight, reused
     // only after the upload recorded behind it has run
     unsigned hdrSeq = 0;
     void* hdrEv[OPALX_ASYNC_DEPTH] = {};
     bool hdrEvSet[OPALX_ASYNC_DEPTH] = {};
+    // Queued searches take turns on TWO streams (mainStream / pipeStream, ladder.cpp: SearchPipe): a search that is one grid counts
+    // its workgroups in as they start (startedCtr, cumulative, never zeroed), and the grid of the search queued behind it -- on the
+    // other stream, behind a one-wave wait kernel -- reaches the dispatcher when the last of them has: it fills the CUs the first one
+    // leaves as it drains (C2: a fixed 0.15-0.2 ms of fill and drain per 1.5 ms search on one stream). Whatever is not one grid
+    // (side launches, row chunks, a re-run list) waits for the whole search before it and is waited for as a whole.
+    void* pipeStream = nullptr;
+    void* curStream = nullptr;          // not null while search_core runs a queued search: the stream main() hands out
+    opal_host::DevBuf<int> startedCtr;  // [1]
+    unsigned startedTotal = 0;          // its value once every tracked grid launched so far has started all its workgroups
+    unsigned char* hdrDev = nullptr;    // the device header slot of the search enqueued last (header.p + slot * slot bytes)
+    struct Pipe {
+        bool active = false;      // search_core is running a queued search on curStream
+        bool resolved = true;     // ... its dependency on the search before it has been enqueued
+        bool untracked = false;   // ... it has launched something beside one tracked grid
+        bool launched = false;    // ... it has launched its tracked grid
+        void* startEv = nullptr;  // ... its start event, recorded behind the wait in front of its grid (nullptr: at the start of the search)
+        int lastIdx = 0;          // stream of the search enqueued last: 0 mainStream, 1 pipeStream
+        int prevKind = 0;         // the search enqueued last: 0 nothing in flight, 1 one tracked grid, 2 anything else
+        unsigned prevTarget = 0;  // kind 1: startedCtr once all its workgroups have started
+        void* done[2] = {nullptr, nullptr};  // event behind the last search on mainStream / pipeStream
+        bool unjoined = false;    // pipeStream carries work that mainStream has not been made to wait for
+        bool foreign = true;      // mainStream has been handed out outside a queued search since the last one: whatever was enqueued
+                                  // on it (a search outside the queue, the multi-GPU handle's peer copies behind a shard's search) the
+                                  // next queued search waits for as a whole
+    } pipe;
     bool clockProbe = false;   // opalx_db_clock_probe
     bool timelineProbe = false;
     opal_host::DevBuf<unsigned long long> timeline;  // [2 x 65536 workgroups] ticks, then [2 x 65536] shader cycles; zeroed before a probed search
@@ -242,7 +271,11 @@ struct OpalxDb {
     void* streams[3] = {nullptr, nullptr, nullptr};
     void* events[13] = {};  // 0 fork, 1-3 joins, 4-5 timing, 6 aux join, 7 fill, 8-10 fork / joins of the 32-bit and unskewable prefixes beside row chunks, 11-12 fork / join of the swapped launch
     void* main() {
+        if (curStream) return curStream;
         if (!mainStream) mainStream = opal_hip_stream_create();
+        // (outside a queued search: whatever the queued searches left on the second stream comes first)
+        if (pipe.unjoined && mainStream) { pipe.unjoined = false; if (pipe.done[1]) opal_hip_stream_wait_event(mainStream, pipe.done[1]); }
+        pipe.foreign = true;
         return mainStream;
     }
     void* copy() {
@@ -273,7 +306,9 @@ struct OpalxDb {
         if (copyStream2) opal_hip_stream_sync(copyStream2);
         if (auxStream) opal_hip_stream_sync(auxStream);
         if (swapStream) opal_hip_stream_sync(swapStream);
+        if (pipeStream) opal_hip_stream_sync(pipeStream);
         if (mainStream) opal_hip_stream_sync(mainStream);
+        pipe.prevKind = 0; pipe.unjoined = false;  // (nothing in flight any more)
     }
 };
 

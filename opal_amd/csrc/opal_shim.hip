@@ -22,6 +22,7 @@
 #include "options.hpp"
 
 static thread_local char g_err[512] = "";
+static thread_local int g_lastBlocks = 0;  // workgroups of the last class / one-launch / streaming grid this thread launched (opal_hip_last_launch_blocks)
 
 static int fail(const char* what, hipError_t e) {
     snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
@@ -492,7 +493,7 @@ extern "C" int opal_hip_launch_uber(const OpalHipUberLaunch* u) {
     b.ovfCount = a->overflow_count; b.ovfItems = a->overflow_items;
     b.chunkRows = a->query_length;
     b.satLimit = a->sat_limit; b.negPad = a->neg_pad;
-    b.clk = a->clock_probe; b.tl = a->timeline;
+    b.clk = a->clock_probe; b.tl = a->timeline; b.started = a->started_counter;
     size_t lds = 0;
     int blocks = 0;
     for (int k = 0; k < 3; k++) {
@@ -511,6 +512,7 @@ extern "C" int opal_hip_launch_uber(const OpalHipUberLaunch* u) {
     if (a->lds_bytes_min > 0 && (size_t)a->lds_bytes_min > lds && a->lds_bytes_min <= 160 * 1024) lds = (size_t)a->lds_bytes_min;
     if (lds > 160 * 1024) { snprintf(g_err, sizeof g_err, "query profile needs %zu bytes of LDS (>160 KiB)", lds); return 2; }
     if (lds > 64 * 1024 && raise_lds_limit((const void*)fn)) return 1;
+    g_lastBlocks = blocks;
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(WAVES_PER_BLOCK * 64), lds, (hipStream_t)a->stream, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("one-launch kernel launch", e);
@@ -551,7 +553,7 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
     p.scratch = a->scratch;
     p.satLimit = a->sat_limit;
     p.negPad = a->neg_pad;
-    p.clk = a->clock_probe; p.tl = a->timeline;
+    p.clk = a->clock_probe; p.tl = a->timeline; p.started = a->started_counter;
     const int slots = 64 / G;
     const int jobs = (a->num_items + slots - 1) / slots;
     const int maxWpb = opal_max_waves_per_block(a->width);
@@ -570,6 +572,7 @@ extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
         return 2;
     }
     if (lds > 64 * 1024 && raise_lds_limit((const void*)fn)) return 1;
+    g_lastBlocks = blocks;
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(wpb * 64), lds, (hipStream_t)a->stream, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("kernel launch", e);
@@ -648,7 +651,7 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
     p.bnd = (uint2*)a->boundary;
     p.scratch = a->scratch;
     p.satLimit = a->sat_limit; p.negPad = a->neg_pad;
-    p.clk = a->clock_probe; p.tl = a->timeline;
+    p.clk = a->clock_probe; p.tl = a->timeline; p.started = a->started_counter;
     sp.next = next_counter;
     sp.prioItems = a->prio_items > 0 ? a->prio_items : 0;
     // persistent workgroups: one per CU (16 waves = 4 per SIMD), fewer when there are not enough sequences to go round
@@ -682,6 +685,7 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
         blocks = std::max(std::min(blocks, cus / 2), cus - sp.sideBlocks - a->reserve_blocks);
     if (opal_host::opts().streamBlocks >= 1) blocks = opal_host::opts().streamBlocks;  // test hook
     if (ldsLaunch > 64 * 1024 && raise_lds_limit((const void*)fn)) return 1;
+    g_lastBlocks = blocks + sp.sideBlocks;
     hipLaunchKernelGGL(fn, dim3(blocks + sp.sideBlocks), dim3(STREAM_WAVES * 64), ldsLaunch, (hipStream_t)a->stream, sp);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("streaming kernel launch", e);
@@ -747,6 +751,28 @@ extern "C" int opal_hip_wait_started(const int* counter, int target, void* strea
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("wait kernel launch", e);
 }
+
+// One wave that ends when a CUMULATIVE counter (never zeroed: every workgroup of every tracked launch adds one when it starts,
+// KParams::started) has reached `target` -- compared as a signed difference, so the counter may wrap. What a queued search puts in
+// front of its grid on its own stream so that the grid reaches the dispatcher when the search before it (on the other stream) has
+// no workgroup left to dispatch: it then fills the CUs that one leaves as it drains. Gives up after `timeout_ticks` of the
+// constant-rate counter (never a deadlock: at worst the two grids share the dispatcher from then on).
+__global__ void __launch_bounds__(64) opal_wait_count_kernel(const int* counter, int target, unsigned long long timeout_ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while ((int)((unsigned)__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)target) < 0) {
+        if (wall_clock64() - t0 > timeout_ticks) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+extern "C" int opal_hip_wait_count(const int* counter, int target, void* stream) {
+    if (!counter) return 0;
+    const unsigned long long ticks = (unsigned long long)(0.5 * opal_hip_wall_clock_hz());  // half a second
+    hipLaunchKernelGGL(opal_wait_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, target, ticks);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("wait kernel launch", e);
+}
+extern "C" int opal_hip_last_launch_blocks(void) { return g_lastBlocks; }
 
 // ------------------------------------------------------------------ role-swapped SW score search (swap_kernel.hpp)
 // Rows per lane: a chunk profile of 64 x rows residues for every query letter. The workgroup shares its CU with the

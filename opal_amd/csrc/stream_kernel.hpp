@@ -166,6 +166,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     constexpr int LANE_BYTES = opal_lane_bytes(ES, S, 1);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const KParams& p = sp.base;
+    count_started(p.started);
     if constexpr (SIDE) {  // (instantiations of their own, inst_stream17head.hip: inside the plain kernels the extra body cost C4 1.1 %)
         if ((int)blockIdx.x < sp.sideBlocks) {
             // The head of a long-tailed database (Swiss-Prot: 35 000 residues among 350): sequences that would pin their G lanes
@@ -547,6 +548,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
     constexpr int LANE_BYTES = opal_lane_bytes(ES, S, 1);
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const KParams& p = sp.base;
+    count_started(p.started);
     if ((int)blockIdx.x < sp.sideBlocks) {
         // The sequences whose skewed values could leave 16 bits (the longest ones, a handful): the class body with plain
         // arithmetic, in the same launch and ahead of the streaming workgroups in dispatch order. (As a separate launch on

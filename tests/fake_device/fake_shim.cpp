@@ -295,6 +295,10 @@ int opal_hip_launch_pair(const OpalHipLaunch* a, void*, unsigned long long, unsi
     return enqueue(c.stream, [c] { run_items(c, Range{c.first_item, c.num_items}, false); });
 }
 int opal_hip_wait_started(const int*, int, void*) { return 0; }  // (the fake streams have no dispatcher to race for)
+// queued searches on two streams: no wait at all here, so that consecutive one-grid searches really run at the same time on
+// their two worker threads -- whatever they share unprotected, ThreadSanitizer sees
+int opal_hip_wait_count(const int*, int, void*) { return 0; }
+int opal_hip_last_launch_blocks(void) { return 1; }
 int opal_hip_launch_swap(const OpalHipLaunch* a) {
     OpalHipLaunch c = *a;
     if (c.mode == OPAL_MODE_SW) c.width = 17;  // (16-bit arithmetic with the re-run list, like the class kernels)
