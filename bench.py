@@ -73,6 +73,8 @@ def parse_args(argv=None):
                     "launches: profiles/r05_clock_c2.txt); 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="default c2 run only: skip the strong-scaling legs `also.c4` / `also.c5` (BASELINE.json "
+                    "configs[3] / [4]: P18080 and a 2000-aa query x 5 000 000 sequences in total, sharded over the N GPUs)")
     ap.add_argument("--query-fasta", default=None, help="use the first record of this FASTA file as the query")
     args = ap.parse_args(argv)
     wl = args.workload
@@ -301,6 +303,102 @@ def e2e_call(query, res_host, offs, matrix, gap_open, gap_ext, search_type, mode
         ok = ok and bool((words[:, 0] == 1).all() and (words[:, 1] == want_scores).all())
     return cold, same, ok
 
+def strong_leg(name, query, total, rank, world, multi, backend, dev, matrix, gap_open, gap_ext, mode, steps=5, warmup=1):
+    """One strong-scaling leg of the default run (BASELINE.json configs[3] / [4]): `query` x the first `total`
+    sequences of the synthetic database, DEALT to the ranks (64-sequence groups by residue count), SW score-only; per step every
+    rank searches its shard and the scores are gathered to rank 0 (the path's one exchange). Same bracket as the headline:
+    barrier + synchronize on both sides of exactly `steps` steps, the maximum over the ranks; a sample of every rank's shard is
+    checked against the CPU oracle (checker only). Every rank calls this; rank 0 gets the dictionary, the others None."""
+    import torch
+    import torch.distributed as dist
+    import oracle_lib
+    from opal_amd import shard, synth
+    from opal_amd.api import PreparedDb
+    all_lens = synth.lengths(42, 0, total)
+    owned_lists = shard.deal(all_lens, world) if multi else [np.arange(total, dtype=np.int64)]
+    owned = owned_lists[rank]
+    n = len(owned)
+    lens = all_lens[owned]
+    npad = max(len(o) for o in owned_lists)
+    d_res, offs = synth.residues_device(owned, lens, 42, dev)
+    torch.cuda.synchronize()
+    pdb = PreparedDb(None, offs, device_ptr=d_res.data_ptr())
+    outs = [torch.zeros(npad, dtype=torch.int32, device=dev) for _ in range(2)]
+    plan = shard.GatherPlan(owned_lists, 1, dev if backend == "nccl" else "cpu", root=rank == 0) if multi else None
+    torch.cuda.synchronize()
+    rdev = dev if backend == "nccl" else torch.device("cpu")
+    kms, xms = [], []
+
+    def fence():
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(i):
+        o = outs[i & 1]
+        rc, k = pdb.search_device(query, gap_open, gap_ext, matrix, 0, mode, o.data_ptr())
+        if rc != 0:
+            raise SystemExit(f"also.{name}: search failed rc={rc}")
+        kms.append(k)
+        if multi:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            plan.gather(o if backend == "nccl" else o.cpu(), rank)
+            b.record()
+            xms.append((a, b))
+    for i in range(warmup):
+        step(i)
+    kms.clear(); xms.clear()
+    for o in outs:
+        o.fill_(-2147483647)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=rdev)
+    rank_k = torch.zeros(world, dtype=torch.float64, device=rdev)
+    rank_k[rank] = float(np.mean(kms))
+    # a sample of this rank's shard against the oracle
+    mine = outs[(steps - 1) & 1].cpu().numpy()[:n]
+    rng = np.random.RandomState(11 + rank)
+    pick = np.unique(np.concatenate([rng.choice(n, min(n, 40), replace=False), np.argsort(lens)[-2:]]))
+    sres, soffs, _ = synth.database_subset(owned[pick], 42, lens=lens[pick])
+    sdb = [sres[soffs[i]:soffs[i + 1]] for i in range(len(pick))]
+    orc, so, _, _ = oracle_lib.Oracle().search(query, sdb, gap_open, gap_ext, matrix, 0, mode)
+    ok = bool(orc == 0 and (mine[pick] == so).all())
+    vflag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=rdev)
+    if multi:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rank_k, op=dist.ReduceOp.SUM)
+        dist.all_reduce(vflag, op=dist.ReduceOp.MIN)
+    out = None
+    if rank == 0:
+        dt = float(tmax.item())
+        cells = float(len(query)) * float(all_lens.astype(np.int64).sum())
+        rank_cells = [float(all_lens[o].astype(np.int64).sum()) for o in owned_lists]
+        rk = [float(v) for v in rank_k.cpu().numpy()]
+        verified = bool(int(vflag.item()) == 1)
+        if multi:  # the gathered block holds rank 0's own values at their database indices
+            verified = verified and bool((plan.glob.cpu().numpy()[0][owned] == mine).all())
+            torch.cuda.synchronize()
+        peak = valu_peak_gcups(9.0)
+        out = {"workload": f"{name}: {len(query)}-aa query x {total} synthetic sequences in total (seed 42), SW score-only, gaps {gap_open}/{gap_ext}, "
+                           f"dealt to {world} GPU(s) in 64-sequence groups by residue count, one gather of the scores per step",
+               "value": round(cells * steps / dt / 1e9, 1), "unit": "GCUPS", "scaling": "strong", "steps": steps, "warmup": warmup,
+               "ms_per_step": round(dt / steps * 1e3, 3),
+               "kernel_ms_per_rank": [round(v, 3) for v in rk],
+               "kernel_gcups_slowest_rank": round(cells / (max(rk) * 1e-3) / 1e9, 1),
+               "frac_of_valu_bound_all_gpus": round(cells / (max(rk) * 1e-3) / 1e9 / (peak * world), 4),
+               "imbalance": round(max(rank_cells) / (sum(rank_cells) / len(rank_cells)), 5),
+               "exchange_ms": round(float(np.mean([a.elapsed_time(b) for a, b in xms])), 4) if xms else None,
+               "verified": verified}
+    pdb.close()
+    del d_res, outs, plan
+    torch.cuda.empty_cache()
+    return out
+
 
 def main():
     args = parse_args()
@@ -444,21 +542,28 @@ def main():
                 period_ms.append(per)
             return
         else:
-            # the search is only ENQUEUED; while the GPU works on it the host issues the previous step's exchange (its
-            # Python / RCCL call overhead, ~0.2 ms, would otherwise sit between two searches), then waits for the search
+            # N > 1: the same two searches in flight; the host waits for step i-1 and issues ITS exchange (the path's one gather:
+            # ~0.2 ms of Python / RCCL call overhead) while the GPU is on step i, whose grid was released when step i-1 had
+            # started its last workgroup
             rc = pdb.search_device_async(query, args.gap_open, args.gap_ext, matrix, args.search_type, mode, score.data_ptr(),
                                          endq.data_ptr() if want_end else 0, endt.data_ptr() if want_end else 0)
             if rc == 0 and pending[0] is not None:
-                exchange(pending[0])
-            rc2, kms = pdb.wait()
-            rc = rc or rc2
+                rc, kms, per = pdb.wait2()
+                if rc == 0:
+                    kernel_ms.append(kms)
+                    period_ms.append(per)
+                    exchange(pending[0])
             pending[0] = b
         if rc != 0:
             raise SystemExit(f"search failed rc={rc}")
-        kernel_ms.append(kms)
 
     def flush():
         if multi and pending[0] is not None:
+            rc, kms, per = pdb.wait2()
+            if rc != 0:
+                raise SystemExit(f"search failed rc={rc}")
+            kernel_ms.append(kms)
+            period_ms.append(per)
             exchange(pending[0])
             pending[0] = None
         if not multi and inflight[0] == 1:  # the last step's search
@@ -555,7 +660,7 @@ def main():
     # first timed search's period starts at the last warm-up search's end, across the untimed poisoning of the buffers: left out.
     launch_kms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     my_kms = launch_kms
-    if not multi and len(period_ms) >= 3 and all(v > 0 for v in period_ms[1:]):
+    if len(period_ms) >= 3 and all(v > 0 for v in period_ms[1:]):
         my_kms = float(np.mean(period_ms[1:]))
     rank_kms = torch.zeros(world, dtype=torch.float64, device=rdev)
     rank_kms[rank] = my_kms
@@ -647,12 +752,13 @@ def main():
                                    f"{int(all_lens.max())}, {'fixed total' if strong else str(args.seqs) + ' per GPU'}), {what}, BLOSUM50, gaps "
                                    f"{args.gap_open}/{args.gap_ext}, 16-bit first rung, 32-bit re-run",
                        "cells_per_step": total_cells, "cells_per_step_rank0": cells,
-                       "parallelism": f"db-shard x{world} (64-seq groups dealt by residue count), 1 gather" if world > 1 else
+                       "parallelism": (f"db-shard x{world} (64-seq groups dealt by residue count), 1 gather per step, issued while the GPU is on the next "
+                                       "search; two searches queued per rank, on two streams in turn") if world > 1 else
                                       ("one GPU, results written at their database index; " +
                                        ("two searches queued on the handle (step i enqueued behind step i-1, then step i-1 waited for), on two streams in turn: the grid of "
                                         "search i is released when search i-1 has started its last workgroup and fills the CUs it leaves (OPAL_HIP_PIPELINE=0: one stream)" if args.in_flight == 2
                                         else "one search at a time: enqueued, waited for"))},
-            "in_flight": 1 if multi else args.in_flight,
+            "in_flight": 2 if multi else args.in_flight,
             "settle": {"ms": args.settle_ms, "steps": settle_steps,
                        "what": "untimed steps before the W warm-up steps, so that the timed region does not start on the clock governor's ramp "
                                "(shader clock 2.07 GHz after an idle gap, 2.38 after ~20 ms of back-to-back launches: profiles/r05_clock_c2.txt)"},
@@ -722,10 +828,40 @@ def main():
                 if not e2e_ok:
                     res_line["verified"] = False
                     status = 3
+                # ... and the prepared multi-GPU handle (opalx_multi_*: shards stay packed on their GPUs, results gathered on
+                # devices[0] and permuted into database order there), once per gather kind: peer copies, one ncclGather per search
+                from opal_amd.api import PreparedMultiDb
+                devlist = [0] * world if os.environ.get("BENCH_SHARE_GPU") == "1" else list(range(world))
+                handle = {}
+                for kind in ("peer", "rccl"):
+                    opal_amd.set_option("OPAL_HIP_MULTI_GATHER", kind)
+                    mh = PreparedMultiDb(hres, hoffs, devlist)
+                    L = _lib.lib()
+                    L.opalx_multi_gather_kind.restype = C.c_int
+                    L.opalx_multi_gather_kind.argtypes = [C.c_void_p]
+                    used = "rccl" if L.opalx_multi_gather_kind(mh._h) == 1 else "peer"
+                    mo = torch.full((total,), -7, dtype=torch.int32, device=dev)
+                    torch.cuda.synchronize()
+                    ts = []
+                    for _ in range(12):
+                        t1 = time.perf_counter()
+                        rcm, _k = mh.search_device(query, args.gap_open, args.gap_ext, matrix, 0, mode, mo.data_ptr())
+                        ts.append((time.perf_counter() - t1) * 1e3)
+                    okm = bool(rcm == 0 and (mo.cpu().numpy() == gscore).all())
+                    handle[kind] = {"gather_used": used, "ms": round(float(np.median(ts[2:])), 3),
+                                    "gcups": round(total_cells / (float(np.median(ts[2:])) * 1e-3) / 1e9, 1), "scores_match": okm}
+                    mh.close()
+                    if not okm:
+                        res_line["verified"] = False
+                        status = 3
+                res_line["multi_handle"] = dict(handle, what=f"opalx_multi_search_device from this process over {world} GPUs, whole database "
+                                                             "(scores in database order on devices[0]), wall clock per call, median of 10")
             except Exception as e:  # noqa: BLE001 -- the line must still be printed
-                res_line["e2e"] = {"error": repr(e)[:300]}
+                res_line.setdefault("e2e", {"error": repr(e)[:300]})
+                res_line["multi_handle_error"] = repr(e)[:300]
             finally:
                 opal_amd.set_option("OPAL_HIP_DEVICES", None)
+                opal_amd.set_option("OPAL_HIP_MULTI_GATHER", None)
         if world == 1 and not args.no_e2e and args.workload == "c2" and (args.mode, args.search_type) == ("SW", 0):
             # SURVEY.md 8d asks for both gap settings of the workload; the other one is timed here, outside the
             # K timed steps (11/1: nothing exceeds the 8-bit range of the reference; 3/1: the reference's CLI default)
@@ -775,6 +911,32 @@ def main():
         else:
             store.wait(["bench_rank0_done"])
         dist.barrier()
+    # ---- the default run also carries north_star's strong-scaling table (BASELINE.json configs[3] and [4]), so that the driver's
+    # N = 1, 2, 4, 8 runs give the C4 / C5 curve as well: P18080 and a 2000-aa query x 5 000 000 sequences IN TOTAL, dealt to the N
+    # GPUs, 5 timed steps each, outside the headline's timed region. (BENCH_ALSO_TOTAL: a smaller total, for rehearsals on one GPU.)
+    default_run = (args.workload == "c2" and args.seqs == 100000 and args.total_seqs is None and args.qlen == 300 and args.mode == "SW"
+                   and args.search_type == 0 and not args.query_fasta)
+    if default_run and not args.no_also and os.environ.get("BENCH_FORCE_DIST") != "1":
+        also_total = int(os.environ.get("BENCH_ALSO_TOTAL", "5000000"))
+        pdb.close()
+        del d_res, outs, plan
+        torch.cuda.empty_cache()
+        legs = {}
+        for leg, q in (("c4", read_fasta(os.path.join(ROOT, "tests", "golden", "data", "query_P18080.fasta"), alphabet)[0]),
+                       ("c5", synth.query(2000, seed=7))):
+            try:
+                r = strong_leg(leg, q, also_total, rank, world, multi, backend, dev, matrix, 11, 1, MODES["SW"])
+            except Exception as e:  # noqa: BLE001 -- the headline line must still be printed (a rank that fails here ends the group: the launcher reports it)
+                r = {"error": repr(e)[:300]}
+                if multi:
+                    raise
+            if rank == 0:
+                legs[leg] = r
+                if not (r or {}).get("verified", False):
+                    status = status or 3
+        if rank == 0:
+            res_line.setdefault("also", {}).update(legs)
+    if multi:
         dist.destroy_process_group()
     if rank == 0:
         sys.stdout.flush()

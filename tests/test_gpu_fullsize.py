@@ -474,7 +474,7 @@ def test_two_rank_bench_on_one_gpu():
     r = two["ranks"]
     assert len(r["kernel_ms"]["per_rank"]) == 2 and 0 < r["kernel_ms"]["min"] <= r["kernel_ms"]["max"]
     assert 1.0 <= r["imbalance"] < 1.02 and r["exchange_ms"] > 0
-    assert one["in_flight"] == 2 and two["in_flight"] == 1 and one["ranks"]["exchange_ms"] is None
+    assert one["in_flight"] == 2 and two["in_flight"] == 2 and one["ranks"]["exchange_ms"] is None
     # ... and the drop-in call over both "GPUs" from one process (OPAL_HIP_DEVICES=0,0 here), the other rank waiting on the store
     two_e2e = _run_bench(["--gpus", "2", "--total-seqs", "30000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
                          {"BENCH_SHARE_GPU": "1", "BENCH_BACKEND": "gloo"})
@@ -485,6 +485,29 @@ def test_two_rank_bench_on_one_gpu():
     two = _run_bench(["--gpus", "2"] + common, {"BENCH_SHARE_GPU": "1", "BENCH_BACKEND": "gloo"})
     assert one["verified"] and two["verified"] and two["n_gpus"] == 2
     assert one["verify"]["score_crc32"] == two["verify"]["score_crc32"]
+
+
+def test_default_run_carries_the_strong_scaling_legs():
+    """What the driver's N = 1, 2, 4, 8 runs of `bench.py --gpus N` (default flags) print: the weak-scaled C2 headline AND, in
+    `also`, north_star's strong-scaling legs -- P18080 (C4) and a 2000-aa query (C5) x one total database dealt to the N GPUs, with
+    every rank's kernel time, the deal's imbalance, the exchange time and a verdict of their own. Rehearsed here with a reduced
+    total (BENCH_ALSO_TOTAL) at N = 1 and, over gloo on the one GPU, N = 2 (which also times the in-library multi-GPU handle
+    with both gather kinds): the same cells per step at both N (strong scaling), both verified."""
+    common = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--settle-ms", "0"]
+    env = {"BENCH_ALSO_TOTAL": "150000"}
+    one = _run_bench(["--gpus", "1", "--no-e2e"] + common, env)
+    two = _run_bench(["--gpus", "2"] + common, dict(env, BENCH_SHARE_GPU="1", BENCH_BACKEND="gloo"))
+    for line, n in ((one, 1), (two, 2)):
+        assert line["verified"] and line["scaling"] == "weak" and line["n_gpus"] == n
+        for leg, qlen in (("c4", 513), ("c5", 2000)):
+            r = line["also"][leg]
+            assert r["verified"] and r["scaling"] == "strong" and r["value"] > 0, r
+            assert len(r["kernel_ms_per_rank"]) == n and min(r["kernel_ms_per_rank"]) > 0 and 1.0 <= r["imbalance"] < 1.02
+            assert (r["exchange_ms"] is None) == (n == 1)
+            assert f"{qlen}-aa query x 150000" in r["workload"]
+    mh = two["multi_handle"]
+    assert mh["peer"]["scores_match"] and mh["rccl"]["scores_match"] and mh["peer"]["ms"] > 0
+    assert mh["peer"]["gather_used"] == "peer"  # (one GPU listed twice: RCCL refuses, the handle falls back)
 
 
 def test_eight_rank_bench_on_one_gpu():
