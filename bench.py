@@ -11,6 +11,10 @@ Workloads (BASELINE.json `configs`):
   c3            the c2 database, --mode NW|HW|OV|SW with end locations
   c4            P18080 (513 aa) x 5 000 000 synthetic sequences in total, sharded over the GPUs        -> "strong"
   c5            2000-aa synthetic query on the c4 database (16 -> 32 bit re-run ladder)                 -> "strong"
+  c5x3          BASELINE.json configs[4] as written -- "forcing 16/32-bit overflow re-run": BLOSUM50 cannot push a 2000-aa
+                alignment past 16 bits, so the forced re-run comes from a x3-scaled matrix and PLANTED copies of
+                the query (--planted, default 1 % of the sequences; exact copies and copies with 20 substitutions) among
+                100 000 synthetic sequences: the 16-bit rung lists them, the 32-bit rung re-runs them in row chunks  -> "strong"
   sprot         the shape the reference was published on (reference aligner_comparison.md:6-34): 541 762 sequences with a
                 Swiss-Prot-like length tail (up to 35 213 residues), gaps 3/1, SW score-only, the published queries
                 O74807 / P19930 / Q3ZAI3 / P18080 (--query-fasta picks the timed one, default P18080)  -> "strong"
@@ -59,7 +63,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5", "sprot"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5", "c5x3", "sprot"])
     ap.add_argument("--seqs", type=int, default=None, help="database sequences per GPU (weak scaling)")
     ap.add_argument("--total-seqs", type=int, default=None, help="database sequences in total (strong scaling)")
     ap.add_argument("--qlen", type=int, default=None)
@@ -71,6 +75,7 @@ def parse_args(argv=None):
     ap.add_argument("--settle-ms", type=float, default=40.0, help="untimed steps for this many ms BEFORE the W warm-up steps: the GPU's clock "
                     "governor raises the shader clock with sustained activity (2.07 GHz after an idle gap, 2.38 after ~20 ms of back-to-back "
                     "launches: profiles/r05_clock_c2.txt); 0 = none")
+    ap.add_argument("--planted", type=float, default=0.01, help="c5x3: fraction of the sequences replaced by copies of the query")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="default c2 run only: skip the strong-scaling legs `also.c4` / `also.c5` (BASELINE.json "
@@ -87,7 +92,9 @@ def parse_args(argv=None):
         args.query_fasta = os.path.join(data, "query_P18080.fasta")
     if args.gap_open is None:
         args.gap_open = 3 if wl == "sprot" else 11
-    if wl == "c5" and args.qlen is None:
+    if wl == "c5x3" and args.total_seqs is None and args.seqs is None:
+        args.total_seqs = 100000
+    if wl in ("c5", "c5x3") and args.qlen is None:
         args.qlen = 2000
     if args.qlen is None:
         args.qlen = 300
@@ -472,12 +479,32 @@ def main():
     # ---- this rank's shard of the one global database. One rank: the database in its own order (results land at their
     # database index). Several: 64-sequence groups dealt by residue count (opal_amd/shard.py).
     all_lens = synth.lengths(42, 0, total, args.dist)
+    planted_ids = np.zeros(0, dtype=np.int64)
+    if args.workload == "c5x3":
+        # every k-th sequence becomes a copy of the query (odd ones of them with 20 substitutions at fixed seeds): under the x3
+        # matrix they score beyond 32 767 - 45, the 16-bit rung hands them to the re-run list, the 32-bit rung computes them
+        matrix = np.ascontiguousarray(matrix * 3, np.int32)
+        nplant = max(1, int(round(total * args.planted)))
+        planted_ids = (np.arange(nplant, dtype=np.int64) * total) // nplant
+        all_lens = all_lens.copy()
+        all_lens[planted_ids] = args.qlen
     owned_lists = shard.deal(all_lens, world) if multi else [np.arange(total, dtype=np.int64)]
     owned = owned_lists[rank]
     n = len(owned)
     npad = max(len(o) for o in owned_lists)
     lens = all_lens[owned]
     d_res, offs = synth.residues_device(owned, lens, 42, dev, stride=stride)
+    if len(planted_ids):
+        mine_planted = np.nonzero(np.isin(owned, planted_ids))[0]
+        if len(mine_planted):
+            rows = np.tile(np.asarray(query, np.uint8), (len(mine_planted), 1))
+            for r, li in enumerate(mine_planted):
+                if int(owned[li]) & 1:
+                    rr = np.random.RandomState(1000 + int(owned[li]) % 100000)
+                    pos = rr.choice(args.qlen, 20, replace=False)
+                    rows[r, pos] = rr.randint(0, 20, 20).astype(np.uint8)
+            idx = (torch.as_tensor(offs[mine_planted], device=dev).unsqueeze(1) + torch.arange(args.qlen, device=dev).unsqueeze(0)).reshape(-1)
+            d_res[idx] = torch.as_tensor(rows.reshape(-1), device=dev)
     torch.cuda.synchronize()  # the library reads the buffer on its own stream: everything that produced it must be complete
     pdb = PreparedDb(None, offs, device_ptr=d_res.data_ptr())
     cells = float(args.qlen) * float(offs[-1])
@@ -639,8 +666,13 @@ def main():
     pick = np.sort(rng.choice(n, nsamp, replace=False))
     if args.dist == "sprot":  # the long tail must be part of the sample
         pick = np.unique(np.concatenate([pick, np.argsort(lens)[-3:]]))
-    sres, soffs, _ = synth.database_subset(owned[pick], 42, lens=lens[pick], stride=stride)
-    sdb = [sres[soffs[i]:soffs[i + 1]] for i in range(len(pick))]
+    if len(planted_ids):  # (planted copies among them: their residues are what the device buffer holds)
+        mp = np.nonzero(np.isin(owned, planted_ids))[0]
+        pick = np.unique(np.concatenate([pick[: max(20, nsamp // 3)], mp[:6]]))
+        sdb = [d_res[int(offs[i]):int(offs[i + 1])].cpu().numpy() for i in pick]
+    else:
+        sres, soffs, _ = synth.database_subset(owned[pick], 42, lens=lens[pick], stride=stride)
+        sdb = [sres[soffs[i]:soffs[i + 1]] for i in range(len(pick))]
     orc_rc, os_, oq, ot = oracle_lib.Oracle().search(query, sdb, args.gap_open, args.gap_ext, matrix, args.search_type, mode)
     ok_local = bool(orc_rc == 0 and (mine[0][pick] == os_).all()) and not untouched
     if want_end:
@@ -752,6 +784,11 @@ def main():
                                    f"{int(all_lens.max())}, {'fixed total' if strong else str(args.seqs) + ' per GPU'}), {what}, BLOSUM50, gaps "
                                    f"{args.gap_open}/{args.gap_ext}, 16-bit first rung, 32-bit re-run",
                        "cells_per_step": total_cells, "cells_per_step_rank0": cells,
+                       **({"rerun": {"matrix": "BLOSUM50 x 3", "planted_copies_of_the_query": int(len(planted_ids)),
+                                     "sequences_re_run_at_32_bits": int((gscore >= 32767 - int(matrix.max())).sum()),
+                                     "re_run_cells_share": round(float(args.qlen) * float(all_lens[planted_ids].astype(np.int64).sum()) / total_cells, 4),
+                                     "what": "scores at or beyond 32 767 - max(matrix) leave the 16-bit rung for the re-run list; their cells are "
+                                             "computed twice and counted once (reference opal_aligner.cpp:203-207)"}} if len(planted_ids) else {}),
                        "parallelism": (f"db-shard x{world} (64-seq groups dealt by residue count), 1 gather per step, issued while the GPU is on the next "
                                        "search; two searches queued per rank, on two streams in turn") if world > 1 else
                                       ("one GPU, results written at their database index; " +

@@ -116,10 +116,9 @@ typedef struct OpalHipLaunch {
     /* opal_hip_launch_stream: the waves working on the first prio_items sequences handed out (the longest of the range) run at
        a raised issue priority (0: none) */
     int prio_items;
-    /* NULL, or a device counter that every workgroup of the launch increments when it starts. opal_hip_launch_swap /
-       opal_hip_launch_pair: zeroed by the caller, waited for with opal_hip_wait_started. opal_hip_launch /
-       opal_hip_launch_uber / opal_hip_launch_stream: a cumulative counter that is never zeroed, waited for with
-       opal_hip_wait_count (queued searches that take turns on two streams) */
+    /* NULL, or a device counter (zeroed by the caller: the search header) that every workgroup of the launch increments when it
+       starts: opal_hip_wait_started (the grids of a search behind its swapped / pair workgroups), opal_hip_wait_count (the
+       grid of the NEXT queued search behind this one's last workgroup) */
     int* started_counter;
 } OpalHipLaunch;
 
@@ -173,11 +172,13 @@ int opal_hip_launch_pair(const OpalHipLaunch* args, void* boundary, unsigned lon
    that fills every CU with workgroups of 39 KB of LDS otherwise starves a 55 KB workgroup arriving a moment later until
    it drains: one retiring workgroup never frees enough (541 762 sequences, 300-aa query: 8.5 ms or 12.5 from run to run). */
 int opal_hip_wait_started(const int* counter, int target, void* stream);
-/* The same for a CUMULATIVE counter (OpalHipLaunch::started_counter of the class / one-launch / streaming launches: never
-   zeroed, may wrap): ends when (int)(*counter - target) >= 0, or after half a second. opal_hip_last_launch_blocks: the grid size
-   of the last such launch made by the calling thread -- what it will have added to the counter once all of it has started. */
+/* The same with a longer patience (a quarter of a second), for the "started" word of another SEARCH's header: queued searches
+   that take turns on two streams (OpalHipLaunch::started_counter of the class / one-launch / streaming launches counts into the
+   same word as the swapped / pair launches in front of them). opal_hip_last_launch_blocks: the grid size of the last class /
+   one-launch / streaming launch made by the calling thread (0 if the call launched nothing). */
 int opal_hip_wait_count(const int* counter, int target, void* stream);
 int opal_hip_last_launch_blocks(void);
+int opal_hip_wait_timeouts(void);   /* opal_hip_wait_count calls on the current device that gave up so far (diagnostics; synchronizes) */
 /* NW / HW / OV have role-swapped kernels too (int32 arithmetic, scores and end cells: out_end_* may be NULL): the same entry
    with args->mode; rows per lane from opal_hip_swap_gl_rows: 16 (2-byte profile entries: every matrix entry must fit 16
    bits) or 8 (4-byte entries). */
@@ -218,6 +219,7 @@ int opal_hip_scatter_results(const int* quads, int count, int* score, int* end_q
 int opal_hip_stream_sync(void* stream);
 void* opal_hip_stream_create(void);       /* non-blocking stream: ordered only through events */
 void* opal_hip_stream_create_high(void);  /* the same at the device's highest stream priority */
+void* opal_hip_stream_create_low(void);    /* ... of the lowest (a priority class, and with it a hardware queue, of its own) */
 void opal_hip_stream_destroy(void* stream);
 int opal_hip_stream_wait_event(void* stream, void* event);
 /* Interleave residues into the pair token streams of the width-16 kernels, on the device: for every pair p and column c,

@@ -305,7 +305,7 @@ void db_release(OpalxDb* db) {
     opal_hip_stream_destroy(db->mainStream); db->mainStream = nullptr;
     opal_hip_stream_destroy(db->pipeStream); db->pipeStream = nullptr;
     for (void*& ev : db->pipe.done) { opal_hip_event_destroy(ev); ev = nullptr; }
-    db->pipe = OpalxDb::Pipe(); db->startedCtr.release(); db->startedTotal = 0; db->hdrDev = nullptr; db->curStream = nullptr;
+    db->pipe = OpalxDb::Pipe(); db->hdrDev = nullptr; db->curStream = nullptr;
     opal_hip_stream_destroy(db->copyStream); db->copyStream = nullptr;
     opal_hip_stream_destroy(db->copyStream2); db->copyStream2 = nullptr;
     opal_hip_stream_destroy(db->auxStream); db->auxStream = nullptr;

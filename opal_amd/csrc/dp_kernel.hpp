@@ -328,6 +328,19 @@ template <> struct Vec<18> : Vec<17> {
 __device__ __forceinline__ unsigned shr1(unsigned v) {
     return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x138, 0xf, 0xf, true);
 }
+// ... fused with the arithmetic that always follows it in the streaming kernels (a DPP operand costs the instruction what the
+// separate v_mov_dpp cost: one instruction instead of two). `s_nop 1`: the two wait states between a VALU write of the shifted
+// register and its DPP read -- the compiler cannot see into the statement.
+__device__ __forceinline__ unsigned shr1_sub16(unsigned v, unsigned c) {  // lane i: (lane i-1's v) - c, 16 bit (lane 0: -c)
+    unsigned r;
+    asm("s_nop 1\n\tv_sub_u16_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned shr1_add32(unsigned v, unsigned c) {  // lane i: (lane i-1's v) + c (lane 0: c)
+    unsigned r;
+    asm("s_nop 1\n\tv_add_u32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v), "v"(c));
+    return r;
+}
 // wave_shl:1 -- lane i receives lane i+1's value; lane 63 receives 0.
 __device__ __forceinline__ unsigned shl1(unsigned v) {
     return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xf, 0xf, true);

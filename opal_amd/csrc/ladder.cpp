@@ -18,8 +18,8 @@ static int pipe_resolve(OpalxDb* db, void* stream, bool grid) {
     pp.resolved = true;
     int e = 0;
     if (pp.prevKind == 1 && grid && opts().pipeline == 1) {
-        e = opal_hip_wait_count(db->startedCtr.p, (int)(pp.prevTarget - (unsigned)opts().pipeSlack), stream);
-        if (debug_on()) fprintf(stderr, "[opal] queued search: grid behind a wait for %u started workgroups of the search before it\n", pp.prevTarget);
+        e = opal_hip_wait_count(pp.prevCtr, pp.prevTarget - opts().pipeSlack, stream);
+        if (debug_on()) fprintf(stderr, "[opal] queued search: grid behind a wait for %d started workgroups of the search before it\n", pp.prevTarget);
     } else if (pp.prevKind != 0) {
         void* done = pp.done[pp.lastIdx];
         if (done) e = opal_hip_stream_wait_event(stream, done);
@@ -34,7 +34,7 @@ static void pipe_launched_grid(OpalxDb* db) {
     OpalxDb::Pipe& pp = db->pipe;
     if (!pp.active) return;
     pp.launched = true;
-    db->startedTotal += (unsigned)opal_hip_last_launch_blocks();
+    pp.blocks += opal_hip_last_launch_blocks();
 }
 
 static void fill_launch(OpalHipLaunch& a, const SearchCtx& c, int width, int swEndPass, int detectWrap, const int* work,
@@ -145,7 +145,7 @@ static int launch_class(const SearchCtx& c, int width, int swEndPass, int detect
         fprintf(stderr, "[opal] launch width=%d mode=%d end=%d items=[%d,+%d) G=%d rows=%d waves/block=%d ldsPad=%d%s%s\n", width,
                 c.mode, swEndPass, k.first, k.count, k.G, k.rows, k.wpb, k.ldsPad, skew ? " skew" : "", side ? " (side)" : "");
     if (pipe_resolve(c.db, stream, grid)) return 1;
-    if (grid && c.db->pipe.active) a.started_counter = c.db->startedCtr.p;
+    if (grid && c.db->pipe.active) a.started_counter = c.db->ovfCount.p + 3;
     if (opal_hip_launch(&a)) return 1;
     if (grid) pipe_launched_grid(c.db);
     if (c.sideBlocks && c.stream) *c.sideBlocks += (k.count + (64 / k.G) * a.waves_per_block - 1) / ((64 / k.G) * a.waves_per_block);
@@ -225,7 +225,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
                     c.mode, swEndPass, bulk.G, bulk.rows, skewBulk ? " skew" : "", u.base.first_item, u.base.num_items, u.long_first_item,
                     u.long_num_items, u.longest_first_item, u.longest_num_items);
         if (pipe_resolve(db, stream, tracked)) return 1;
-        if (tracked && db->pipe.active) u.base.started_counter = db->startedCtr.p;
+        if (tracked && db->pipe.active) u.base.started_counter = db->ovfCount.p + 3;
         if (opal_hip_launch_uber(&u)) return 1;
         if (tracked) pipe_launched_grid(db);
         count(CNT_ONE_LAUNCH);
@@ -516,7 +516,9 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                     if (!pp.done[idx]) pp.done[idx] = opal_hip_event_create_untimed();
                     if (pp.done[idx] && !opal_hip_event_record(pp.done[idx], st)) {
                         pp.prevKind = (pp.launched && !pp.untracked) ? 1 : 2;
-                        pp.prevTarget = db->startedTotal;
+                        pp.prevTarget = pp.blocks;
+                        pp.prevCtr = db->ovfCount.p ? db->ovfCount.p + 3 : nullptr;
+                        if (!pp.prevCtr) pp.prevKind = 2;
                         pp.lastIdx = idx;
                         if (idx == 1) pp.unjoined = true;
                     } else ok = false;
@@ -533,9 +535,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
         OpalxDb::Pipe& pp = db->pipe;
         if (db->asyncHead == db->asyncTail) pp.prevKind = 0;  // (every queued search has been waited for: nothing of theirs is in flight)
         if (!db->mainStream) db->main();
-        if (!db->pipeStream) db->pipeStream = opal_hip_stream_create();
-        if (!db->startedCtr.p && (!db->startedCtr.ensure(4) || opal_hip_memset32(db->startedCtr.p, 0, 4, db->main()) || opal_hip_stream_sync(db->main())))
-            return OPAL_ERR_NO_SIMD_SUPPORT;
+        if (!db->pipeStream) db->pipeStream = opts().pipePrio < 0 ? opal_hip_stream_create_low() : opts().pipePrio > 0 ? opal_hip_stream_create_high() : opal_hip_stream_create();
         if (db->mainStream && db->pipeStream) {
             if (pp.foreign) {
                 // something else has been enqueued on mainStream since the last queued search (main() was handed out, and it made
@@ -548,7 +548,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
             scope.piped = true;
             scope.idx = pp.prevKind != 0 ? (pp.lastIdx ^ 1) : 0;
             db->curStream = scope.idx ? db->pipeStream : db->mainStream;
-            pp.active = true; pp.resolved = false; pp.untracked = false; pp.launched = false; pp.startEv = nullptr;
+            pp.active = true; pp.resolved = false; pp.untracked = false; pp.launched = false; pp.startEv = nullptr; pp.blocks = 0;
         }
     }
     void* const st = db->main();
@@ -708,7 +708,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                 a.prio_items = stream_prio_items(db, a.first_item, a.num_items, splan.G);
                 if (!gate_items(db, st, 0, 2 * P)) return OPAL_ERR_NO_SIMD_SUPPORT;
                 if (pipe_resolve(db, st, splan.passes == 1)) return OPAL_ERR_NO_SIMD_SUPPORT;  // (row chunks share db->boundary)
-                if (splan.passes == 1 && db->pipe.active) a.started_counter = db->startedCtr.p;
+                if (splan.passes == 1 && db->pipe.active) a.started_counter = db->ovfCount.p + 3;
                 if (splan.passes > 1) {
                     // a query beyond one wave: row chunks from the top, the first one partial (as launch_chunked cuts them), a
                     // chunk's bottom row through db->boundary (4 bytes per residue), the hand-out counter zeroed in between
@@ -760,6 +760,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                         return OPAL_ERR_NO_SIMD_SUPPORT;
                     }
                     count(CNT_SWAPPED, swapN);
+                    db->pipe.blocks += swapN;  // (they count themselves in on the same word as the grid behind them)
                 }
                 rc = launch_range(c, narrow, wantEnd, 0, nullptr, swapN, nNarrow - swapN, seqLenOf, db->ovfCount.p);
                 if (rc && swapN > 0) db->quiesce();  // (the swapped launch may still be writing results and the re-run list on its stream)
@@ -884,7 +885,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                         a.first_item, a.num_items);
             count(CNT_STREAM_GLOBAL);
             if (!gate_items(db, st, 0, 2 * P) || pipe_resolve(db, st, true)) return 1;
-            if (db->pipe.active) a.started_counter = db->startedCtr.p;
+            if (db->pipe.active) a.started_counter = db->ovfCount.p + 3;
             if (opal_hip_launch_stream(&a, db->ovfCount.p + 2)) return 1;
             pipe_launched_grid(db);
             return 0;
@@ -947,6 +948,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                     return OPAL_ERR_NO_SIMD_SUPPORT;
                 }
                 count(CNT_PAIRED, pairN);
+                db->pipe.blocks += pairN;
                 taken = nBad + pairN;  // (no CUs reserved for them: the stream behind waits until they have started, and takes their CUs when they end)
             }
         }
@@ -979,6 +981,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
                     return OPAL_ERR_NO_SIMD_SUPPORT;
                 }
                 count(CNT_SWAPPED, swapG);
+                db->pipe.blocks += swapG;
             }
         }
         // (what the swapped launch took is gone from both rungs: the 32-bit range is empty, the 16-bit one starts behind it)

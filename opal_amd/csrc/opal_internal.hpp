@@ -196,14 +196,12 @@ struct OpalxDb {
     void* hdrEv[OPALX_ASYNC_DEPTH] = {};
     bool hdrEvSet[OPALX_ASYNC_DEPTH] = {};
     // Queued searches take turns on TWO streams (mainStream / pipeStream, ladder.cpp: SearchPipe): a search that is one grid counts
-    // its workgroups in as they start (startedCtr, cumulative, never zeroed), and the grid of the search queued behind it -- on the
+    // its workgroups in as they start (the "started" word of its own header slot), and the grid of the search queued behind it -- on the
     // other stream, behind a one-wave wait kernel -- reaches the dispatcher when the last of them has: it fills the CUs the first one
     // leaves as it drains (C2: a fixed 0.15-0.2 ms of fill and drain per 1.5 ms search on one stream). Whatever is not one grid
     // (side launches, row chunks, a re-run list) waits for the whole search before it and is waited for as a whole.
     void* pipeStream = nullptr;
     void* curStream = nullptr;          // not null while search_core runs a queued search: the stream main() hands out
-    opal_host::DevBuf<int> startedCtr;  // [1]
-    unsigned startedTotal = 0;          // its value once every tracked grid launched so far has started all its workgroups
     unsigned char* hdrDev = nullptr;    // the device header slot of the search enqueued last (header.p + slot * slot bytes)
     struct Pipe {
         bool active = false;      // search_core is running a queued search on curStream
@@ -212,8 +210,10 @@ struct OpalxDb {
         bool launched = false;    // ... it has launched its tracked grid
         void* startEv = nullptr;  // ... its start event, recorded behind the wait in front of its grid (nullptr: at the start of the search)
         int lastIdx = 0;          // stream of the search enqueued last: 0 mainStream, 1 pipeStream
+        int blocks = 0;           // ... workgroups it has launched that count themselves in on its header's "started" word
         int prevKind = 0;         // the search enqueued last: 0 nothing in flight, 1 one tracked grid, 2 anything else
-        unsigned prevTarget = 0;  // kind 1: startedCtr once all its workgroups have started
+        int prevTarget = 0;       // kind 1: the "started" word of its header once all its workgroups have started ...
+        int* prevCtr = nullptr;   // ... and where that word is
         void* done[2] = {nullptr, nullptr};  // event behind the last search on mainStream / pipeStream
         bool unjoined = false;    // pipeStream carries work that mainStream has not been made to wait for
         bool foreign = true;      // mainStream has been handed out outside a queued search since the last one: whatever was enqueued

@@ -143,6 +143,16 @@ extern "C" void* opal_hip_stream_create_high(void) {
     if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest) != hipSuccess) return opal_hip_stream_create();
     return (void*)st;
 }
+// ... and of the LOWEST (the second stream of a handle's queued searches: a priority class of its own means a hardware queue that
+// the handle's main stream, an ordinary one, can never share -- two streams of one class may land on the same queue, where a grid
+// waits for the grid before it to END, whatever the streams say)
+extern "C" void* opal_hip_stream_create_low(void) {
+    int least = 0, greatest = 0;
+    hipStream_t st;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) return opal_hip_stream_create();
+    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least) != hipSuccess) return opal_hip_stream_create();
+    return (void*)st;
+}
 extern "C" int opal_hip_stream_wait_event(void* stream, void* event) {
     hipError_t e = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0);
     return e == hipSuccess ? 0 : fail("hipStreamWaitEvent", e);
@@ -461,6 +471,7 @@ extern "C" int opal_hip_uber_supported(int mode, int want_end, int skew, int row
 }
 
 extern "C" int opal_hip_launch_uber(const OpalHipUberLaunch* u) {
+    g_lastBlocks = 0;
     const OpalHipLaunch* a = &u->base;
     const int G0 = a->lanes_per_seq, S0 = a->rows_per_lane;
     int log2G0 = 0;
@@ -519,6 +530,7 @@ extern "C" int opal_hip_launch_uber(const OpalHipUberLaunch* u) {
 }
 
 extern "C" int opal_hip_launch(const OpalHipLaunch* a) {
+    g_lastBlocks = 0;  // (a call that launches nothing has started nothing: opal_hip_last_launch_blocks)
     const int G = a->lanes_per_seq;
     int log2G = 0;
     while ((1 << log2G) < G) log2G++;
@@ -608,6 +620,7 @@ extern "C" size_t opal_hip_stream_lds_bytes(int width, int mode, int lanes_per_s
     return stream_lds_bytes(width, mode, lanes_per_seq, rows_per_lane, alphabet_length);
 }
 extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter) {
+    g_lastBlocks = 0;
     const int G = a->lanes_per_seq;
     int log2G = 0;
     while ((1 << log2G) < G) log2G++;
@@ -752,22 +765,29 @@ extern "C" int opal_hip_wait_started(const int* counter, int target, void* strea
     return e == hipSuccess ? 0 : fail("wait kernel launch", e);
 }
 
-// One wave that ends when a CUMULATIVE counter (never zeroed: every workgroup of every tracked launch adds one when it starts,
-// KParams::started) has reached `target` -- compared as a signed difference, so the counter may wrap. What a queued search puts in
-// front of its grid on its own stream so that the grid reaches the dispatcher when the search before it (on the other stream) has
-// no workgroup left to dispatch: it then fills the CUs that one leaves as it drains. Gives up after `timeout_ticks` of the
-// constant-rate counter (never a deadlock: at worst the two grids share the dispatcher from then on).
+// One wave that ends when `target` workgroups have counted themselves in on `counter` -- the "started" word of ANOTHER search's header
+// slot (zeroed with that header; every workgroup of its grid, and of the swapped / pair launches in front of it, adds one when it
+// starts: KParams::started). What a queued search puts in front of its grid on its own stream so that the grid reaches the
+// dispatcher when the search before it (on the other stream) has no workgroup left to dispatch: it then fills the CUs that one
+// leaves as it drains. Gives up after `timeout_ticks` of the constant-rate counter (never a deadlock: at worst the two grids share
+// the dispatcher from then on).
+__device__ int g_wait_timeouts = 0;  // waits that gave up (opal_hip_wait_timeouts: tests assert that none did)
 __global__ void __launch_bounds__(64) opal_wait_count_kernel(const int* counter, int target, unsigned long long timeout_ticks) {
     if (threadIdx.x != 0) return;
     const unsigned long long t0 = wall_clock64();
-    while ((int)((unsigned)__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (unsigned)target) < 0) {
-        if (wall_clock64() - t0 > timeout_ticks) break;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (wall_clock64() - t0 > timeout_ticks) { atomicAdd(&g_wait_timeouts, 1); break; }
         __builtin_amdgcn_s_sleep(32);
     }
 }
+extern "C" int opal_hip_wait_timeouts(void) {  // (synchronizes the device)
+    int v = -1;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_wait_timeouts), sizeof v, 0, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return v;
+}
 extern "C" int opal_hip_wait_count(const int* counter, int target, void* stream) {
-    if (!counter) return 0;
-    const unsigned long long ticks = (unsigned long long)(0.5 * opal_hip_wall_clock_hz());  // half a second
+    if (!counter || target <= 0) return 0;
+    const unsigned long long ticks = (unsigned long long)(0.25 * opal_hip_wall_clock_hz());  // a quarter of a second
     hipLaunchKernelGGL(opal_wait_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, target, ticks);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("wait kernel launch", e);

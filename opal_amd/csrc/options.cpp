@@ -105,6 +105,7 @@ const std::vector<Desc>& table() {
         flag("OPAL_HIP_NO_UBER", &Options::noUber),
         one_of("OPAL_HIP_PIPELINE", &Options::pipeline, {0, 1, 2}),
         integer("OPAL_HIP_PIPE_SLACK", &Options::pipeSlack, 0, 1 << 20),
+        one_of("OPAL_HIP_PIPE_PRIO", &Options::pipePrio, {-1, 0, 1}),
         flag("OPAL_HIP_UBER_ONLY", &Options::uberOnly),
         flag("OPAL_HIP_UBER_LDS_PAD", &Options::uberLdsPad),
         flag("OPAL_HIP_NO_SLICES", &Options::noSlices),

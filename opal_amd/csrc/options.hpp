@@ -70,6 +70,7 @@ struct Options {
     int pipeline = 1;                 // OPAL_HIP_PIPELINE=0: queued searches (opalx_search_device_async) one after the other on one stream (round 5); 1: in turn on two
                                       // streams, a search's grid reaching the dispatcher when the one before has started its last workgroup; 2 (test hook): in turn on two
                                       // streams with no "started" wait (each waits for the whole search before it: the order of round 5 on two streams)
+    int pipePrio = -1;                // OPAL_HIP_PIPE_PRIO: priority class of the second stream of queued searches: -1 lowest (default: a hardware queue of its own), 0 ordinary, 1 highest
     int pipeSlack = 0;                // OPAL_HIP_PIPE_SLACK: a queued search's grid is released when all but this many workgroups of the one before have started
     bool noStartedWait = false;       // OPAL_HIP_NO_STARTED_WAIT: the grids of a search do not wait for its swapped workgroups to have started
     int swap = -1;                    // OPAL_HIP_SWAP: 0 never use the role-swapped kernel, N > 0 (test hook) the N longest targets, -1 automatic

@@ -255,9 +255,10 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     // lanes above me have entered already (a slot has at most two sequences in flight: an entry spans at least 2G positions).
     // The column that holds the best cell waits in LDS, one buffer per sequence in flight (by the parity of its number).
     int curV = 0, curS = INT_MIN, nxtV = 0, nxtS = INT_MIN;  // (INT_MIN: a tie at score 0 replaces nothing)
-    // The two sequences a slot may have in flight settle separately, GROUPED by the parity of (sequences finished by the lane -
-    // those lane 0 of the slot had finished at the last refill): in the middle of a sequence every lane of every slot is in group
-    // 0 and one all-reduce serves the wave (by the parity alone, four slots would need both groups almost every time).
+    // The sequences a slot has in flight (two; three when a sequence shorter than G - 2 follows a long one, see the settlement)
+    // settle separately, GROUPED by (sequences finished by the lane - those lane 0 of the slot had finished at the last refill)
+    // modulo 3: in the middle of a sequence every lane of every slot is in group 0 and one all-reduce serves the wave (by the
+    // sequence number alone, four slots would need several groups almost every time).
     int refCount = 0;
     constexpr int CKW = opal_swend_ckpt_words(S);
     auto ckpt_base = [&]() { return (unsigned)(uintptr_t)(opal_lds_u8*)(clkSlot + 48) + (unsigned)((wave * slots + slot) * 2 * CKW * 4); };  // (made when needed: no register across the loop)
@@ -402,8 +403,15 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
             const int cv = (int)((unsigned)cm & 0xffffu);  // (SW values are >= 0)
             const bool cand = OPAL_ABL >= 3 ? false : (cv > curV || (cv == curV && s < curS));
             if (__ballot(cand) != 0ull && (OPAL_ABL < 2 || p.satLimit < 0)) {
-                const int par = flushCount & 1, grp = (flushCount - refCount) & 1;
-                static_for<2>([&](auto pgc) {
+                // (THREE groups, round 6: the lanes move on to their next sequence at its predecessor's second separator, and two of
+                // those can be three positions apart -- a sequence shorter than G - 2 behind a long one, whose entry is padded
+                // BEHIND its separators -- so the G lanes of a slot can be on three sequences: n, the short n+1, and, in its pad
+                // columns, already n+2. By parity alone the lanes on n+2 took the settlements of n for their own and never raised a
+                // smaller best of n+2 again: a wrong end cell among equal scores, a lower score otherwise -- rare: found by the ties
+                // test once in 25 runs (which slot a sequence lands in depends on timing). The two LDS buffers by parity are safe: n+2 has no
+                // real column before every lane has left n.)
+                const int par = flushCount & 1, grp = (int)((unsigned)(flushCount - refCount + 3000) % 3u);
+                static_for<3>([&](auto pgc) {
                     constexpr int pg = decltype(pgc)::value;
                     const bool mine = cand && grp == pg;
                     if (__ballot(mine) != 0ull) {
@@ -634,7 +642,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
     reg Hp[S], En[S];
 #pragma unroll
     for (int j = 0; j < S; j++) { Hp[j] = 0; En[j] = 0; }
-    reg outH = 0, outF = 0, diagIn = 0;
+    reg outF = 0, diagIn = 0;
     const reg Qv = V::splat(Go), Rv = V::splat(Ge);
     const unsigned GQs = (unsigned)(Go - Ge) & 0xffffu;
     const reg SR1v = V::splat((S - 1) * Ge);
@@ -654,9 +662,12 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
     jlo = jlo < 0 ? 0 : (jlo > S ? S : jlo);
     jhi = jhi < 0 ? 0 : (jhi > S ? S : jhi);
 
+    unsigned laneBytesV = (unsigned)LANE_BYTES, sr1V = (unsigned)SR1v;  // (in registers: operands of DPP instructions)
+    asm volatile("" : "+v"(laneBytesV), "+v"(sr1V));
     SlotStream st;  // the stream of this slot
     int started = 0;                    // entries this lane has begun
     int myStart = 0, myLen = 0, myNext = 0;  // my current sequence: first stream position, length; where my next one begins
+    int xLast = INT_MIN;                // stream position of its last column (INT_MIN: it has none)
     reg bestF = V::splat(-32768);  // HW/OV: last-row maximum so far, in the skewed frame of the step at hand
     int bestCol = -1;              // its first column
     int outLcV = INT_MIN, outLcRow = -1;                    // OV: last-column maximum handed down the lanes
@@ -667,8 +678,12 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
     unsigned outq = 0;     // CHUNK: lane queue of the last lane's outputs (true values), oldest towards lane 0
     unsigned outPack = 0;  // CHUNK: what I produced in the step behind us, out of my frame
 
-    for (int s = 0;; s++) {
-        if ((s & (G - 1)) == 0) {
+    // (batches of G steps: the refill -- and the test for the end of the stream -- sit between them, the inner loop has a plain trip
+    // count; as ONE loop with the refill under a test every step paid a scalar test, a branch and what the compiler kept live for
+    // the exit path)
+    for (int s0 = 0;; s0 += G) {
+        {
+            const int s = s0;
             const unsigned letter = st.tokNext;
             const unsigned above = st.bndNext;
             if constexpr (CHUNK) {  // store the last lane's words of positions s-2G .. s-G-1 (see opal_sw_stream)
@@ -690,11 +705,16 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
             bndq = above;
             if (__ballot(!(st.done && s >= st.lastEnd + G)) == 0ull) break;
         }
+        for (int s = s0; s < s0 + G; s++) {
         if constexpr (CHUNK) {  // the last lane's outputs of the step behind us join the queue
             const unsigned shifted = shl1(outq);
             outq = (k == G - 1) ? outPack : shifted;
         }
         const int x = s - k;  // my stream position
+        // ---- inputs of this column from the lane above (frame change of S-1 registers): its last row's H and F of the step behind
+        // us, both still in their registers -- read BEFORE a lane that starts a sequence in this step reloads its rows
+        reg inH = (reg)shr1_sub16((unsigned)Hp[S - 1], sr1V);
+        reg inF = (reg)shr1_sub16((unsigned)outF, sr1V);
         // ---- first column of my next sequence: reload the boundary column
         if (__ballot(x == myNext) != 0ull) {
             if (x == myNext) {
@@ -703,10 +723,12 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
                     myStart = d0.x;  // == myNext
                     myLen = d0.y;
                     myNext = d0.x + max(d0.y, 2 * G);
+                    xLast = d0.y > 0 ? d0.x + d0.y - 1 : INT_MIN;
                     started++;
                 } else {  // the stream has run dry: nothing of mine is a result any more
                     myLen = 0;
                     myNext = INT_MAX;
+                    xLast = INT_MIN;
                 }
                 static_for<SP4 / 4>([&](auto bc) {
                     constexpr int b = decltype(bc)::value;
@@ -719,14 +741,13 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
                 });
                 diagIn = (reg)lds_ld16(myInit + 2 * SP4 * 4).x;
                 sRv = V::splat(k * Ge);
-                bestF = V::splat(-32768); bestCol = -1;
+                bestF = V::splat(-32768); bestCol = INT_MIN;
             }
         }
-        const int c = x - myStart;  // my column
+        // (my column is x - myStart; the per-step code works with stream positions -- the last column is x == xLast, the best
+        // column is kept as a position and turned into a column when it is written: three instructions per step less)
 
-        // ---- inputs of this column: from the lane above (frame change of S-1 registers), or the top boundary
-        reg inH = V::subs_s((reg)shr1((unsigned)outH), SR1s);
-        reg inF = V::subs_s((reg)shr1((unsigned)outF), SR1s);
+        // ---- ... or the top boundary
         if (k == 0) {
             // H[-1][c] + (c-1)*Ge and F[0][c] + c*Ge = H[-1][c] - Go + c*Ge; NW: H[-1][c] = -Go - c*Ge, HW/OV: 0
             if (hasPrev) {  // ... a lower chunk: what the chunk above left for this column, into my frame (k = 0: sRv = c*Ge)
@@ -737,7 +758,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
         }
         if constexpr (CHUNK) bndq = shl1(bndq);
         {
-            const unsigned shifted = shr1(offv) + (unsigned)LANE_BYTES;
+            const unsigned shifted = shr1_add32(offv, laneBytesV);
             offv = (k == 0) ? tokq : shifted;
             tokq = shl1(tokq);
         }
@@ -770,19 +791,18 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
                 pc = pn;
             });
         }
-        outH = Hp[S - 1];
         outF = f;
         diagIn = inH;
         if constexpr (CHUNK) {
             // my outputs as true values: H of my last row is in frame (S-1 + local step), the F input of the row below in
             // frame (S + local step); sRv = local step * Ge
             const reg fr = V::adds(sRv, SR1v);
-            outPack = ((unsigned)V::subs(outH, fr) & 0xffffu) | ((unsigned)V::subs(outF, V::adds(fr, Rv)) << 16);
+            outPack = ((unsigned)V::subs(Hp[S - 1], fr) & 0xffffu) | ((unsigned)V::subs(outF, V::adds(fr, Rv)) << 16);
         }
 
         // ---- results (caller index and length of my sequence: descriptor started-1)
         if (MODE == MODE_NW && !hasNext) {
-            if (k == kLast && c == myLen - 1 && myLen > 0) {  // the final cell: once per sequence
+            if (k == kLast && x == xLast) {  // the final cell: once per sequence
                 const reg hl = SelectRow<reg, S, 0, S>::get(Hp, jLast);
                 const int v = V::half(V::subs(hl, V::adds(sRv, V::splat(jLast * Ge))), 0);
                 const int seq = ring[((started - 1) & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4) + 2];
@@ -793,7 +813,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
             }
         }
         if (MODE == MODE_HW || MODE == MODE_OV) {
-            const bool lastc = c == myLen - 1 && myLen > 0;
+            const bool lastc = x == xLast;
             int lcV = INT_MIN, lcRow = -1;
             if (MODE == MODE_OV) {
                 // the last column: its maximum over the query rows (value, then smallest row), lane by lane as the column
@@ -833,10 +853,10 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
             // step: the running best moves into the frame of the new step with one addition (only the last lane's value is
             // ever used; columns beyond the sequence come after its result has been written).
             const reg prevF = bestF;                      // OV: the maximum over columns 0 .. c-1, in this step's frame
-            V::track_best_any(outH, bestF, bestCol, c);  // strict >: first column wins (opal.cpp:824-834)
+            V::track_best_any(Hp[S - 1], bestF, bestCol, x);  // strict >: first column wins (opal.cpp:824-834)
             if (k == kLast && lastc) {
                 const reg frame = V::adds(sRv, SR1v);
-                int sc = V::half(V::subs(bestF, frame), 0), eq = p.Q - 1, et = bestCol;
+                int sc = V::half(V::subs(bestF, frame), 0), eq = p.Q - 1, et = bestCol == INT_MIN ? -1 : bestCol - myStart;
                 const int seq = ring[((started - 1) & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4) + 2];
                 if constexpr (CHUNK && MODE == MODE_OV) {  // the last-column maximum over the chunks (the upper rows win ties)
                     if (seq >= 0) {
@@ -859,6 +879,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
             bestF = V::adds_s(bestF, Rs);  // into the frame of the next step
         }
         sRv = V::adds_s(sRv, Rs);
+        }
     }
     clk_end(clkSlot);
 }

@@ -171,6 +171,7 @@ int opal_hip_scatter_results(const int* quads, int count, int* score, int* eq, i
 int opal_hip_stream_sync(void* stream) { S(stream)->sync(); return 0; }
 void* opal_hip_stream_create(void) { return new Stream; }
 void* opal_hip_stream_create_high(void) { return new Stream; }
+void* opal_hip_stream_create_low(void) { return new Stream; }
 void opal_hip_stream_destroy(void* stream) { if (stream) delete (Stream*)stream; }
 
 void* opal_hip_event_create(void) { return new Event; }
@@ -299,6 +300,7 @@ int opal_hip_wait_started(const int*, int, void*) { return 0; }  // (the fake st
 // their two worker threads -- whatever they share unprotected, ThreadSanitizer sees
 int opal_hip_wait_count(const int*, int, void*) { return 0; }
 int opal_hip_last_launch_blocks(void) { return 1; }
+int opal_hip_wait_timeouts(void) { return 0; }
 int opal_hip_launch_swap(const OpalHipLaunch* a) {
     OpalHipLaunch c = *a;
     if (c.mode == OPAL_MODE_SW) c.width = 17;  // (16-bit arithmetic with the re-run list, like the class kernels)

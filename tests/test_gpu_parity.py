@@ -162,6 +162,39 @@ def test_sw_end_cells_with_ties_in_the_streaming_kernels(lanes, qlen, narrow, ou
             _check(got, want, "SW", f"stream ties G={lanes} Q={qlen} w{narrow} gaps {go}/{ge} blocks={blocks}")
 
 
+@pytest.mark.parametrize("lanes,qlen", [(64, 700), (32, 513), (16, 300)])
+def test_sw_end_cells_with_three_sequences_in_flight(lanes, qlen, ours, oracle, opal_opt):
+    """Round 6: a sequence shorter than G - 2 behind a long one puts THREE sequences into the G lanes of a slot -- the long one, the
+    short one and, in the short one's pad columns, already the lanes' next -- and the settlement of the streaming SW kernels
+    grouped lanes by the parity of their sequence number: the lanes on the third took the first one's best cell for their own
+    and never raised the (lower) best of their real sequence again: a wrong end cell among equal scores, a lower score otherwise.
+    Rare in the suite (which slot a sequence lands in depends on timing; the ties test above failed once in 25 runs), certain here:
+    one persistent workgroup, long sequences whose score grows to their last column, then only short ones whose first best
+    cell sits in lane 0. Fails on the round-5 kernel."""
+    A = 4
+    m = np.full((A, A), -1, np.int32)
+    np.fill_diagonal(m, 1)
+    q = np.zeros(qlen, np.uint8)
+    slots = 16 * (64 // lanes)
+    db = [np.zeros(3 * lanes + 7 * (i % 5), np.uint8) for i in range(3 * slots)]            # long: the score grows to the last column
+    db += [np.zeros(1 + (i % max(2, lanes - 3)), np.uint8) for i in range(40 * slots)]      # short: 1 .. G-3 residues, every best in lane 0
+    db += [np.array([0, 1, 0, 0, 1, 0], np.uint8), np.array([1], np.uint8)]
+    opal_opt.set("OPAL_HIP_STREAM", "1")
+    opal_opt.set("OPAL_HIP_LANES_PER_SEQ", str(lanes))
+    opal_opt.set("OPAL_HIP_NARROW", "17")
+    cnt = (C.c_longlong * 11)()
+    for blocks in ("1", "2"):
+        opal_opt.set("OPAL_HIP_STREAM_BLOCKS", blocks)
+        for go, ge in ((1, 1), (0, 0), (2, 1)):
+            ours.lib.opalx_counters(cnt, 11)
+            before = cnt[0]
+            got = ours.search(q, db, go, ge, m, 1, MODES["SW"])[:4]
+            ours.lib.opalx_counters(cnt, 11)
+            assert cnt[0] - before >= 1, "not on the streaming kernels"
+            want = oracle.search(q, db, go, ge, m, 1, MODES["SW"])
+            _check(got, want, "SW", f"three in flight G={lanes} Q={qlen} gaps {go}/{ge} blocks={blocks}")
+
+
 def test_api_rules(ours, oracle):
     q, db, m = cases.materialise(cases.CASES["readme_example"])
     # score-only search: end locations -1; alignment fields post-filled (opal.cpp:1508-1515)

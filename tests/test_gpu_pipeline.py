@@ -10,6 +10,16 @@ import oracle_lib
 pytestmark = pytest.mark.gpu
 
 
+def _timeouts():
+    """opal_hip_wait_count calls that gave up: a queued search whose wait for "the search before it has started all its
+    workgroups" ran into its quarter-second patience means the count it waited for was wrong."""
+    import ctypes as C
+    from opal_amd import _lib
+    f = _lib.lib().opal_hip_wait_timeouts
+    f.restype = C.c_int
+    return int(f())
+
+
 def _sync(pdb, n, q, go, ge, m, st, mode):
     import torch
     out = torch.full((3 * n,), -99, dtype=torch.int32, device="cuda")
@@ -53,6 +63,7 @@ def test_queued_searches_of_every_kind_equal_the_synchronous_call(pipeline, opal
     from opal_amd.api import PreparedDb
     from opal_amd.score_matrix import blosum50
     opal_opt.set("OPAL_HIP_PIPELINE", pipeline)
+    t0 = _timeouts()
     n = 24000
     res, offs, lens = synth.database(n, seed=42, first=50000)
     m = blosum50()[1]
@@ -83,6 +94,7 @@ def test_queued_searches_of_every_kind_equal_the_synchronous_call(pipeline, opal
             else:
                 assert (g[1:] == -99).all()
         assert all(k > 0 for k in kms) and all(p >= 0 for p in per)
+    assert _timeouts() == t0, "a queued search waited in vain for the started-workgroup count of the search before it"
     pdb.close()
 
 
@@ -94,6 +106,7 @@ def test_queued_one_grid_searches_overlap_and_keep_their_own_queries(opal_opt):
     from opal_amd.api import PreparedDb
     from opal_amd.score_matrix import blosum50
     n = 100000
+    t0 = _timeouts()
     res, offs, lens = synth.database(n, seed=42)
     m = blosum50()[1]
     pdb = PreparedDb(res, offs)
@@ -110,6 +123,7 @@ def test_queued_one_grid_searches_overlap_and_keep_their_own_queries(opal_opt):
             if st:
                 np.testing.assert_array_equal(g[n:], want[j & 1][n:])
         ratio[pipeline] = float(np.mean(per[5:])) / float(np.mean(kms[5:]))
+    assert _timeouts() == t0
     print(f"\nperiod / own launch life: pipeline on {ratio['1']:.3f}, off {ratio['0']:.3f}")
     assert ratio["1"] < 0.97, ratio     # overlapped: a search costs less than its launch lives
     assert ratio["0"] > 0.99, ratio     # one stream: period = life + the gap between launches
