@@ -756,7 +756,7 @@ def main():
                     ("c5", 2000, 100000, "SW", 0): "c5", ("c5", 2000, 100000, "SW", 1): "c5end", ("c5", 2000, 100000, "NW", 1): "c5nw",
                     ("c5", 2000, 100000, "HW", 1): "c5hw", ("c5", 2000, 100000, "OV", 1): "c5ov"}
             tag = tags.get(key[:5]) if (key[5], key[6]) == (11, 1) else None
-            for rnd in ("r05", "r04", "r03", "r02"):
+            for rnd in ("r06", "r05", "r04", "r03", "r02"):
                 path = os.path.join(ROOT, "profiles", f"{rnd}_{tag}.json")
                 if tag and os.path.exists(path):
                     with open(path) as fh:

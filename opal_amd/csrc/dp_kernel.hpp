@@ -721,6 +721,11 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
     int slotLen = len[0];
     if (NH == 2 && len[NH - 1] > slotLen) slotLen = len[NH - 1];
     const int maxLen = __builtin_amdgcn_readfirstlane(wave_max_i32(slotLen));
+    // the first step at which some lane of the wave is on the LAST column of its sequence (lane 0 of the shortest one): before it
+    // the last-column test of OV is a scalar compare, not a vector compare + ballot + branch every step (sorted sequences: the
+    // slots of a wave differ by a residue or two, so that is all but the last G + a few steps)
+    const int negFirstLast = __builtin_amdgcn_readfirstlane(wave_max_i32(slotLen > 0 ? 1 - slotLen : INT_MIN));
+    const int firstLastStep = negFirstLast == INT_MIN ? INT_MAX : -negFirstLast;
     const int nsteps = maxLen > 0 ? maxLen + G - 1 : 0;
 
     // ---- per-lane DP state
@@ -1170,7 +1175,7 @@ __device__ __forceinline__ void opal_dp_body(const KParams& p, const KClass cls,
             // larger value, then the smaller row. The lane holding query row Q-1 ends up with the column's maximum and the
             // smallest row attaining it.
             const bool lastc = c >= 0 && c == len[0] - 1;
-            if (__ballot(lastc) != 0ull) {  // (marking this and the other rare blocks unlikely, so that they are laid out behind the loop, measured no faster)
+            if (s >= firstLastStep && __ballot(lastc) != 0ull) {  // (marking this and the other rare blocks unlikely, so that they are laid out behind the loop, measured no faster)
                 unsigned inKey = shr1((unsigned)lcMax[0]);
                 if (k == 0) inKey = 0u;
                 if (lastc) {

@@ -2,7 +2,16 @@
 // device selection, memory, copies, events and the single kernel-launch entry. No DP logic and
 // no scheduling here: the kernels are in dp_kernel.hpp, the scheduler in opal_api.cpp.
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>  // types only: the library is loaded with dlopen, on request (opal_hip_rccl_init)
+// RCCL: types only -- the library is loaded with dlopen, on request (opal_hip_rccl_init). A ROCm installation without the rccl
+// development package still builds libopal.so: the few types the dlsym'ed entry points need are then declared here (the ABI of
+// nccl.h: opaque communicator pointer, int enums), and a run-time librccl.so is all the RCCL gather wants.
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1, ncclInt32 = 2, ncclInt = 2 } ncclDataType_t;
+#endif
 #include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -72,6 +81,17 @@ extern "C" void* opal_hip_host_malloc_device_cached(size_t bytes) {
 extern "C" void opal_hip_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 // Ticks per second of s_memrealtime (the constant-rate counter the clock probe divides shader cycles by).
+// Compute units of the calling thread's current device (256 on MI355X), cached per thread and device.
+static int opal_hip_cu_count() {
+    static thread_local int cus = 0, cusDevice = -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (cusDevice != dev) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cusDevice = dev;
+    }
+    return cus;
+}
 extern "C" double opal_hip_wall_clock_hz(void) {
     int dev = 0, khz = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0.0;
@@ -641,13 +661,7 @@ extern "C" int opal_hip_launch_stream(const OpalHipLaunch* a, int* next_counter)
     if (a->num_items <= 0) return 0;
     const size_t lds = stream_lds_bytes(a->width, a->mode, G, a->rows_per_lane, a->alphabet_length);
     if (lds > 160 * 1024) { snprintf(g_err, sizeof g_err, "query profile needs %zu bytes of LDS (>160 KiB)", lds); return 2; }
-    static thread_local int cus = 0, cusDevice = -1;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return fail("hipGetDevice", hipGetLastError());
-    if (cusDevice != dev) {
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        cusDevice = dev;
-    }
+    const int cus = opal_hip_cu_count();
     StreamParams sp;
     memset(&sp, 0, sizeof sp);
     KParams& p = sp.base;
@@ -750,17 +764,23 @@ extern "C" int opal_hip_launch_pair(const OpalHipLaunch* a, void* boundary, unsi
 }
 
 // One wave that ends when `target` workgroups of a launch on another stream have started (see include/opal_hip.h).
-__global__ void __launch_bounds__(64) opal_wait_started_kernel(const int* counter, int target) {
+__global__ void __launch_bounds__(64) opal_wait_started_kernel(const int* counter, int target, unsigned long long timeout_ticks) {
     if (threadIdx.x != 0) return;
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        if (wall_clock64() - t0 > 200000ull) break;  // ~2 ms of the 100 MHz counter: never a deadlock, at worst the old order
+        if (wall_clock64() - t0 > timeout_ticks) break;  // never a deadlock, at worst the old order
         __builtin_amdgcn_s_sleep(32);
     }
 }
 extern "C" int opal_hip_wait_started(const int* counter, int target, void* stream) {
     if (!counter || target <= 0) return 0;
-    hipLaunchKernelGGL(opal_wait_started_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, target);
+    // (no more workgroups than can be resident at once -- one per CU for the 55-100 KB workgroups this is for: on a part with fewer
+    // CUs than workgroups the rest start when the first ones end, and waiting for THEM would cost every search the whole timeout;
+    // 2 ms of the constant-rate counter, from its measured rate)
+    const int cus = opal_hip_cu_count();
+    if (cus > 0 && target > cus) target = cus;
+    const unsigned long long ticks = (unsigned long long)(0.002 * opal_hip_wall_clock_hz());
+    hipLaunchKernelGGL(opal_wait_started_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, target, ticks);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("wait kernel launch", e);
 }

@@ -662,8 +662,11 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
     jlo = jlo < 0 ? 0 : (jlo > S ? S : jlo);
     jhi = jhi < 0 ? 0 : (jhi > S ? S : jhi);
 
-    unsigned laneBytesV = (unsigned)LANE_BYTES, sr1V = (unsigned)SR1v;  // (in registers: operands of DPP instructions)
-    asm volatile("" : "+v"(laneBytesV), "+v"(sr1V));
+    // The lane hand-off and the profile address as ONE DPP instruction each (shr1_sub16 / shr1_add32: their second operand must be a
+    // register) -- where two more long-lived registers fit: the tallest shapes keep the shift and the arithmetic apart.
+    constexpr bool FUSE = S <= 35;
+    unsigned laneBytesV = (unsigned)LANE_BYTES, sr1V = (unsigned)SR1v;
+    if constexpr (FUSE) asm volatile("" : "+v"(laneBytesV), "+v"(sr1V));
     SlotStream st;  // the stream of this slot
     int started = 0;                    // entries this lane has begun
     int myStart = 0, myLen = 0, myNext = 0;  // my current sequence: first stream position, length; where my next one begins
@@ -681,9 +684,11 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
     // (batches of G steps: the refill -- and the test for the end of the stream -- sit between them, the inner loop has a plain trip
     // count; as ONE loop with the refill under a test every step paid a scalar test, a branch and what the compiler kept live for
     // the exit path)
-    for (int s0 = 0;; s0 += G) {
+    // (... where the nested loops fit the register file: at 36 rows per lane and more the compiler keeps more alive across them and
+    // spills; those shapes run the single loop with the refill under a test, as in round 5)
+    constexpr bool BATCHED = S <= 35;
+    auto refill = [&](const int s) -> bool {  // start of a batch of G steps; true: the stream has ended
         {
-            const int s = s0;
             const unsigned letter = st.tokNext;
             const unsigned above = st.bndNext;
             if constexpr (CHUNK) {  // store the last lane's words of positions s-2G .. s-G-1 (see opal_sw_stream)
@@ -703,9 +708,12 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
             fetch(s + G + k);
             tokq = ldsBase + letter * (unsigned)stride;
             bndq = above;
-            if (__ballot(!(st.done && s >= st.lastEnd + G)) == 0ull) break;
+            if (__ballot(!(st.done && s >= st.lastEnd + G)) == 0ull) return true;
         }
-        for (int s = s0; s < s0 + G; s++) {
+        return false;
+    };
+    auto column_step = [&](const int s) {
+        {
         if constexpr (CHUNK) {  // the last lane's outputs of the step behind us join the queue
             const unsigned shifted = shl1(outq);
             outq = (k == G - 1) ? outPack : shifted;
@@ -713,8 +721,14 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
         const int x = s - k;  // my stream position
         // ---- inputs of this column from the lane above (frame change of S-1 registers): its last row's H and F of the step behind
         // us, both still in their registers -- read BEFORE a lane that starts a sequence in this step reloads its rows
-        reg inH = (reg)shr1_sub16((unsigned)Hp[S - 1], sr1V);
-        reg inF = (reg)shr1_sub16((unsigned)outF, sr1V);
+        reg inH, inF;
+        if constexpr (FUSE) {
+            inH = (reg)shr1_sub16((unsigned)Hp[S - 1], sr1V);
+            inF = (reg)shr1_sub16((unsigned)outF, sr1V);
+        } else {
+            inH = V::subs_s((reg)shr1((unsigned)Hp[S - 1]), SR1s);
+            inF = V::subs_s((reg)shr1((unsigned)outF), SR1s);
+        }
         // ---- first column of my next sequence: reload the boundary column
         if (__ballot(x == myNext) != 0ull) {
             if (x == myNext) {
@@ -758,7 +772,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
         }
         if constexpr (CHUNK) bndq = shl1(bndq);
         {
-            const unsigned shifted = shr1_add32(offv, laneBytesV);
+            const unsigned shifted = FUSE ? shr1_add32(offv, laneBytesV) : shr1(offv) + (unsigned)LANE_BYTES;
             offv = (k == 0) ? tokq : shifted;
             tokq = shl1(tokq);
         }
@@ -879,6 +893,17 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
             bestF = V::adds_s(bestF, Rs);  // into the frame of the next step
         }
         sRv = V::adds_s(sRv, Rs);
+        }
+    };
+    if constexpr (BATCHED) {
+        for (int s0 = 0;; s0 += G) {
+            if (refill(s0)) break;
+            for (int s = s0; s < s0 + G; s++) column_step(s);
+        }
+    } else {
+        for (int s = 0;; s++) {
+            if ((s & (G - 1)) == 0 && refill(s)) break;
+            column_step(s);
         }
     }
     clk_end(clkSlot);

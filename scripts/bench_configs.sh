@@ -28,3 +28,5 @@ run --workload c5 --total-seqs 100000 --qlen 3000 --search-type 1 --no-e2e
 run --workload c5 --total-seqs 100000 --qlen 3000 --search-type 1 --mode NW --no-e2e
 run --workload c5 --total-seqs 100000 --qlen 6000 --no-e2e
 run --workload sprot --no-e2e
+run --workload c3 --mode SW --gap-open 3 --no-e2e
+run --workload c5x3 --no-e2e

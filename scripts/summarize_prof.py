@@ -46,14 +46,15 @@ for k, cs in counters.items():
         e["effective_clock_ghz_raw"] = round(e["GRBM_GUI_ACTIVE"] / (stats[k]["avg_us"] * 1e3), 3)
     pk[k] = e
 out["per_kernel"] = pk
-# searches per profiled bench run: 5 timed + 2 warm-up + the 5 of the clock probe (bench.py, after the timed region)
-steps = int(sys.argv[4]) if len(sys.argv) > 4 else 12
-valu = sum(e.get("SQ_INSTS_VALU", 0) * stats.get(k, {}).get("calls", 0) for k, e in pk.items())
+# searches of the profiled bench run = the calls of the DP kernel that runs once per search (the smallest call count among them:
+# settle / warm-up / timed / clock-probe searches all launch it; the probe runs for >= 30 ms, so the count depends on the search)
 calls = {k: stats.get(k, {}).get("calls", 0) for k in pk}
 out["calls"] = calls
-if cells and pk:
-    # launches of a kernel per bench step = launches seen / steps run (a kernel name can serve several length classes)
-    lps = {k: max(1.0, round(e["_launches_seen"] / steps)) for k, e in pk.items()}
+nz = [c for c in calls.values() if c > 0]
+if cells and pk and nz:
+    searches = int(sys.argv[4]) if len(sys.argv) > 4 else min(nz)
+    out["searches_in_the_profiled_run"] = searches
+    lps = {k: (calls[k] / searches if calls[k] else 0) for k in pk}
     out["launches_per_step"] = lps
     per_step = sum(e.get("SQ_INSTS_VALU", 0) * lps[k] for k, e in pk.items())
     out["valu_wave_instr_per_cell_lane"] = round(per_step * 64 / cells, 3)

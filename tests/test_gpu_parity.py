@@ -233,6 +233,53 @@ def test_result_reuse(ours):
     assert rc == 0 and s[0] == 155
 
 
+def test_result_reuse_in_a_large_database(ours, oracle):
+    """The same on a database large enough for the device ordering to run while the result structs are looked through (opal_api.cpp,
+    overlapLook: one device, >= 16 384 sequences): when some results are already set the overlapped ordering of ALL sequences is
+    dropped and the call goes on with what is left -- on a cached context whose previous database it has just overwritten. Kept
+    results stay, everything else is the oracle's, and the next call (everything to compute, same database) is right too."""
+    from opal_amd import synth
+    from opal_amd.score_matrix import blosum50
+    m = blosum50()[1]
+    n = 20000
+    res_, offs, lens = synth.database(n, seed=42, first=700000)
+    db = [res_[offs[i]:offs[i + 1]] for i in range(n)]
+    q = synth.query(150, seed=9)
+    rc, s0, eq0, et0, *_ = ours.search(q, db, 11, 1, m, 1, MODES["SW"])      # the context now holds this database
+    assert rc == 0
+    res = ours.new_results(n)
+    arr, _ = res
+    kept = list(range(0, n, 97))
+    for i in kept:
+        arr[i].scoreSet = 1; arr[i].score = 100000 + i; arr[i].endLocationQuery = 5; arr[i].endLocationTarget = 6
+    arr[11].scoreSet = 1; arr[11].score = -5    # no end location: recomputed for SCORE_END
+    rc, s, eq, et, sset, _ = ours.search(q, db, 11, 1, m, 1, MODES["SW"], results=res)
+    assert rc == 0 and (sset == 1).all()
+    mask = np.ones(n, bool); mask[kept] = False
+    np.testing.assert_array_equal(s[kept], 100000 + np.array(kept))
+    assert (eq[kept] == 5).all() and (et[kept] == 6).all()
+    np.testing.assert_array_equal(s[mask], s0[mask])
+    np.testing.assert_array_equal(eq[mask], eq0[mask])
+    np.testing.assert_array_equal(et[mask], et0[mask])
+    pick = np.arange(3, n, 400)
+    want = oracle.search(q, [db[i] for i in pick], 11, 1, m, 1, MODES["SW"])
+    np.testing.assert_array_equal(s[pick][mask[pick]], want[1][mask[pick]])
+    # alignment search with some results set (score + end cells): only those are traced, the others computed first
+    res2 = ours.new_results(n)
+    arr2, _ = res2
+    for i in kept[:50]:
+        arr2[i].scoreSet = 1; arr2[i].score = int(s0[i]); arr2[i].endLocationQuery = int(eq0[i]); arr2[i].endLocationTarget = int(et0[i])
+    rc, s2, eq2, et2, *_ = ours.search(q, db, 11, 1, m, 1, MODES["SW"], results=res2)
+    assert rc == 0
+    np.testing.assert_array_equal(s2, s0)
+    np.testing.assert_array_equal(eq2, eq0)
+    # ... and everything again from scratch on the same context
+    rc, s3, eq3, et3, *_ = ours.search(q, db, 11, 1, m, 1, MODES["SW"])
+    assert rc == 0
+    np.testing.assert_array_equal(s3, s0)
+    np.testing.assert_array_equal(et3, et0)
+
+
 def test_empty_and_ragged(ours, oracle):
     """Zero-length targets, one-residue targets, an empty database; values defined in oracle/opal_oracle.c."""
     from opal_amd.score_matrix import blosum50
