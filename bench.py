@@ -823,7 +823,9 @@ def main():
                                   "this one, mean over the timed steps but the first -- consecutive searches overlap on two streams (a search's grid is "
                                   "released when the one before has started its last workgroup), so launch_ms, the life of one search's launches from "
                                   "their release to their end (what rocprofv3 --kernel-trace calls its duration), is longer than what the search costs and "
-                                  "frac_per_launch prices that; N > 1: kernel_ms = HIP events around all DP launches of a step on rank 0; clock_ghz = "
+                                  "frac_per_launch prices that -- in a rocprofv3 kernel trace kernel_ms is the average difference between the End_Timestamps of "
+                                  "consecutive launches of the dominant kernel and launch_ms their average duration (scripts/trace_period.py, "
+                                  "profiles/r06_trace_periods.txt); N > 1: the same per rank; clock_ghz = "
                                   "shader cycles / constant-rate ticks over one wave's lifetime per workgroup, measured in the DP kernels "
                                   "themselves on the last of >= 30 ms of searches queued two deep after the timed region (as the timed steps are); "
                                   "frac_at_measured_clock prices the bound at it",

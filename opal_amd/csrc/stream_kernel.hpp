@@ -87,14 +87,23 @@ struct SlotStream {
 // sequence; an entry spans at least 2G positions (pad columns after short sequences), which is what bounds the look-up
 // to two descriptors and the ring to four.
 // Descriptor: {start, len, caller index, -, residue offset lo, hi, item, running maximum (SW with end locations)}.
+// The FIRST sequence of every slot is not drawn from the counter but dealt (round 6): slot (workgroup b, wave w, slot sl) starts on
+// item (w * workgroups + b) * slots + sl, so the launch's longest sequences -- the first items -- sit on wave 0 of every persistent
+// workgroup (one wave per CU; the slots of a wave take neighbours in length, which end together), the next ones on another SIMD
+// of every CU, and so on; the counter then hands out the items from the
+// number of slots on. Drawn from the counter, the sixteen longest sequences of a tailed database went to whichever waves won the
+// race, now and then four of them to one SIMD: a 1700-aa query on the first 100 000 sequences of the published shape took 17.4 to
+// 28.7 ms from search to search on one and the same plan (the waves on a launch's longest sequences run at raised priority --
+// among themselves that is no priority).
 template <int SEPS, bool BND = false>
 __device__ __forceinline__ void stream_fetch(SlotStream& st, const KParams& p, int* next, int* ring, const int x, const int k,
-                                             const int G, const int slotLane0, const int PAD, const int prioItems = 0) {
+                                             const int G, const int slotLane0, const int PAD, const int prioItems = 0,
+                                             const int firstIdx = -1, const int totalSlots = 0) {
     const int base = x - k;
     const bool need = !st.done && st.coveredEnd <= base + G - 1;  // slot-uniform
     if (__ballot(need) != 0ull) {  // (wave-uniform branch, every lane inside: the broadcast below reads lane 0 of the slot)
         int idx = 0;
-        if (need && k == 0) idx = atomicAdd(next, 1);
+        if (need && k == 0) idx = (firstIdx >= 0 && st.nEntries == 0) ? firstIdx : atomicAdd(next, 1) + totalSlots;
         idx = __shfl(idx, slotLane0, 64);
         if (need) {
             if (idx < p.numItems) {
@@ -263,7 +272,10 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     constexpr int CKW = opal_swend_ckpt_words(S);
     auto ckpt_base = [&]() { return (unsigned)(uintptr_t)(opal_lds_u8*)(clkSlot + 48) + (unsigned)((wave * slots + slot) * 2 * CKW * 4); };  // (made when needed: no register across the loop)
 
-    auto fetch = [&](const int x) { stream_fetch<2, CHUNK>(st, p, sp.next, ring, x, k, G, slotLane0, PAD, sp.prioItems); };
+    // (this slot's first item and the number of slots of the launch: see stream_fetch)
+    const int streamBlocks = (int)gridDim.x - (SIDE ? sp.sideBlocks : 0), streamBlock = (int)blockIdx.x - (SIDE ? sp.sideBlocks : 0);
+    const int totalSlots = streamBlocks * STREAM_WAVES * slots, firstIdx = (wave * streamBlocks + streamBlock) * slots + slot;
+    auto fetch = [&](const int x) { stream_fetch<2, CHUNK>(st, p, sp.next, ring, x, k, G, slotLane0, PAD, sp.prioItems, firstIdx, totalSlots); };
     fetch(k);
     unsigned bndq = 0;  // CHUNK: lane queue of the boundary words above the columns of this batch (lane 0 consumes)
     unsigned outq = 0;  // CHUNK: lane queue of the last lane's outputs, oldest towards lane 0
@@ -675,7 +687,9 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
     int bestCol = -1;              // its first column
     int outLcV = INT_MIN, outLcRow = -1;                    // OV: last-column maximum handed down the lanes
 
-    auto fetch = [&](const int x) { stream_fetch<0, CHUNK>(st, p, sp.next, ring, x, k, G, slotLane0, PAD, sp.prioItems); };
+    const int streamBlocks = (int)gridDim.x - sp.sideBlocks, streamBlock = (int)blockIdx.x - sp.sideBlocks;
+    const int totalSlots = streamBlocks * STREAM_WAVES * slots, firstIdx = (wave * streamBlocks + streamBlock) * slots + slot;
+    auto fetch = [&](const int x) { stream_fetch<0, CHUNK>(st, p, sp.next, ring, x, k, G, slotLane0, PAD, sp.prioItems, firstIdx, totalSlots); };
     fetch(k);
     unsigned bndq = 0;     // CHUNK: lane queue of the boundary words above the columns of this batch (lane 0 consumes)
     unsigned outq = 0;     // CHUNK: lane queue of the last lane's outputs (true values), oldest towards lane 0

@@ -25,6 +25,7 @@ for r in $(seq 1 ${ROUNDS:-2}); do
     c4end) ARGS="--workload c4 --total-seqs 625000 --search-type 1 --steps 10" ;;
     sprotend) ARGS="--workload sprot --search-type 1 --steps 8" ;;
     c3sw31) ARGS="--workload c3 --mode SW --gap-open 3 --gap-ext 1" ;;
+    sprot) ARGS="--workload sprot --steps 8" ;;
   esac
   for V in tree "$@"; do
     if [ $V = tree ]; then unset OPAL_LIB_PATH; else export OPAL_LIB_PATH=$GRAFT_REPO_ROOT/build/$V/libopal.so; fi

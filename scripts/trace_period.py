@@ -19,5 +19,11 @@ for n, v in rows.items():
     med = sorted(per)[len(per) // 2]
     steady = [p for p in per if p <= 3 * med]
     overl = sum(1 for i in range(len(v) - 1) if v[i + 1][0] < v[i][1])
+    # ... and over the QUEUED phases alone: pairs of launches of which the second starts before the first ends (bench.py's settle,
+    # warm-up, timed and clock-probe searches; the drop-in calls of its e2e leg are one search per call and never overlap)
+    qper = [v[i + 1][1] - v[i][1] for i in range(len(v) - 1) if v[i + 1][0] < v[i][1]]
+    qdur = [v[i + 1][1] - v[i + 1][0] for i in range(len(v) - 1) if v[i + 1][0] < v[i][1]]
+    if qper:
+        print(f"{d.split('/')[-2]:10s} {n[:60]:60s} queued launches only ({len(qper)}): avg duration {sum(qdur) / len(qdur) / 1e3:9.1f} us  avg period {sum(qper) / len(qper) / 1e3:9.1f} us")
     print(f"{d.split('/')[-2]:10s} {n[:60]:60s} launches {len(v):4d}  avg duration {sum(dur) / len(dur) / 1e3:9.1f} us  avg period (steady) {sum(steady) / len(steady) / 1e3:9.1f} us  "
           f"launches that start before the one before ends: {overl}")
