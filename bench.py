@@ -970,9 +970,7 @@ def main():
                 if multi:
                     raise
             if rank == 0:
-                legs[leg] = r
-                if not (r or {}).get("verified", False):
-                    status = status or 3
+                legs[leg] = r  # (a leg that fails or does not verify says so in its own entry: the exit status is the headline's)
         if rank == 0:
             res_line.setdefault("also", {}).update(legs)
     if multi:
