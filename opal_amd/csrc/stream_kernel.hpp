@@ -748,6 +748,16 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
             inH = V::subs_s((reg)shr1((unsigned)Hp[S - 1]), SR1s);
             inF = V::subs_s((reg)shr1((unsigned)outF), SR1s);
         }
+        // ---- this step's profile address, and its first read, BEFORE the reload below: a lane that starts a sequence in this step
+        // waits for sixteen boundary reads there, and the profile read rides along instead of starting its own round trip behind them
+        // (the address depends on tokens only)
+        int4 pfirst = make_int4(0, 0, 0, 0);
+        if constexpr (BATCHED) {
+            const unsigned shifted = FUSE ? shr1_add32(offv, laneBytesV) : shr1(offv) + (unsigned)LANE_BYTES;
+            offv = (k == 0) ? tokq : shifted;
+            tokq = shl1(tokq);
+            pfirst = lds_ld16(offv);
+        }
         // ---- first column of my next sequence: reload the boundary column
         if (__ballot(x == myNext) != 0ull) {
             if (x == myNext) {
@@ -790,7 +800,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
             else { inH = V::subs_s(sRv, Rs); inF = V::subs_s(sRv, Qs); }
         }
         if constexpr (CHUNK) bndq = shl1(bndq);
-        {
+        if constexpr (!BATCHED) {
             const unsigned shifted = FUSE ? shr1_add32(offv, laneBytesV) : shr1(offv) + (unsigned)LANE_BYTES;
             offv = (k == 0) ? tokq : shifted;
             tokq = shl1(tokq);
@@ -799,7 +809,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
         reg unused = 0;
         {
             constexpr int NBLK = SPAD / RB;
-            int4 pc = lds_ld16(offv);
+            int4 pc = BATCHED ? pfirst : lds_ld16(offv);
             reg d = V::adds(diagIn, (reg)pc.x), t = 0;
             static_for<NBLK>([&](auto rbc) {
                 constexpr int rb = decltype(rbc)::value;
