@@ -164,7 +164,7 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
     auto skew_ok = [&](int item) {
         const long long L0 = lenOf(item);
         // (frame: row position among the slot's G * S <= Q + 512 register rows + column, see dp_kernel.hpp)
-        return std::min<long long>(c.Q, L0) * c.maxScore + (c.Q + 512 + L0 + 64 + 4) * (long long)c.Ge < 32000;
+        return std::min<long long>(c.qBound, L0 * c.maxScore) + (c.Q + 512 + L0 + 64 + 4) * (long long)c.Ge < 32000;
     };
     const bool maySkew = width == 17 && c.mode != OPAL_MODE_SW && !work && !opts().noSkew;
     // One launch for all classes where a one-launch kernel exists (plain 16-bit, no re-run list): see dp_kernel.hpp.
@@ -172,8 +172,8 @@ static int launch_range(const SearchCtx& c, int width, int swEndPass, int detect
     std::vector<LaunchClass> classes;
     std::string key;
     if (!work) {  // (re-run lists differ from search to search: planned every time)
-        char buf[160];
-        snprintf(buf, sizeof buf, "%d/%d/%d/%d/%d/%d/%d/%lld/%d/%d/%d|%s", width, c.mode, swEndPass, c.Q, c.A, c.Go, c.Ge, c.maxScore, firstItem, numItems,
+        char buf[256];
+        snprintf(buf, sizeof buf, "%d/%d/%d/%d/%d/%d/%d/%lld/%lld/%d/%d/%d|%s", width, c.mode, swEndPass, c.Q, c.A, c.Go, c.Ge, c.maxScore, c.qBound, firstItem, numItems,
                  (int)uberEligible, opts().plan_key().c_str());
         key = buf;
         auto it = db->planCache.find(key);
@@ -584,6 +584,18 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
     long long maxS = 0, minS = 0;
     for (int i = 0; i < A * A; i++) { maxS = std::max<long long>(maxS, M[i]); minS = std::min<long long>(minS, M[i]); }
     bool fits16 = Go <= 32767 && Ge <= 32767 && maxS <= 32767 && minS >= -32768;
+    // The largest value any cell can hold (H, E, F and the diagonal sum alike: each is the score of an alignment of two prefixes):
+    // no alignment scores more than its matched query residues against their best letters, gaps only cost (reference recurrence
+    // opal.cpp:748-771). Rounds 1-5 used min(Q, L) * maxS -- twice the true bound for a protein matrix (BLOSUM50: diagonal 5-15), and
+    // with it half of a 2000-aa query's targets beyond 2 000 residues left the skewed 16-bit kernels for no reason.
+    long long qBound = 0;
+    for (int i = 0; i < Q; i++) {
+        long long best = maxS;
+        if ((int)query[i] < A) { best = 0; for (int b = 0; b < A; b++) best = std::max<long long>(best, M[(int)query[i] * A + b]); }
+        qBound += best;
+    }
+    if (opts().noQueryBound) qBound = (long long)Q * maxS;
+    auto hi_bound = [&](long long L) { return std::min<long long>(qBound, L * maxS); };  // (<= min(Q, L) * maxS)
     if (opts().forceWidth == 32) fits16 = false;  // test / profiling hook
 
     // Narrow rung: 17 = plain 16-bit, one sequence per lane (full-rate VALU, 4-byte LDS profile entries); 16 = packed
@@ -668,7 +680,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
     }
     const bool plain = narrow != 16 || splan.G;
     const int satLimit = plain ? (int)(32767 - maxS) : 32767;
-    SearchCtx c{db, Q, A, Go, Ge, mode, wantEnd, dScore, dEndQ, dEndT, satLimit, mode == OPAL_MODE_SW ? -satLimit : 0, maxS};
+    SearchCtx c{db, Q, A, Go, Ge, mode, wantEnd, dScore, dEndQ, dEndT, satLimit, mode == OPAL_MODE_SW ? -satLimit : 0, maxS, qBound};
     const int nNarrow = narrow == 16 ? P : 2 * P;  // items of the narrow rung: pairs or sequences
     const LenView pairLenOf{db->pairLen.data(), 2, nullptr};  // width-16 items are pairs
     const LenView seqLenOf{db->pairLen.data(), 1, nullptr};   // width-17/18/32 items are pair*2+half
@@ -685,7 +697,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
     else if (evStart) opal_hip_event_record(evStart, st);
     // A 16-bit rung whose scores can reach its limit may leave a re-run list (db->ovfItems, one per handle) and reads its length
     // back: such a search waits for the one before it and is waited for as a whole.
-    const bool canSaturate = (long long)std::min<long long>(Q, db->pairLen[0]) * maxS >= (long long)satLimit;
+    const bool canSaturate = hi_bound(db->pairLen[0]) >= (long long)satLimit;
     if (mode == OPAL_MODE_SW && (canSaturate || !fits16) && pipe_resolve(db, st, false)) return OPAL_ERR_NO_SIMD_SUPPORT;
 
     if (mode == OPAL_MODE_SW) {
@@ -818,7 +830,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
             while (p32 < P) {
                 const long long L = db->pairLen[2 * (size_t)p32];
                 const long long lo = 3LL * Go + (Q + L + 2) * (long long)Ge - minS;  // -minS: diag + P must not wrap either
-                const long long hi = std::min<long long>(Q, L) * maxS;
+                const long long hi = hi_bound(L);
                 if (lo < 32768 - 1 && hi < 32767) break;
                 p32++;
             }
@@ -832,7 +844,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
         if (fits16 && p32 < P) {
             long long moved = 0;
             auto skew_safe = [&](long long L) {
-                return std::min<long long>(Q, L) * maxS + (OPAL_HIP_MAX_ROWS + L + 64 + 4) * (long long)Ge < 32000;
+                return hi_bound(L) + (OPAL_HIP_MAX_ROWS + L + 64 + 4) * (long long)Ge < 32000;
             };
             while (q32 < P && !skew_safe(db->pairLen[2 * (size_t)q32])) { moved += db->pairLen[2 * (size_t)q32] + db->pairLen[2 * (size_t)q32 + 1]; q32++; }
             // (a query in row chunks: the unskewable sequences run on the class kernels' chunks on a side stream BESIDE the

@@ -391,6 +391,7 @@ struct SearchCtx {
     int* dScore; int* dEndQ; int* dEndT;
     int satLimit, negPad;  // width 17 (plain 16-bit) parameters
     long long maxScore;    // largest matrix entry (>= 0)
+    long long qBound;      // no cell of this query's DP matrices holds more: every query residue against its best letter (<= Q * maxScore)
     bool zeroCopy = false; // launches read the residues from the pinned staging buffer (db->hRaw) instead of the device copy
     void* stream = nullptr; // launch on this stream instead of the handle's main one (row chunks of a 32-bit prefix beside the 16-bit ones)
     int* sideBlocks = nullptr;  // (launches on `stream`) counts their workgroups: a persistent streaming launch beside them leaves that many CUs free

@@ -102,6 +102,7 @@ const std::vector<Desc>& table() {
         flag("OPAL_HIP_NO_STREAM_HEAD", &Options::noStreamHead),
         flag("OPAL_HIP_NO_STREAM_CHUNKS", &Options::noStreamChunks),
         flag("OPAL_HIP_NO_SKEW", &Options::noSkew),
+        flag("OPAL_HIP_NO_QUERY_BOUND", &Options::noQueryBound),
         flag("OPAL_HIP_NO_UBER", &Options::noUber),
         one_of("OPAL_HIP_PIPELINE", &Options::pipeline, {0, 1, 2}),
         integer("OPAL_HIP_PIPE_SLACK", &Options::pipeSlack, 0, 1 << 20),

@@ -53,6 +53,7 @@ struct Options {
     bool noStreamHead = false;        // OPAL_HIP_NO_STREAM_HEAD
     bool noStreamChunks = false;      // OPAL_HIP_NO_STREAM_CHUNKS
     bool noSkew = false;              // OPAL_HIP_NO_SKEW: NW/HW/OV on the unskewed kernels
+    bool noQueryBound = false;        // OPAL_HIP_NO_QUERY_BOUND: the a-priori score bound of the 16-bit rung from the largest matrix entry alone (rounds 1-5), not from the query's own residues
     bool noUber = false;              // OPAL_HIP_NO_UBER: length classes as separate launches
     bool uberOnly = false;            // OPAL_HIP_UBER_ONLY: keep the one-launch chain whatever the tail
     bool uberLdsPad = true;           // OPAL_HIP_UBER_LDS_PAD=0: length classes as separate launches when the bulk wants a padded LDS request (round 3)

@@ -1153,3 +1153,68 @@ def test_chunked_query_with_32bit_prefix_at_forced_width16(mode, oracle, opal_op
         np.testing.assert_array_equal(s[pick], want[1], err_msg=f"{mode} narrow={narrow}: score")
         np.testing.assert_array_equal(eq[pick], want[2], err_msg=f"{mode} narrow={narrow}: endQ")
         np.testing.assert_array_equal(et[pick], want[3], err_msg=f"{mode} narrow={narrow}: endT")
+
+
+# ---- the a-priori score bound of the 16-bit rung (ladder.cpp: every query residue against its best letter) ----
+_BOUND_M = np.array([[3, 5, -4, -4],     # asymmetric on purpose: query letter 0 scores best against TARGET letter 1 (5 > 3), while
+                     [-4, 7, -4, -4],    # target letter 0 never scores more than 3 -- a bound taken over the wrong index would be too small
+                     [-4, -4, 11, -4],
+                     [-4, -4, -4, 15]], dtype=np.int32)
+
+
+def _bound_case(counts, scale, seed, lengths, fillers=260):
+    """A query with the given letter counts (shuffled), whose bound is scale * (5 n0 + 7 n1 + 11 n2 + 15 n3), and a database that
+    REACHES that bound: the target that pairs every query residue with its best letter, alone and inside random flanks of the
+    given total lengths, near copies of it, and unrelated sequences."""
+    rng = np.random.RandomState(seed)
+    q = np.repeat(np.arange(4, dtype=np.uint8), counts)
+    rng.shuffle(q)
+    best = np.where(q == 0, 1, q).astype(np.uint8)
+    m = (_BOUND_M * scale).astype(np.int32)
+    bound = int(scale * (5 * counts[0] + 7 * counts[1] + 11 * counts[2] + 15 * counts[3]))
+    db = [best.copy()]
+    for L in lengths:
+        extra = max(0, L - len(best))
+        left = int(rng.randint(0, extra + 1))
+        db.append(np.concatenate([rng.randint(0, 4, size=left), best, rng.randint(0, 4, size=extra - left)]).astype(np.uint8))
+    for i in range(12):  # near copies: a few substitutions, one deletion
+        t = best.copy()
+        t[rng.randint(0, len(t), size=1 + i)] = rng.randint(0, 4, size=1 + i)
+        db.append(np.delete(t, int(rng.randint(0, len(t)))) if i % 2 else t)
+    for i in range(fillers):
+        db.append(rng.randint(0, 4, size=int(rng.randint(1, 700))).astype(np.uint8))
+    return q, [db[i] for i in rng.permutation(len(db))], m, bound
+
+
+@pytest.mark.parametrize("mode", ["SW", "NW", "HW", "OV"])
+@pytest.mark.parametrize("which", ["sat-1", "sat", "int16", "int16+2", "skew-edge", "far"])
+def test_scores_that_reach_the_a_priori_bound(mode, which, ours, oracle, opal_opt):
+    """The 16-bit rung is chosen by a bound computed from the query's own residues (every residue against its best letter),
+    and the database holds a target that attains it. The bound sits one below / at the saturation limit of the SW kernels
+    (32767 - the largest entry), at the top of the int16 range and two beyond it, and where the diagonal-skewed kernels stop
+    being safe (bound + (rows + columns) * extension = 32000: targets on either side of it); scheduler's choice and a forced
+    stream of sequences."""
+    if which == "sat-1":      # bound 32736 = 32767 - 30 - 1: "cannot saturate", no re-run list is read
+        counts, scale, ge, lengths = (6, 34, 100, 1000), 2, 1, (1141, 1200, 1500)
+    elif which == "sat":      # bound 32738: may saturate
+        counts, scale, ge, lengths = (2, 37, 100, 1000), 2, 1, (1140, 1200, 1500)
+    elif which == "int16":    # bound 32766: the largest that stays on the 16-bit kernels in NW / HW / OV
+        counts, scale, ge, lengths = (2, 39, 100, 1000), 2, 1, (1141, 1200, 1500)
+    elif which == "int16+2":  # bound 32768: targets of 1093 residues and more need 32 bits
+        counts, scale, ge, lengths = (5, 37, 100, 1000), 2, 1, (1142, 1090, 1093, 1500)
+    elif which == "skew-edge":  # bound 16383, extension 4: the streamed skewed kernels are safe to 1276 columns, the class kernels' to 2182
+        counts, scale, ge, lengths = (2, 39, 100, 1000), 1, 4, tuple(range(1270, 1284)) + tuple(range(2176, 2190))
+    else:                     # bound 16383 with extension 1: everything skewed
+        counts, scale, ge, lengths = (2, 39, 100, 1000), 1, 1, (1141, 1300, 2500, 6000)
+    q, db, m, bound = _bound_case(counts, scale, 77, lengths)
+    go = 3 * ge + 8
+    want = oracle.search(q, db, go, ge, m, 1, MODES[mode])
+    assert int(want[1].max()) == bound, (int(want[1].max()), bound)  # (the bound is attained: free end gaps, or the bare target)
+    for stream in ("", "1"):
+        if stream:
+            opal_opt.set("OPAL_HIP_STREAM", "1")
+        got = ours.search(q, db, go, ge, m, 1, MODES[mode])[:4]
+        _check(got, want, mode, f"bound {which} {mode} stream={stream or 'auto'}")
+    got0 = ours.search(q, db, go, ge, m, 0, MODES[mode])[:4]
+    assert got0[0] == want[0]
+    np.testing.assert_array_equal(got0[1], want[1], err_msg=f"bound {which} {mode} score only")
