@@ -5,7 +5,6 @@
 // another geometry or the class kernels)
 template <int MODE, int ROWS> struct GlFn { static constexpr StreamFn fn = opal_gl_stream<18, MODE, ROWS>; };
 template <> struct GlFn<MODE_OV, 40> { static constexpr StreamFn fn = nullptr; };
-template <> struct GlFn<MODE_OV, 38> { static constexpr StreamFn fn = nullptr; };
 template <> struct GlFn<MODE_OV, 39> { static constexpr StreamFn fn = nullptr; };
 template <> struct GlFn<MODE_NW, 29> { static constexpr StreamFn fn = nullptr; };
 

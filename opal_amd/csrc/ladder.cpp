@@ -825,37 +825,51 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
         // width 32 otherwise. Pairs are sorted by length (descending) and both bounds grow with the
         // length, so the width-32 pairs form a prefix of the pair list.
         int p32 = 0;
-        if (!fits16) p32 = P;
-        else {
-            while (p32 < P) {
-                const long long L = db->pairLen[2 * (size_t)p32];
-                const long long lo = 3LL * Go + (Q + L + 2) * (long long)Ge - minS;  // -minS: diag + P must not wrap either
-                const long long hi = hi_bound(L);
-                if (lo < 32768 - 1 && hi < 32767) break;
-                p32++;
-            }
-        }
         // Long queries on large databases: the 16-bit part as a stream of sequences through persistent waves
         // (stream_kernel.hpp, diagonal-skewed kernels). The few sequences whose skewed values could leave 16 bits (the longest
         // ones) run on the unskewed class body in the first workgroups of the same launch; if they hold more than 2 % of the
         // residues the class kernels run everything.
         StreamPlan gplan;
-        int q32 = p32;  // pairs [p32, q32): 16-bit, but not safe for the skewed stream kernels -> class kernels beside the stream
-        if (fits16 && p32 < P) {
-            long long moved = 0;
-            auto skew_safe = [&](long long L) {
-                return hi_bound(L) + (OPAL_HIP_MAX_ROWS + L + 64 + 4) * (long long)Ge < 32000;
-            };
-            while (q32 < P && !skew_safe(db->pairLen[2 * (size_t)q32])) { moved += db->pairLen[2 * (size_t)q32] + db->pairLen[2 * (size_t)q32 + 1]; q32++; }
-            // (a query in row chunks: the unskewable sequences run on the class kernels' chunks on a side stream BESIDE the
-            // streamed ones, not inside the launch -- they may hold a sixth of the residues before they become the longer side)
-            // (round 5: a sixth also for unchunked queries -- the longest of them now go to the pair kernel, and the alternative to
-            // a stream with a few hundred side workgroups ahead of it is the class kernels at 64 lanes for EVERYTHING: 81 ms
-            // against ~50 for a 2000-aa query on the Swiss-Prot shape, whose unskewable targets hold 2.7 % of the residues)
-            if (q32 < P && (moved * (chunkedQuery ? 6 : (opts().pair != 0 ? 16 : 50)) <= db->residues || opts().stream == 1) && !opts().noSkew) {
-                gplan = plan_stream(Q, A, mode, wantEnd, db->residues - moved, db->pairLen[2 * (size_t)q32], db->numSeqs - 2 * q32);
+        int q32 = 0;  // pairs [p32, q32): 16-bit, but not safe for the skewed stream kernels -> class kernels beside the stream
+        auto plan_rungs = [&](bool queryBound) {
+            auto hi_of = [&](long long L) { return queryBound ? hi_bound(L) : std::min<long long>(Q, L) * maxS; };
+            p32 = 0;
+            if (!fits16) p32 = P;
+            else {
+                while (p32 < P) {
+                    const long long L = db->pairLen[2 * (size_t)p32];
+                    const long long lo = 3LL * Go + (Q + L + 2) * (long long)Ge - minS;  // -minS: diag + P must not wrap either
+                    const long long hi = hi_of(L);
+                    if (lo < 32768 - 1 && hi < 32767) break;
+                    p32++;
+                }
             }
-            if (!gplan.G) q32 = p32;
+            gplan = StreamPlan();
+            q32 = p32;
+            if (fits16 && p32 < P) {
+                long long moved = 0;
+                auto skew_safe = [&](long long L) {
+                    return hi_of(L) + (OPAL_HIP_MAX_ROWS + L + 64 + 4) * (long long)Ge < 32000;
+                };
+                while (q32 < P && !skew_safe(db->pairLen[2 * (size_t)q32])) { moved += db->pairLen[2 * (size_t)q32] + db->pairLen[2 * (size_t)q32 + 1]; q32++; }
+                // (a query in row chunks: the unskewable sequences run on the class kernels' chunks on a side stream BESIDE the
+                // streamed ones, not inside the launch -- they may hold a sixth of the residues before they become the longer side)
+                // (round 5: a sixth also for unchunked queries -- the longest of them now go to the pair kernel, and the alternative to
+                // a stream with a few hundred side workgroups ahead of it is the class kernels at 64 lanes for EVERYTHING: 81 ms
+                // against ~50 for a 2000-aa query on the Swiss-Prot shape, whose unskewable targets hold 2.7 % of the residues)
+                if (q32 < P && (moved * (chunkedQuery ? 6 : (opts().pair != 0 ? 16 : 50)) <= db->residues || opts().stream == 1) && !opts().noSkew) {
+                    gplan = plan_stream(Q, A, mode, wantEnd, db->residues - moved, db->pairLen[2 * (size_t)q32], db->numSeqs - 2 * q32);
+                }
+                if (!gplan.G) q32 = p32;
+            }
+        };
+        plan_rungs(true);
+        // Class-kernel row chunks (a query beyond one wave on a database too small or too long-tailed to stream) keep the looser
+        // bound: the 32-bit prefix it sets aside runs on a side stream BESIDE the chunks of the rest, and that overlap is worth more
+        // there than the 16-bit rate (2600-aa HW x 20 000 sequences: 4.6 ms with the prefix beside them, 5.9 without; NW / OV 2-7 %).
+        if (fits16 && qBound < (long long)Q * maxS && chunkedQuery && !gplan.G) {
+            plan_rungs(false);
+            c.qBound = (long long)Q * maxS;
         }
         int sideBlocks = 0;  // workgroups of the launches that run beside the main range on other streams
         int taken = 0;       // items [.., taken) have been handed to a pair launch (pair_kernel.hpp): every range below starts behind them

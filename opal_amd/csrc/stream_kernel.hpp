@@ -279,8 +279,10 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     // 390 aa on the published shape 10.5 ms drawn, 11.1 dealt)
     const bool deal = !SIDE || sp.sideBlocks == 0;
     const int totalSlots = deal ? streamBlocks * STREAM_WAVES * slots : 0, firstIdx = deal ? (wave * streamBlocks + streamBlock) * slots + slot : -1;
-    auto fetch = [&](const int x) { stream_fetch<2, CHUNK>(st, p, sp.next, ring, x, k, G, slotLane0, PAD, sp.prioItems, firstIdx, totalSlots); };
-    fetch(k);
+    // (the dealt item is the slot's FIRST fetch only: the step loop's fetches do not keep its index alive -- a register the 38- and
+    // 39-row shapes do not have)
+    auto fetch = [&](const int x) { stream_fetch<2, CHUNK>(st, p, sp.next, ring, x, k, G, slotLane0, PAD, sp.prioItems, -1, totalSlots); };
+    stream_fetch<2, CHUNK>(st, p, sp.next, ring, k, k, G, slotLane0, PAD, sp.prioItems, firstIdx, totalSlots);
     unsigned bndq = 0;  // CHUNK: lane queue of the boundary words above the columns of this batch (lane 0 consumes)
     unsigned outq = 0;  // CHUNK: lane queue of the last lane's outputs, oldest towards lane 0
 
@@ -685,7 +687,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
     if constexpr (FUSE) asm volatile("" : "+v"(laneBytesV), "+v"(sr1V));
     SlotStream st;  // the stream of this slot
     int started = 0;                    // entries this lane has begun
-    int myStart = 0, myLen = 0, myNext = 0;  // my current sequence: first stream position, length; where my next one begins
+    int myStart = 0, myNext = 0;  // my current sequence: first stream position; where my next one begins (its last column: xLast)
     int xLast = INT_MIN;                // stream position of its last column (INT_MIN: it has none)
     reg bestF = V::splat(-32768);  // HW/OV: last-row maximum so far, in the skewed frame of the step at hand
     int bestCol = -1;              // its first column
@@ -694,8 +696,8 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
     const int streamBlocks = (int)gridDim.x - sp.sideBlocks, streamBlock = (int)blockIdx.x - sp.sideBlocks;
     const bool deal = sp.sideBlocks == 0;  // (as in opal_sw_stream)
     const int totalSlots = deal ? streamBlocks * STREAM_WAVES * slots : 0, firstIdx = deal ? (wave * streamBlocks + streamBlock) * slots + slot : -1;
-    auto fetch = [&](const int x) { stream_fetch<0, CHUNK>(st, p, sp.next, ring, x, k, G, slotLane0, PAD, sp.prioItems, firstIdx, totalSlots); };
-    fetch(k);
+    auto fetch = [&](const int x) { stream_fetch<0, CHUNK>(st, p, sp.next, ring, x, k, G, slotLane0, PAD, sp.prioItems, -1, totalSlots); };
+    stream_fetch<0, CHUNK>(st, p, sp.next, ring, k, k, G, slotLane0, PAD, sp.prioItems, firstIdx, totalSlots);
     unsigned bndq = 0;     // CHUNK: lane queue of the boundary words above the columns of this batch (lane 0 consumes)
     unsigned outq = 0;     // CHUNK: lane queue of the last lane's outputs (true values), oldest towards lane 0
     unsigned outPack = 0;  // CHUNK: what I produced in the step behind us, out of my frame
@@ -764,12 +766,10 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
                 if (started < st.nEntries) {
                     const int4 d0 = *reinterpret_cast<const int4*>(ring + (started & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4));
                     myStart = d0.x;  // == myNext
-                    myLen = d0.y;
                     myNext = d0.x + max(d0.y, 2 * G);
                     xLast = d0.y > 0 ? d0.x + d0.y - 1 : INT_MIN;
                     started++;
                 } else {  // the stream has run dry: nothing of mine is a result any more
-                    myLen = 0;
                     myNext = INT_MAX;
                     xLast = INT_MIN;
                 }
@@ -851,7 +851,7 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
                 const int seq = ring[((started - 1) & (STREAM_RING - 1)) * (STREAM_DESC_BYTES / 4) + 2];
                 if (seq >= 0) {
                     p.outScore[seq] = v;
-                    if (p.outEndQ) { p.outEndQ[seq] = p.Q - 1; p.outEndT[seq] = myLen - 1; }
+                    if (p.outEndQ) { p.outEndQ[seq] = p.Q - 1; p.outEndT[seq] = x - myStart; }  // (x == xLast: the last column)
                 }
             }
         }
@@ -911,8 +911,8 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_gl_stream(const Stream
                     }
                 }
                 if (MODE == MODE_OV) {
-                    const int prevBest = (myLen > 1) ? V::half(V::subs(prevF, frame), 0) : INT_MIN;
-                    if (lcV > prevBest) { sc = lcV; et = myLen - 1; eq = lcRow; }
+                    const int prevBest = (x > myStart) ? V::half(V::subs(prevF, frame), 0) : INT_MIN;  // (x == xLast here: a sequence of more than one column)
+                    if (lcV > prevBest) { sc = lcV; et = x - myStart; eq = lcRow; }
                 }
                 if (seq >= 0 && !hasNext) {
                     p.outScore[seq] = sc;
