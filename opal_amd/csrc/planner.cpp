@@ -417,6 +417,15 @@ StreamPlan plan_stream(int Q, int A, int mode, int wantEnd, long long residues, 
             // for 2 000 sequences.
         } else if (best.G >= 32) {
             if (crit > 1.5 * total) best = StreamPlan();
+            // (round 6) ... and the rule of the branch below for 32 lanes: with end locations the streams stop at 36 rows per lane, so a
+            // query of 16 x 37..40 rows streams at 32 x 19..20 -- 608 aa on the published shape 25.5 ms against 20.9 on the class
+            // kernels at 16 lanes, 640 aa 25.6 against 22.8, synthetic 541 762 sequences (gaps 11/1) 19.2 against 17.1. Not one step
+            // up: 1216-1280 aa stream at 64 x 19..20 in 47 ms where the class kernels at 32 lanes take 60-66.
+            if (best.G == 32 && wantEnd && mode == OPAL_MODE_SW) {
+                const int needHalf = (Q + 15) / 16;
+                const int rowsHalf = needHalf <= OPAL_HIP_MAX_ROWS ? opal_hip_rows_supported(17, mode, 1, needHalf) : 0;
+                if (rowsHalf && opal_hip_lds_bytes(17, 16, rowsHalf, A) <= 160 * 1024) best = StreamPlan();
+            }
         } else {
             // 16 lanes per sequence or fewer: the class kernels lose little to fill and drain, and streaming only wins
             // (2-4 %: 513-aa query x 625 000 sequences 6 790 -> 7 050 GCUPS, 300-aa x 1 000 000 7 230 -> 7 390) when every

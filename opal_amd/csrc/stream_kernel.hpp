@@ -293,7 +293,10 @@ __global__ void __launch_bounds__(STREAM_WAVES * 64) opal_sw_stream(const Stream
     // read inside the last row block of the current step -- behind the batch refill when the next step starts a batch --, so
     // a step no longer begins by waiting out an LDS round trip (dp_kernel.hpp, PF_LATE: the registers that carry the three
     // reads are live across the step's tail only).
-    constexpr bool LATE = !CHUNK && S <= (SWEND ? 33 : (SIDE ? 37 : 38)) && OPAL_STREAM_PF_LATE != 0;  // (the tallest shapes are two registers short)
+    // (... not at 33 rows per lane and more with 2-byte profile entries, score only: measured on the published shape, 2200 aa = 64 x 35
+    // rows 68.6 ms with it, 63.5 without, 2432 aa = 64 x 38 rows 75.2 / 66.5; at 32 rows and fewer it gains 0-17 %, and with 4-byte
+    // entries at every height -- profiles/r06_ab_stream_late_prefetch.txt)
+    constexpr bool LATE = !CHUNK && S <= (SWEND ? 33 : (SIDE ? 37 : 38)) && !(ES == 2 && !SWEND && S > 32) && OPAL_STREAM_PF_LATE != 0;  // (the tallest shapes are two registers short)
     bool finished = false;
     int4 infoNext = make_int4(0, 0, 0, 0), pfirst = make_int4(0, 0, 0, 0);
     // start of a batch of G steps (wave-uniform): refill the queue with columns s .. s+G-1, fetch those of the next batch
