@@ -256,8 +256,15 @@ int plan_swap(int Q, int A, int mode, LenView lenOf, int first, int count, long 
     // (global modes: 6-instruction rows in the bulk; the long targets mostly on the unskewed 8-instruction rows; the swapped
     // int32 kernel at 9 per row)
     const double totalClocks = (double)residues / (64 / G0) * (gl ? 2.15 * 6.5 * S0 + 90.0 : step_clocks(17, S0)) / 1024.0;
-    const double budget = std::max(totalClocks * (opts().tailFraction > 0 ? opts().tailFraction : 0.7), 20000.0);
-    auto classClocks = [&](int len) { return (len + Gw - 1) * (gl ? 4.8 * (8.0 * Sw + 28.0) : lone_step_clocks(17, Sw)); };
+    // (global modes, round 6: what stays on the class body must fit a THIRD of the search, not 0.7 of it -- the long targets of a
+    // global search run there unskewed, on fewer lanes than the model's 4 G0 where the planner's classes say so, and start behind the
+    // launches in front of them. Forced-count runs on the published shape and its 20 000- / 100 000-sequence heads, 220-513-aa
+    // queries: 40 targets on the swapped kernel beat the model's 15-19 by 15-45 %, and the pair kernel's by 10-80 %:
+    // profiles/r06_planner_sweep_swap_first.txt)
+    const double budget = std::max(totalClocks * (opts().tailFraction > 0 ? opts().tailFraction : (gl ? 0.33 : 0.7)), 20000.0);
+    // (x 1.35 in the global modes, round 6: a 400-aa search of the first 100 000 sequences of the published shape takes 8.1 ms with its
+    // long targets on the class body -- 19 M clocks where this model says 14 -- and 5.8 with 40 of them swapped)
+    auto classClocks = [&](int len) { return (len + Gw - 1) * (gl ? 1.35 * 4.8 * (8.0 * Sw + 28.0) : lone_step_clocks(17, Sw)); };
     // A swapped step is a latency chain with a large fixed part (address -> LDS -> first row, lane hand-off): measured on the
     // published shape, clocks per step: the 16-bit SW kernel 600 at 8 rows per lane, 1 900 at 40; the int32 global kernels 730
     // at 8 rows, 1 060 at 16. (With the first, optimistic model -- 4.8 clocks per instruction -- the planner sent the 5 000-residue
@@ -266,12 +273,25 @@ int plan_swap(int Q, int A, int mode, LenView lenOf, int first, int count, long 
     auto swapClocks = [&](int len) { return (double)((len + 64 * rows - 1) / (64 * rows)) * (Q + 63) * swapStep; };
     const int longest = lenOf(first);
     // (a clear win only: at 64 lanes on the chain the two are within 10 % of each other -- 390-aa query, 35 213 residues)
-    if (classClocks(longest) <= budget || swapClocks(longest) >= 0.7 * classClocks(longest)) return 0;
+    // (round 6, global modes: any win. The 30 % margin kept 160-400-aa queries off the swapped kernel on the published shape --
+    // measured with 40 targets forced there: NW 180 aa 5.9 -> 4.5 ms, 256 aa 7.9 -> 5.8, 320 aa 8.0 -> 6.7: the class body runs
+    // these targets UNSKEWED, one wave each, and they end last)
+    if (classClocks(longest) <= budget || swapClocks(longest) >= (gl ? 1.0 : 0.7) * classClocks(longest)) return 0;
     // the search cannot end before its longest target has, wherever that runs: whatever fits THAT time stays on the chain
-    const double limit = std::max(budget, swapClocks(longest));
+    // (how many: global modes by the round-5 figures -- 0.7 of the search, the uncorrected model; with the new ones a 150-aa search of
+    // 100 000 synthetic sequences counted more than 240 and swapped none, 0.75 ms against 0.67 with its 80)
+    const double limit = std::max(gl ? std::max(totalClocks * (opts().tailFraction > 0 ? opts().tailFraction : 0.7), 20000.0) : budget, swapClocks(longest));
     int n = 0;
-    while (n < count && n <= 240 && classClocks(lenOf(first + n)) > limit) n++;
-    if (n > 240) return 0;
+    while (n < count && n <= 240 && classClocks(lenOf(first + n)) > (gl ? 1.35 : 1.0) * limit) n++;
+    if (n > 240) {  // (not a handful of outliers: a class. Global modes, short queries: the forty longest all the same -- 40 aa x 100 000
+        // synthetic sequences 0.89 ms with none swapped, 0.55 with forty)
+        if (!(gl && Q <= 600)) return 0;
+        n = 40;
+    }
+    // (global modes, queries to 600 residues: forty at least. A swapped workgroup has a CU's LDS to itself and there are 256 CUs; what
+    // the limit above leaves behind -- targets whose modelled time on the class body just fits -- shares CUs eight waves to a workgroup
+    // and ends last: with the model's 10-19 targets 180-400-aa searches of the published shape took 4.7-10.5 ms, with 40: 4.1-8.5)
+    if (gl && Q <= 600) n = std::max(n, std::min(40, count));
     if (debug_on())
         fprintf(stderr, "[opal] swap plan: Q=%d, chain up to %d lanes x %d rows, budget %.0f clocks: the %d longest targets (%d .. %d residues) on the swapped kernel, %d rows per lane (longest: %.0f clocks there, %.0f on the chain)\n",
                 Q, Gw, Sw, budget, n, longest, lenOf(first + n - 1), rows, swapClocks(longest), classClocks(longest));
@@ -317,13 +337,19 @@ int plan_pair(int Q, int A, int mode, LenView lenOf, int first, int count, long 
     if (swapRows && opts().swap != 0) {
         const double swapClocks = (double)((longest + 64 * swapRows - 1) / (64 * swapRows)) * (Q + 63) * 5.0 * (8.3 * swapRows + 80.0);
         if (swapClocks <= pairClocks(longest)) return 0;
+        // (round 6: ... and to 600 residues wherever plan_swap takes anything at all: at 2-3 waves x 2 rows per lane a pair step is all overhead --
+        // 256 aa on the published shape 7.7 ms with 19 targets here, 5.3 with 40 on the swapped kernel; from 700 aa on the pair kernel wins)
+        if (Q <= 600 && need32 <= 240) {
+            int r = 0;
+            if (plan_swap(Q, A, mode, lenOf, first, count, residues, &r, fits16) > 0) return 0;
+        }
     }
     const double limit = std::max(budget, pairClocks(longest));  // the search cannot end before its longest target has
     int n = 0;
     while (n < count && n < 128) {
         const int len = lenOf(first + n);
         const bool wide = n < need32;
-        if (!wide && !(classClocks(len, false) > limit && pairClocks(len) < 0.7 * classClocks(len, false))) break;
+        if (!wide && !(classClocks(len, false) > limit && pairClocks(len) < classClocks(len, false))) break;  // (round 6: any win, as plan_swap)
         n++;
     }
     if (n < need32) return 0;  // (all of the 32-bit ones or none: what is left of them would need the 32-bit class kernels anyway)

@@ -31,7 +31,9 @@ TOL = float(os.environ.get("TOL", "1.10"))
 # (name, options): every alternative the scheduler could have taken; an option that does not apply to a search changes nothing
 ALTS = [("natural", {}), ("stream=0", {"OPAL_HIP_STREAM": "0"}), ("stream=1", {"OPAL_HIP_STREAM": "1"}), ("narrow=16", {"OPAL_HIP_NARROW": "16"}),
         ("narrow=18", {"OPAL_HIP_NARROW": "18"}), ("swap=0", {"OPAL_HIP_SWAP": "0"}), ("no_uber", {"OPAL_HIP_NO_UBER": "1"}),
-        ("qbound=0", {"OPAL_HIP_NO_QUERY_BOUND": "1"}), ("natural", {})]
+        ("qbound=0", {"OPAL_HIP_NO_QUERY_BOUND": "1"})] + \
+       [(f"{k.lower()}={v}", {f"OPAL_HIP_{k}": v}) for k, v in (kv.split("=") for kv in os.environ.get("EXTRA_ALTS", "").split(",") if kv)] + [("natural", {})]
+# (EXTRA_ALTS="SWAP=40,PAIR=40": further forced alternatives for one run)
 # (the natural plan is timed twice, first and last, and the better one counts: whatever runs first in a row starts behind the host
 # work between two rows -- an idle gap that costs the GPU its clock, 2.07 GHz instead of 2.3: 10 % on a 1 ms search)
 import ctypes as C
