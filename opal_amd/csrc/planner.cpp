@@ -256,12 +256,12 @@ int plan_swap(int Q, int A, int mode, LenView lenOf, int first, int count, long 
     // (global modes: 6-instruction rows in the bulk; the long targets mostly on the unskewed 8-instruction rows; the swapped
     // int32 kernel at 9 per row)
     const double totalClocks = (double)residues / (64 / G0) * (gl ? 2.15 * 6.5 * S0 + 90.0 : step_clocks(17, S0)) / 1024.0;
-    // (global modes, round 6: what stays on the class body must fit a THIRD of the search, not 0.7 of it -- the long targets of a
-    // global search run there unskewed, on fewer lanes than the model's 4 G0 where the planner's classes say so, and start behind the
-    // launches in front of them. Forced-count runs on the published shape and its 20 000- / 100 000-sequence heads, 220-513-aa
-    // queries: 40 targets on the swapped kernel beat the model's 15-19 by 15-45 %, and the pair kernel's by 10-80 %:
+    // (global modes, round 6: the gate is the longest target itself -- alone on the class body it must outlast the WHOLE search by the
+    // uncorrected model before anything is swapped. That keeps C3 shut (100 000 synthetic sequences to 5 000 residues, 300-aa query:
+    // 0.95 of the search; forty swapped there cost 3-4 %, tests/test_gpu_fullsize.py holds it) and opens every search the forced-count
+    // runs gained on: published shape 180-320 aa 1.2-1.3, its 20 000- / 100 000-sequence heads and 20 000 synthetic sequences 2-7:
     // profiles/r06_planner_sweep_swap_first.txt)
-    const double budget = std::max(totalClocks * (opts().tailFraction > 0 ? opts().tailFraction : (gl ? 0.33 : 0.7)), 20000.0);
+    const double budget = std::max(totalClocks * (opts().tailFraction > 0 ? opts().tailFraction : (gl ? 1.05 * 1.35 : 0.7)), 20000.0);
     // (x 1.35 in the global modes, round 6: a 400-aa search of the first 100 000 sequences of the published shape takes 8.1 ms with its
     // long targets on the class body -- 19 M clocks where this model says 14 -- and 5.8 with 40 of them swapped)
     auto classClocks = [&](int len) { return (len + Gw - 1) * (gl ? 1.35 * 4.8 * (8.0 * Sw + 28.0) : lone_step_clocks(17, Sw)); };
