@@ -363,6 +363,13 @@ int opalx_debug_pool_selftest(int rounds, int callers);
    `residues`, `longest`, `num_seqs` describe the database. Returns 0. */
 int opalx_debug_plan_stream(int query_length, int alphabet_length, int mode, int want_end, long long residues, int longest,
                             int num_seqs, int* out);
+/* Test hook, no device needed: where the scheduler would send the LONGEST sequences of a search (planner.cpp, plan_pair then
+   plan_swap, as ladder.cpp asks them): out[0] = how many go to the role-swapped kernel (swap_kernel.hpp), out[1] its rows per
+   lane; out[2] = how many to the pair kernel (pair_kernel.hpp; global modes only), out[3] its rows per lane, out[4] its waves.
+   `lengths_desc`: the database's sequence lengths, longest first (`count` of them; the scheduler looks at the head of the list),
+   `residues` their sum over the whole database, `need32` how many of them the a-priori bounds send to the 32-bit rung. Returns 0. */
+int opalx_debug_plan_long_targets(int query_length, int alphabet_length, int mode, const int* lengths_desc, int count,
+                                  long long residues, int need32, int* out);
 /* The library's options (INTEGRATION.md lists them) carry the names of environment variables -- OPAL_HIP_DEVICES,
    OPAL_HIP_DEBUG, the scheduler's test hooks ... The environment is read ONCE, when the library first needs an option; after
    that this call is the way to change one from inside the process (value NULL: back to the default). Values are

@@ -666,6 +666,17 @@ extern "C" int opalx_debug_plan_stream(int query_length, int alphabet_length, in
     return 0;
 }
 
+// Test hook (no device needed): where the longest sequences of a search would go, see include/opal_hip.h.
+extern "C" int opalx_debug_plan_long_targets(int query_length, int alphabet_length, int mode, const int* lengths_desc, int count,
+                                             long long residues, int need32, int* out) {
+    const opal_host::LenView lenOf{lengths_desc, 1, nullptr};
+    int rowsP = 0, wavesP = 0, rowsS = 0;
+    const int pairN = opal_host::plan_pair(query_length, alphabet_length, mode, lenOf, 0, count, residues, need32, true, &rowsP, &wavesP);
+    const int swapN = pairN > 0 ? 0 : opal_host::plan_swap(query_length, alphabet_length, mode, lenOf, 0, count, residues, &rowsS, true);
+    out[0] = swapN; out[1] = swapN ? rowsS : 0; out[2] = pairN; out[3] = pairN ? rowsP : 0; out[4] = pairN ? wavesP : 0;
+    return 0;
+}
+
 // Test hook (no device needed): the ordering of opalx_db_create* / opalSearchDatabase on plain host arrays. Fills
 // seq / len / off (capacity entries each) in item order; returns the number of items (sequences of length > 0, rounded up
 // to even), or -1 if capacity is too small.

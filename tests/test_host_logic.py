@@ -368,8 +368,75 @@ def test_streaming_plan_of_the_scheduler(opal_opt):
     # ... but what is left behind its 128 longest sequences streams on 16 lanes
     w, g, rows, passes = plan(513, nseq=541762 - 128, mean=355, longest=9000)
     assert (w, g, passes) == (17, 16, 1) and rows == 33
+    # SW with end locations at 16 x 37..40 rows (the streams stop at 36): the class kernels at 16 lanes, not a 32-lane stream
+    # (608 aa on the published shape: 25.5 -> 20.8 ms); one step up it streams (1216 aa at 64 x 19: 47 ms against 60)
+    assert plan(608, end=1, nseq=541762, mean=360, longest=5000) == (0, 0, 0, 0)
+    assert plan(560, end=1, nseq=541762, mean=360, longest=5000)[1] == 16
+    assert plan(608, end=0, nseq=541762, mean=360, longest=5000)[1] == 16
+    assert plan(1216, end=1, nseq=541762, mean=360, longest=5000)[1] == 64
     # an alphabet whose profile leaves no room for a streaming geometry
     assert plan(3000, a=250) == (0, 0, 0, 0)
+
+
+def test_long_target_plan_of_the_scheduler(opal_opt):
+    """planner.cpp::plan_pair / plan_swap on the host alone: where the LONGEST sequences of a search go (the role-swapped kernel,
+    the pair kernel, or nowhere: the class body). Round 6 retuned this for the global modes after a query-length scan
+    (DESIGN.md 3.10): the rules below are the measured ones."""
+    import ctypes as C
+    from opal_amd import synth
+    L = C.CDLL(LIB)
+    L.opalx_debug_plan_long_targets.restype = C.c_int
+    L.opalx_debug_plan_long_targets.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_longlong, C.c_int, C.POINTER(C.c_int)]
+    for e in ("OPAL_HIP_SWAP", "OPAL_HIP_PAIR", "OPAL_HIP_TAIL_FRACTION", "OPAL_HIP_SWAP_ROWS"):
+        opal_opt.unset(e)
+    NW, OV, SW = 0, 2, 3
+    cache = {}
+
+    def plan(q, shape, n, mode=NW):
+        if (shape, n) not in cache:
+            lens = np.sort(synth.lengths(42, 0, n, shape))[::-1].astype(np.int32)
+            cache[(shape, n)] = np.ascontiguousarray(lens[lens > 0])
+        lens = cache[(shape, n)]
+        need32 = int((3 * 3 + (q + lens.astype(np.int64) + 2) + 5 >= 32767).sum())  # (the negative bound of ladder.cpp, gaps 3/1)
+        out = (C.c_int * 5)()
+        assert L.opalx_debug_plan_long_targets(q, 24, mode, lens.ctypes.data_as(C.POINTER(C.c_int)), len(lens), int(lens.sum()), need32, out) == 0
+        swapped, _, paired, _, waves = out
+        assert not (swapped and paired)
+        return swapped, paired, need32
+
+    # C3 (100 000 synthetic sequences clamped at 5 000 residues, 300-aa query): the longest target alone does not outlast the
+    # search -- nothing on the role-swapped kernel (forty there cost 3-4 %), a handful on the pair kernel as in round 5
+    for mode in (NW, OV):
+        swapped, paired, _ = plan(300, "c2", 100000, mode)
+        assert swapped == 0 and 0 < paired <= 16
+    # ... nor anything at all on the 541 762-sequence synthetic database, whatever the query
+    for q in (110, 256, 513, 1000):
+        assert plan(q, "c2", 541762)[:2] == (0, 0)
+    # the published shape (tail to 35 213 residues): 160-320-aa global searches send their forty longest targets to the role-swapped
+    # kernel (the model alone said 10-19: 256-aa NW 7.7 ms, with forty 5.3), and the pair kernel takes none of them
+    for q in (180, 256, 300):
+        swapped, paired, need32 = plan(q, "sprot", 541762)
+        assert swapped == 40 and paired == 0 and need32 in (9, 10)
+    assert plan(110, "sprot", 541762)[0] >= 40  # (short queries: as many as the model counts, 43)
+    # from 400 residues on the longest target no longer outlasts that search: the pair kernel, as before
+    for q, least in ((400, 10), (513, 10), (700, 20), (1000, 30)):
+        swapped, paired, need32 = plan(q, "sprot", 541762)
+        assert swapped == 0 and paired >= max(least, need32)
+    # the first 100 000 / 20 000 sequences of it, and 20 000 synthetic ones: the search is shorter, the tail the same -- forty swapped to
+    # 513 aa (400 aa x 100 000: 7.5 -> 5.8 ms), the pair kernel beyond 600
+    for shape, n in (("sprot", 100000), ("sprot", 20000), ("c2", 20000)):
+        for q in (180, 256, 400, 513):
+            assert plan(q, shape, n)[:2] == (40, 0), (shape, n, q)
+        swapped, paired, _ = plan(700, shape, n)
+        assert swapped == 0 and paired > 0
+    # more than 240 candidates (a 40-aa query: every 1 000-residue sequence outlasts its share): the forty longest, not none
+    assert plan(40, "c2", 100000)[:2] == (40, 0)
+    # SW keeps the round-5 rule (a 30 % modelled win, at most 240): the published shape's tail at short queries only
+    assert plan(110, "sprot", 541762, SW)[0] > 40 and plan(513, "sprot", 541762, SW)[:2] == (0, 0)
+    assert plan(300, "c2", 100000, SW)[:2] == (0, 0)
+    # the test hook still forces a count
+    opal_opt.set("OPAL_HIP_SWAP", "7")
+    assert plan(300, "c2", 100000)[0] == 7
 
 
 def test_swend_slot_buffer_geometry():
