@@ -412,7 +412,7 @@ std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass, int sk
 bool plan_chunks(int width, int mode, int swEndPass, int Q, int A, long long nItems, double meanLen, int maxLen, int* G, int* rows, int* wpb);
 struct StreamPlan { int width = 0, G = 0, rows = 0, passes = 1; };  // passes > 1: the query runs in that many row chunks
 StreamPlan plan_stream(int Q, int A, int mode, int wantEnd, long long residues, int longest, int numSeqs);
-int plan_swap(int Q, int A, int mode, LenView lenOf, int first, int count, long long residues, int* rowsOut, bool fits16 = true);  // items for swap_kernel.hpp (0: none)
+int plan_swap(int Q, int A, int mode, LenView lenOf, int first, int count, long long residues, int* rowsOut, bool fits16 = true, bool quiet = false);  // items for swap_kernel.hpp (0: none)
 // items for pair_kernel.hpp (0: none): the targets that need 32 bits (need32 of them, a prefix) and the ones behind them that would
 // outlast the search alone on a wave; rows / waves: the kernel's shape for this query
 int plan_pair(int Q, int A, int mode, LenView lenOf, int first, int count, long long residues, int need32, bool fits16, int* rowsOut, int* wavesOut);

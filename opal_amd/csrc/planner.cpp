@@ -235,7 +235,7 @@ std::vector<LaunchClass> plan_classes(int width, int mode, int swEndPass, int sk
  * (Q + 63) steps per chunk of 64 x rows residues -- provided it is the faster place for the longest of them and there are
  * no more of them than CUs (one workgroup fills most of a CU's LDS: the kernel is for a handful of outliers, not a class).
  */
-int plan_swap(int Q, int A, int mode, LenView lenOf, int first, int count, long long residues, int* rowsOut, bool fits16) {
+int plan_swap(int Q, int A, int mode, LenView lenOf, int first, int count, long long residues, int* rowsOut, bool fits16, bool quiet) {
     *rowsOut = 0;
     const int forced = opts().swap;  // 0: never; N > 0 (test hook): the N longest items whatever the model says
     if (forced == 0) return 0;
@@ -292,7 +292,7 @@ int plan_swap(int Q, int A, int mode, LenView lenOf, int first, int count, long 
     // the limit above leaves behind -- targets whose modelled time on the class body just fits -- shares CUs eight waves to a workgroup
     // and ends last: with the model's 10-19 targets 180-400-aa searches of the published shape took 4.7-10.5 ms, with 40: 4.1-8.5)
     if (gl && Q <= 600) n = std::max(n, std::min(40, count));
-    if (debug_on())
+    if (debug_on() && !quiet)
         fprintf(stderr, "[opal] swap plan: Q=%d, chain up to %d lanes x %d rows, budget %.0f clocks: the %d longest targets (%d .. %d residues) on the swapped kernel, %d rows per lane (longest: %.0f clocks there, %.0f on the chain)\n",
                 Q, Gw, Sw, budget, n, longest, lenOf(first + n - 1), rows, swapClocks(longest), classClocks(longest));
     return n;
@@ -341,7 +341,7 @@ int plan_pair(int Q, int A, int mode, LenView lenOf, int first, int count, long 
         // 256 aa on the published shape 7.7 ms with 19 targets here, 5.3 with 40 on the swapped kernel; from 700 aa on the pair kernel wins)
         if (Q <= 600 && need32 <= 240) {
             int r = 0;
-            if (plan_swap(Q, A, mode, lenOf, first, count, residues, &r, fits16) > 0) return 0;
+            if (plan_swap(Q, A, mode, lenOf, first, count, residues, &r, fits16, /*quiet=*/true) > 0) return 0;
         }
     }
     const double limit = std::max(budget, pairClocks(longest));  // the search cannot end before its longest target has
