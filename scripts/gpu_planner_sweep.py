@@ -5,7 +5,8 @@ MISS when the natural plan is more than 10 % behind the best alternative. Result
 
   python3 scripts/gpu_planner_sweep.py            the full grid (minutes of GPU time), table on stdout
   SWEEP=quick python3 scripts/gpu_planner_sweep.py   the grid tests/test_gpu_planner.py runs
-Environment: QS, NS, SHAPES, MODES, TYPES (comma lists) narrow the grid; REPS (default 3) searches per timing (median).
+Environment: QS, NS, SHAPES, MODES, TYPES (comma lists) narrow the grid; REPS (default 3) searches per timing (median);
+CONFIRM (default 2): a row beyond the tolerance is timed again that many times before it counts; EXTRA_ALTS="SWAP=40,PAIR=40".
 Exit code 1 if any miss (or any result mismatch)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,6 +29,7 @@ MODES = env_list("MODES", ["SW", "HW"] if quick else ["SW", "NW", "HW", "OV"], s
 TYPES = env_list("TYPES", [0, 1])
 REPS = int(os.environ.get("REPS", "3"))
 TOL = float(os.environ.get("TOL", "1.10"))
+CONFIRM = int(os.environ.get("CONFIRM", "2"))  # rounds of re-timing before a row counts as a miss (0: none)
 # (name, options): every alternative the scheduler could have taken; an option that does not apply to a search changes nothing
 ALTS = [("natural", {}), ("stream=0", {"OPAL_HIP_STREAM": "0"}), ("stream=1", {"OPAL_HIP_STREAM": "1"}), ("narrow=16", {"OPAL_HIP_NARROW": "16"}),
         ("narrow=18", {"OPAL_HIP_NARROW": "18"}), ("swap=0", {"OPAL_HIP_SWAP": "0"}), ("no_uber", {"OPAL_HIP_NO_UBER": "1"}),
@@ -67,36 +69,54 @@ for shape in SHAPES:
                     if cells1 * Q > 6e12:
                         continue
                     times, ref, paths = [], None, []
-                    for name, o in ALTS:
-                        c0 = counters()
+
+                    def time_alt(name, o, out, check):
+                        """median kernel ms of REPS searches under the options `o` (nan: the search failed); check: compare / keep the results"""
                         for k, v in o.items():
                             opal_amd.set_option(k, v)
                         try:
                             ks = []
-                            out = outs[0] if (name == "natural" and ref is None) else outs[1]
                             out.fill_(-7)
                             for rep in range(REPS + 1):  # (the first one untimed: launch plans, first use of a kernel shape)
                                 rc, k = pdb.search_device(q, 3 if shape == "sprot" else 11, 1, m, st, opal_amd.MODES[mode], out.data_ptr(),
                                                           out[n:].data_ptr() if st else 0, out[2 * n:].data_ptr() if st else 0)
                                 if rep: ks.append(k)
                             if rc not in (0, 1):
-                                times.append(float("nan")); continue
-                            times.append(float(np.median(ks)))
-                            got = out[: (3 if st else 1) * n]
+                                return float("nan"), None
+                            return float(np.median(ks)), (out[: (3 if st else 1) * n] if check else None)
+                        finally:
+                            for k in o:
+                                opal_amd.set_option(k, None)
+
+                    for name, o in ALTS:
+                        c0 = counters()
+                        t, got = time_alt(name, o, outs[0] if (name == "natural" and ref is None) else outs[1], True)
+                        times.append(t)
+                        if got is not None:
                             if ref is None:
                                 ref = got.clone()
                             elif not torch.equal(ref, got):
                                 mismatches.append((shape, n, Q, mode, st, name))
-                        finally:
-                            for k in o:
-                                opal_amd.set_option(k, None)
-                            paths.append(path(counters() - c0))
+                        paths.append(path(counters() - c0))
                     times[0] = min(times[0], times[-1]); times.pop(); paths.pop()
                     best = np.nanmin(times)
                     ratio = times[0] / best
+                    confirmed = ""
+                    if ratio > TOL and CONFIRM > 0:
+                        # a row beyond the tolerance is timed again, the natural plan and the best alternative in turn: searches of a
+                        # millisecond move by 10 % with the clock and with whatever ran before them, and a miss must be one twice
+                        bi = int(np.nanargmin(times))
+                        tn, tb = [times[0]], [times[bi]]
+                        for _ in range(CONFIRM):
+                            tb.append(time_alt(ALTS[bi][0], ALTS[bi][1], outs[1], False)[0])
+                            tn.append(time_alt("natural", {}, outs[1], False)[0])
+                        again = float(np.nanmin(tn)) / float(np.nanmin(tb))
+                        confirmed = f" (again: {again:.3f})"
+                        if again <= TOL:
+                            ratio = again
                     rows += 1
                     flag = "  MISS" if ratio > TOL else ""
-                    print(f"  {shape:5s} {n:7d} {Q:5d} {mode:4s} {st:3d} | " + " ".join(f"{t:10.3f}" for t in times) + f" | {ratio:6.3f}  {ALTS[int(np.nanargmin(times))][0]}{flag}  [natural: {paths[0]}" + (f"; best: {paths[int(np.nanargmin(times))]}" if ratio > 1.03 else "") + "]", flush=True)
+                    print(f"  {shape:5s} {n:7d} {Q:5d} {mode:4s} {st:3d} | " + " ".join(f"{t:10.3f}" for t in times) + f" | {ratio:6.3f}  {ALTS[int(np.nanargmin(times))][0]}{flag}  [natural: {paths[0]}" + (f"; best: {paths[int(np.nanargmin(times))]}" if ratio > 1.03 else "") + "]" + confirmed, flush=True)
                     if ratio > TOL:
                         misses.append((shape, n, Q, mode, st, ratio, ALTS[int(np.nanargmin(times))][0]))
         del pdb, d_res, outs
