@@ -363,6 +363,10 @@ int opalx_debug_pool_selftest(int rounds, int callers);
    `residues`, `longest`, `num_seqs` describe the database. Returns 0. */
 int opalx_debug_plan_stream(int query_length, int alphabet_length, int mode, int want_end, long long residues, int longest,
                             int num_seqs, int* out);
+/* Test hook, no device needed: the a-priori bound on every DP value of a search with this query -- the sum over its residues of
+   the best score the matrix gives that residue against any letter (score_matrix[query_letter * alphabet_length + target_letter],
+   as opal.h), at least 0 per residue -- which decides what may run on the 16-bit kernels (ladder.cpp). */
+long long opalx_debug_score_bound(const unsigned char* query, int query_length, const int* score_matrix, int alphabet_length);
 /* Test hook, no device needed: where the scheduler would send the LONGEST sequences of a search (planner.cpp, plan_pair then
    plan_swap, as ladder.cpp asks them): out[0] = how many go to the role-swapped kernel (swap_kernel.hpp), out[1] its rows per
    lane; out[2] = how many to the pair kernel (pair_kernel.hpp; global modes only), out[3] its rows per lane, out[4] its waves.

@@ -666,6 +666,11 @@ extern "C" int opalx_debug_plan_stream(int query_length, int alphabet_length, in
     return 0;
 }
 
+// Test hook (no device needed): the score bound the 16-bit rung is planned with, see include/opal_hip.h.
+extern "C" long long opalx_debug_score_bound(const unsigned char* query, int query_length, const int* score_matrix, int alphabet_length) {
+    return opal_host::query_score_bound(query, query_length, score_matrix, alphabet_length);
+}
+
 // Test hook (no device needed): where the longest sequences of a search would go, see include/opal_hip.h.
 extern "C" int opalx_debug_plan_long_targets(int query_length, int alphabet_length, int mode, const int* lengths_desc, int count,
                                              long long residues, int need32, int* out) {

@@ -415,6 +415,22 @@ static int stream_prio_items(const OpalxDb* db, int firstItem, int numItems, int
     return (int)std::min<long long>(lo, slots / 8);
 }
 
+// The largest value any DP cell of this query can hold: every query residue against its best letter (never less than 0 per
+// residue: a residue may stay unaligned in SW and costs a gap, not a match, elsewhere -- and a bound may be loose, never tight
+// from below). A residue outside the alphabet counts with the largest entry of the matrix. See search_core.
+long long query_score_bound(const unsigned char* query, int Q, const int* M, int A) {
+    long long maxS = 0;
+    for (int i = 0; i < A * A; i++) maxS = std::max<long long>(maxS, M[i]);
+    long long rowMax[256];
+    for (int r = 0; r < 256; r++) {
+        rowMax[r] = maxS;
+        if (r < A) { rowMax[r] = 0; for (int b = 0; b < A; b++) rowMax[r] = std::max<long long>(rowMax[r], M[r * A + b]); }
+    }
+    long long bound = 0;
+    for (int i = 0; i < Q; i++) bound += rowMax[query[i]];
+    return bound;
+}
+
 // reference opal.cpp:178-198 / :610-630 at 32 bits
 bool args_fit_int32(int Go, int Ge, const int* M, int A) {
     const int lo = INT_MIN / 2, hi = INT_MAX / 2;
@@ -588,12 +604,7 @@ int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, 
     // no alignment scores more than its matched query residues against their best letters, gaps only cost (reference recurrence
     // opal.cpp:748-771). Rounds 1-5 used min(Q, L) * maxS -- twice the true bound for a protein matrix (BLOSUM50: diagonal 5-15), and
     // with it half of a 2000-aa query's targets beyond 2 000 residues left the skewed 16-bit kernels for no reason.
-    long long qBound = 0;
-    for (int i = 0; i < Q; i++) {
-        long long best = maxS;
-        if ((int)query[i] < A) { best = 0; for (int b = 0; b < A; b++) best = std::max<long long>(best, M[(int)query[i] * A + b]); }
-        qBound += best;
-    }
+    long long qBound = query_score_bound(query, Q, M, A);
     if (opts().noQueryBound) qBound = (long long)Q * maxS;
     auto hi_bound = [&](long long L) { return std::min<long long>(qBound, L * maxS); };  // (<= min(Q, L) * maxS)
     if (opts().forceWidth == 32) fits16 = false;  // test / profiling hook

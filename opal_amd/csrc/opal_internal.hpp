@@ -417,6 +417,7 @@ int plan_swap(int Q, int A, int mode, LenView lenOf, int first, int count, long 
 // outlast the search alone on a wave; rows / waves: the kernel's shape for this query
 int plan_pair(int Q, int A, int mode, LenView lenOf, int first, int count, long long residues, int need32, bool fits16, int* rowsOut, int* wavesOut);
 
+long long query_score_bound(const unsigned char* query, int Q, const int* M, int A);  // ladder.cpp: the a-priori bound of the 16-bit rung
 bool args_fit_int32(int Go, int Ge, const int* M, int A);
 int ensure_query_buffers(OpalxDb* db, const unsigned char* query, int Q, const int* M, int A);
 int search_core(OpalxDb* db, const unsigned char* query, int Q, int Go, int Ge, const int* M, int A, int searchType, int mode,

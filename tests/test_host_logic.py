@@ -378,6 +378,42 @@ def test_streaming_plan_of_the_scheduler(opal_opt):
     assert plan(3000, a=250) == (0, 0, 0, 0)
 
 
+def test_score_bound_of_the_16_bit_rung():
+    """ladder.cpp::query_score_bound on the host alone: every query residue against its best letter, the QUERY letter on the rows of
+    the matrix (score_matrix[query * A + target], as opal.h and opal.cpp:260-268), never below 0 per residue, the largest entry
+    for a residue outside the alphabet. (tests/test_gpu_parity.py::test_scores_that_reach_the_a_priori_bound holds searches whose
+    scores attain it.)"""
+    import ctypes as C
+    from opal_amd.score_matrix import blosum50
+    L = C.CDLL(LIB)
+    L.opalx_debug_score_bound.restype = C.c_longlong
+    L.opalx_debug_score_bound.argtypes = [C.POINTER(C.c_ubyte), C.c_int, C.POINTER(C.c_int), C.c_int]
+
+    def bound(q, m):
+        q = np.ascontiguousarray(q, dtype=np.uint8); m = np.ascontiguousarray(m, dtype=np.int32)
+        a = int(round(m.size ** 0.5))
+        return int(L.opalx_debug_score_bound(q.ctypes.data_as(C.POINTER(C.c_ubyte)), len(q), m.ctypes.data_as(C.POINTER(C.c_int)), a))
+
+    # asymmetric: query letter 0 scores 5 against target letter 1, target letter 0 never more than 3
+    m = np.array([[3, 5, -4, -4], [-4, 7, -4, -4], [-4, -4, 11, -4], [-4, -4, -4, 15]], dtype=np.int32)
+    assert bound([0], m) == 5 and bound([1], m) == 7 and bound([0, 1, 2, 3, 3], m) == 5 + 7 + 11 + 15 + 15
+    assert bound([], m) == 0
+    # a letter that scores negative against everything contributes nothing; one outside the alphabet the largest entry
+    m2 = np.array([[-2, -3], [-1, 6]], dtype=np.int32)
+    assert bound([0, 0, 1], m2) == 6 and bound([7], m2) == 6 and bound([0, 200, 1], m2) == 12
+    # random queries under BLOSUM50 and a random asymmetric matrix: the numpy restatement; never above Q x the largest entry
+    rng = np.random.RandomState(3)
+    b50 = np.asarray(blosum50()[1], dtype=np.int32).reshape(24, 24)
+    for mat in (b50, rng.randint(-9, 12, size=(24, 24)).astype(np.int32)):
+        for qlen in (1, 17, 400, 2000):
+            q = rng.randint(0, 24, size=qlen).astype(np.uint8)
+            want = int(np.maximum(mat[q].max(axis=1), 0).sum())
+            assert bound(q, mat) == want <= qlen * int(mat.max())
+    # a 2000-aa protein query under BLOSUM50: less than half of length x 15, which is what keeps its mid-length targets on the 16-bit kernels
+    from opal_amd import synth
+    assert bound(synth.query(2000, seed=7), b50) == 13181
+
+
 def test_long_target_plan_of_the_scheduler(opal_opt):
     """planner.cpp::plan_pair / plan_swap on the host alone: where the LONGEST sequences of a search go (the role-swapped kernel,
     the pair kernel, or nowhere: the class body). Round 6 retuned this for the global modes after a query-length scan
