@@ -3,6 +3,7 @@ the host traceback (opalx_find_alignments) against the reference's recorded alig
 import ctypes as C
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -376,6 +377,19 @@ def test_streaming_plan_of_the_scheduler(opal_opt):
     assert plan(1216, end=1, nseq=541762, mean=360, longest=5000)[1] == 64
     # an alphabet whose profile leaves no room for a streaming geometry
     assert plan(3000, a=250) == (0, 0, 0, 0)
+
+
+def test_no_kernel_keeps_dp_state_in_scratch():
+    """The DP kernels are built with resource remarks and the build itself fails on a spilled VGPR or a demoted register array
+    (opal_amd/csrc/Makefile, inst_%.o); `make check-scratch` applies the same rule to the remarks of the objects as built --
+    seconds, nothing is recompiled when the library is up to date -- and lists the kernels that park SGPRs."""
+    import shutil
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("no hipcc here")
+    p = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "opal_amd", "csrc"), "-j8", "check-scratch"], capture_output=True, text=True, timeout=3000)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "no kernel uses scratch for DP state" in p.stdout
+    assert "VGPR spills" not in p.stdout
 
 
 def test_score_bound_of_the_16_bit_rung():
